@@ -1,0 +1,113 @@
+"""Seeded synthetic weights / inputs for the LRP hot path.
+
+No trained checkpoints or datasets can be fetched, so parity tests, the golden
+generator (tests/golden/make_golden.py) and bench.py all draw weights from the
+same seeded generators.  The ORDER of the RandomState draws is part of the
+fixture contract: full-size golden files store only the seed.
+
+Weight naming follows the Keras layers the reference reads them from
+(models/explainers.py:264-278 adaptive, :1000-1019 grid-TD); every matrix is
+(input_dim, output_dim), i.e. y = x @ W + b, LSTM gate order i,f,g,o.
+"""
+import numpy as np
+
+
+def _n(rs, *shape, fan_in=None):
+    s = 1.0 if fan_in is None else 1.0 / np.sqrt(fan_in)
+    return (rs.standard_normal(shape) * s).astype(np.float32)
+
+
+def adaptive_weights(rs, L, D, H, E, V):
+    """Adaptive-attention decoder (model.py:415-604)."""
+    assert E == H
+    w = {}
+    w["image_features_W"] = _n(rs, D, H, fan_in=D)
+    w["image_features_b"] = _n(rs, H) * 0.1
+    w["global_W"] = _n(rs, D, E, fan_in=D)
+    w["global_b"] = _n(rs, E) * 0.1
+    w["embedding"] = _n(rs, V, E) * 0.5
+    w["lstm_Wi"] = _n(rs, 2 * E, 4 * H, fan_in=2 * E)
+    w["lstm_Wh"] = _n(rs, H, 4 * H, fan_in=H)
+    w["lstm_b"] = _n(rs, 4 * H) * 0.1
+    w["Wv"] = _n(rs, H, H, fan_in=H)
+    w["Wg"] = _n(rs, H, H, fan_in=H)
+    w["V"] = _n(rs, H, 1, fan_in=H)
+    w["Wx"] = _n(rs, 2 * E, H, fan_in=2 * E)
+    w["Wh"] = _n(rs, H, H, fan_in=H)
+    w["Ws"] = _n(rs, H, H, fan_in=H)
+    w["output_W"] = _n(rs, H, V, fan_in=H)
+    w["output_b"] = _n(rs, V) * 0.1
+    return w
+
+
+def gridtd_weights(rs, L, D, H, E, V):
+    """Grid-TD (bottom-up/top-down) decoder (model.py:609-823)."""
+    w = {}
+    w["image_features_W"] = _n(rs, D, H, fan_in=D)
+    w["image_features_b"] = _n(rs, H) * 0.1
+    w["global_W"] = _n(rs, D, E, fan_in=D)
+    w["global_b"] = _n(rs, E) * 0.1
+    w["embedding"] = _n(rs, V, E) * 0.5
+    w["td_Wi"] = _n(rs, H + 2 * E, 4 * H, fan_in=H + 2 * E)
+    w["td_Wh"] = _n(rs, H, 4 * H, fan_in=H)
+    w["td_b"] = _n(rs, 4 * H) * 0.1
+    w["lang_Wi"] = _n(rs, 2 * H, 4 * H, fan_in=2 * H)
+    w["lang_Wh"] = _n(rs, H, 4 * H, fan_in=H)
+    w["lang_b"] = _n(rs, 4 * H) * 0.1
+    w["W_va"] = _n(rs, H, H, fan_in=H)
+    w["W_ha"] = _n(rs, H, H, fan_in=H)
+    w["W_a"] = _n(rs, H, 1, fan_in=H)
+    w["W_x"] = _n(rs, H + 2 * E, H, fan_in=H + 2 * E)
+    w["W_h"] = _n(rs, H, H, fan_in=H)
+    w["W_s"] = _n(rs, H, H, fan_in=H)
+    w["output_W"] = _n(rs, H, V, fan_in=H)
+    w["output_b"] = _n(rs, V) * 0.1
+    return w
+
+
+def decoder_inputs(rs, L, D, V, T):
+    """CNN feature map (1, sqrt L, sqrt L, D) >= 0 and a caption of T word ids
+    followed by EOS (tokenizer ids: EOS=1, SOS=2, words >= 3; model column = id-1,
+    preprocessors.py:179-189)."""
+    g = int(round(np.sqrt(L)))
+    feat = np.maximum(rs.standard_normal((1, g, g, D)), 0).astype(np.float32)
+    cap = [int(c) for c in rs.randint(3, V + 1, size=T)] + [1]
+    return feat, cap
+
+
+def decoder_case(kind, seed, L, D, H, V, T):
+    """Everything a golden decoder case is built from, in fixture draw order."""
+    rs = np.random.RandomState(seed)
+    w = (adaptive_weights if kind == "adaptive" else gridtd_weights)(rs, L, D, H, H, V)
+    feat, cap = decoder_inputs(rs, L, D, V, T)
+    return w, feat, cap
+
+
+# --------------------------------------------------------------------------- CNN
+VGG16_CFG = [  # (name, C_in, C_out, pool_after)   keras.applications.vgg16 up to block5_conv3
+    ("block1_conv1", 3, 64, False), ("block1_conv2", 64, 64, True),
+    ("block2_conv1", 64, 128, False), ("block2_conv2", 128, 128, True),
+    ("block3_conv1", 128, 256, False), ("block3_conv2", 256, 256, False), ("block3_conv3", 256, 256, True),
+    ("block4_conv1", 256, 512, False), ("block4_conv2", 512, 512, False), ("block4_conv3", 512, 512, True),
+    ("block5_conv1", 512, 512, False), ("block5_conv2", 512, 512, False), ("block5_conv3", 512, 512, False),
+]
+
+
+def vgg_weights(rs, cfg=VGG16_CFG, bias_std=0.05):
+    """He-normal HWIO kernels (3,3,Cin,Cout) and mixed-sign biases (exercise the
+    b+/b- split of relevance_rule.py:256-260).  ImageNet weights cannot be fetched."""
+    w = {}
+    for name, cin, cout, _ in cfg:
+        w[name + "_W"] = (rs.standard_normal((3, 3, cin, cout)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+        w[name + "_b"] = (rs.standard_normal((cout,)) * bias_std).astype(np.float32)
+    return w
+
+
+def images(rs, B, H=224, W=224):
+    """BGR 'caffe'-mode preprocessed images: U[0,255] - mean (preprocessors.py:43-44)."""
+    mean = np.array([103.939, 116.779, 123.68], dtype=np.float32)
+    return (rs.uniform(0, 255, size=(B, H, W, 3)).astype(np.float32) - mean).astype(np.float32)
+
+
+def captions(rs, B, T, V):
+    return [[int(c) for c in rs.randint(3, V + 1, size=T)] + [1] for _ in range(B)]

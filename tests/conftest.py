@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def rel_l1(a, b):
+    """sum|a-b| / sum|b| — the parity metric of BASELINE.json / SURVEY.md §8d."""
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = np.abs(b).sum()
+    return float(np.abs(a - b).sum() / den) if den else float(np.abs(a - b).sum())
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
