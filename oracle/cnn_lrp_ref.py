@@ -1,0 +1,209 @@
+"""ORACLE — test infrastructure only (never imported by the product path).
+
+CPU restatement of the CNN half of the hot path: what
+`LRPSequentialPresetA(image_model, epsilon=0.01, neuron_selection_mode='replace')
+ .analyze([X, R])` computes (models/explainers.py:32, :179-181).
+
+The reference only *builds a Keras graph*; the numbers come from TensorFlow
+1.x kernels (conv2d, conv2d_backprop_input, max_pool_grad reached through
+tf.gradients — innvestigate/utils/keras/backend.py:45-60).  TensorFlow is
+absent here and the reference pins no numeric values at this boundary
+(innvestigate/utils/tests/dryrun.py:103-116 asserts shape / finite only), so
+for the CNN half **parity is unpinned by reference fixtures**: this file is a
+literal restatement of the published graph semantics, written with
+torch.autograd.grad so that each `GradientWRT` (innvestigate/layers.py:138-157)
+maps one-to-one, and it is pinned by hand-computed known-answer tests
+(tests/test_oracle_cnn.py).
+
+Rules restated (RR = innvestigate/analyzer/relevance_based/relevance_rule.py,
+RA = .../relevance_analyzer.py, IL = innvestigate/layers.py,
+KG = innvestigate/utils/keras/graph.py, AB = innvestigate/analyzer/base.py):
+  * preset table: Dense -> EpsilonRule(eps, bias=False), Conv -> Alpha1Beta0Rule
+    (RA:695-721)
+  * AlphaBetaRule.apply with alpha=1, beta=0 (RR:274-322): x+/x- split with
+    >=0 / <0 masks (RR:279-280), w+/w- AND b+/b- split (RR:256-260, bias kept
+    RR:262-271), Z = Z1 + Z2, SafeDivide, two gradient calls, multiply by
+    x+ / x-, add; inhibitor branch skipped because beta == 0 (RR:314-322)
+  * SafeDivide: a / (b + [b == 0] * 1e-7)  (IL:446-461)
+  * layer activation stripped for the rule's forward copies
+    (KG:244-264); relevance passes through the fused ReLU unchanged
+  * MaxPooling2D etc: plain gradient with R as grad_ys (RA:470-480)
+  * EpsilonRule (RR:113-144), BatchNorm / Add reverse layers (RA:197-286)
+    for completeness of the rule set the captioning code can reach
+  * head: relevance of the model output := the injected second input
+    (KG:898-900); result returned for the image input only (KG:938)
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SAFE_EPS = 1e-7      # K.epsilon(), IL:449-451
+
+
+def safe_divide(a, b):
+    """IL:446-461."""
+    return a / (b + (b == 0).to(b.dtype) * SAFE_EPS)
+
+
+# ----------------------------------------------------------------------------
+# network description: list of ("conv", W_hwio, b) / ("pool",) entries
+# ----------------------------------------------------------------------------
+def vgg_layers(weights, cfg):
+    """cfg: lrp_imagecaptioning_amd.synthetic.VGG16_CFG-style list."""
+    layers = []
+    for name, cin, cout, pool_after in cfg:
+        layers.append(("conv", weights[name + "_W"], weights[name + "_b"]))
+        if pool_after:
+            layers.append(("pool",))
+    return layers
+
+
+def _t(a, dtype):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(dtype)
+
+
+def _nchw(x):       # (N,H,W,C) -> (N,C,H,W)
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _w_oihw(W_hwio, dtype):
+    return _t(W_hwio, dtype).permute(3, 2, 0, 1).contiguous()
+
+
+def forward(layers, x_nhwc, dtype=torch.float64, return_inputs=False):
+    """Keras forward of the truncated encoder: conv3x3 'same' + ReLU, 2x2/2
+    max-pool 'valid'.  Returns the (N,h,w,C) feature map (post-ReLU, the
+    output of block5_conv3, models/explainers.py:29-30)."""
+    x = _nchw(_t(x_nhwc, dtype))
+    inputs = []
+    for L in layers:
+        inputs.append(x)
+        if L[0] == "conv":
+            x = F.relu(F.conv2d(x, _w_oihw(L[1], dtype), _t(L[2], dtype), padding=1))
+        else:
+            x = F.max_pool2d(x, 2, 2)
+    out = _nhwc(x).numpy()
+    return (out, inputs) if return_inputs else out
+
+
+def alpha1beta0_conv(x, W_hwio, b, R, dtype):
+    """RR:274-322 for one Conv2D (NCHW tensors), literal: 2 forward convs, one
+    SafeDivide, 2 gradient calls."""
+    w = _w_oihw(W_hwio, dtype)
+    bias = _t(b, dtype)
+    wp, wn = w * (w >= 0).to(dtype), w * (w < 0).to(dtype)
+    bp, bn = bias * (bias >= 0).to(dtype), bias * (bias < 0).to(dtype)
+    x1 = (x * (x >= 0).to(dtype)).detach().requires_grad_(True)
+    x2 = (x * (x < 0).to(dtype)).detach().requires_grad_(True)
+    Z1 = F.conv2d(x1, wp, bp, padding=1)
+    Z2 = F.conv2d(x2, wn, bn, padding=1)
+    S = safe_divide(R, (Z1 + Z2).detach())
+    g1, = torch.autograd.grad(Z1, x1, grad_outputs=S)
+    g2, = torch.autograd.grad(Z2, x2, grad_outputs=S)
+    return (x1 * g1 + x2 * g2).detach()
+
+
+def gradient_route(x, fn, R):
+    """RA:470-480 -> IL:138-157: tf.gradients(fn(x), x, grad_ys=R)."""
+    xr = x.detach().requires_grad_(True)
+    g, = torch.autograd.grad(fn(xr), xr, grad_outputs=R)
+    return g.detach()
+
+
+def analyze(layers, X_nhwc, R_nhwc, dtype=torch.float64):
+    """`analyzer.analyze([X, R])` (AB:478-520): one full forward to obtain
+    every layer's input, then the reverse walk.  (N,H,W,3),(N,h,w,C)->(N,H,W,3)."""
+    _, inputs = forward(layers, X_nhwc, dtype, return_inputs=True)
+    R = _nchw(_t(R_nhwc, dtype))
+    for L, x in zip(reversed(layers), reversed(inputs)):
+        if L[0] == "conv":
+            R = alpha1beta0_conv(x, L[1], L[2], R, dtype)
+        else:
+            R = gradient_route(x, lambda v: F.max_pool2d(v, 2, 2), R)
+    return _nhwc(R).numpy()
+
+
+def analyze_cached(layers, X_nhwc, R_nhwc, dtype=torch.float64):
+    """The restructured algorithm the HIP path uses, in float64 on CPU, to
+    show it is parity-neutral (tests/test_oracle_cnn.py):
+      per image:  a_l (forward), Z_l = conv(x+,w+)+conv(x-,w-)+b once,
+                  G_l = argmaxmask_l * a_l / safe(Z_l)   (all in [0,1])
+      per token:  S_top = R/safe(Z_top);  S_{l-1} = up2?(convT(S_l, w_l+)) * G_{l-1};
+                  R_img = x+ * convT(S_1,w_1+) + x- * convT(S_1,w_1-)
+    The x- / w- branch is dropped for every layer whose input is post-ReLU
+    (identically zero contribution)."""
+    x = _nchw(_t(X_nhwc, dtype))
+    convs = []          # (x_in, w+, Z, a_out, pooled_after)
+    cur = x
+    i = 0
+    while i < len(layers):
+        L = layers[i]
+        assert L[0] == "conv"
+        w = _w_oihw(L[1], dtype)
+        b = _t(L[2], dtype)
+        wp, wn = w * (w >= 0), w * (w < 0)
+        xp, xn = cur * (cur >= 0), cur * (cur < 0)
+        Z = F.conv2d(xp, wp, padding=1) + F.conv2d(xn, wn, padding=1) + b.view(1, -1, 1, 1)
+        a = F.relu(F.conv2d(cur, w, b, padding=1))
+        pooled = i + 1 < len(layers) and layers[i + 1][0] == "pool"
+        convs.append((cur, wp, wn, Z, a, pooled))
+        cur = F.max_pool2d(a, 2, 2) if pooled else a
+        i += 2 if pooled else 1
+    S = safe_divide(_nchw(_t(R_nhwc, dtype)), convs[-1][3])
+    for li in range(len(convs) - 1, 0, -1):
+        _, wp, _, _, _, _ = convs[li]
+        _, _, _, Zm, am, pooled = convs[li - 1]
+        C = F.conv_transpose2d(S, wp, padding=1)
+        if pooled:
+            # first-max-in-scan-order argmax mask (TF MaxPoolGrad / torch agree)
+            _, idx = F.max_pool2d(am, 2, 2, return_indices=True)
+            mask = torch.zeros_like(am).flatten(2)
+            mask.scatter_(2, idx.flatten(2), 1.0)
+            mask = mask.view_as(am)
+            C = F.interpolate(C, scale_factor=2, mode="nearest")
+            G = mask * safe_divide(am, Zm)
+        else:
+            G = safe_divide(am, Zm)
+        S = C * G
+    x0, wp, wn, _, _, _ = convs[0]
+    xp, xn = x0 * (x0 >= 0), x0 * (x0 < 0)
+    R = xp * F.conv_transpose2d(S, wp, padding=1) + xn * F.conv_transpose2d(S, wn, padding=1)
+    return _nhwc(R).numpy()
+
+
+# ----------------------------------------------------------------------------
+# other rules reachable from the preset (kept small; used by known-answer tests
+# and by the ResNet-101 "next" row)
+# ----------------------------------------------------------------------------
+def epsilon_dense(x, W, R, eps, dtype=torch.float64):
+    """EpsilonRule with bias=False (RR:113-144, RA:706-711): x (N,Din), W (Din,Dout)."""
+    x = _t(x, dtype)
+    W = _t(W, dtype)
+    R = _t(R, dtype)
+    Z = x @ W
+    S = R / (Z + ((Z >= 0).to(dtype) * 2 - 1) * eps)
+    return (x * (S @ W.t())).numpy()
+
+
+def batchnorm_reverse(x, gamma, beta, mean, var, bn_eps, R, dtype=torch.float64):
+    """BatchNormalizationReverseLayer (RA:197-257), channels-last."""
+    x, R = _t(x, dtype), _t(R, dtype)
+    g, bt, mu, v = (_t(a, dtype) for a in (gamma, beta, mean, var))
+    y = (x - mu) / torch.sqrt(v + bn_eps) * g + bt
+    xmu = x - mu
+    num = x * (y - bt) * R
+    den = xmu * y
+    den = den + ((den >= 0).to(dtype) * 2 - 1) * SAFE_EPS
+    return safe_divide(num, den).numpy()
+
+
+def add_reverse(xs, R, dtype=torch.float64):
+    """AddReverseLayer (RA:260-286): R_i = x_i * SafeDivide(R, sum_j x_j)."""
+    xs = [_t(x, dtype) for x in xs]
+    R = _t(R, dtype)
+    S = safe_divide(R, sum(xs))
+    return [(x * S).numpy() for x in xs]
