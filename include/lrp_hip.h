@@ -1,0 +1,179 @@
+/* lrp_hip.h — C ABI of the MI355X-native LRP engine (liblrp_hip.so).
+ *
+ * Drop-in boundary for the explanation hot path of SunJiamei/LRP-ImageCaptioning.
+ * The reference is pure Python and has no FFI; each entry point below names the
+ * reference call it stands in for (file:line in /root/reference; E: =
+ * models/explainers.py, AB: = innvestigate/analyzer/base.py, RA:/RR: =
+ * innvestigate/analyzer/relevance_based/relevance_{analyzer,rule}.py).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; every `*_dev` pointer is DEVICE memory owned by the
+ *    caller (e.g. a torch tensor's data_ptr()); every `*_host` pointer is host
+ *    memory read before the call returns.
+ *  - the library allocates only its own workspace (in lrp_create, freed in
+ *    lrp_destroy); it never allocates or synchronises inside a compute call
+ *    except for copying the small host index arrays.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *  - return value: 0 = LRP_OK, negative = error; text via lrp_last_error().
+ *  - one handle per GPU / stream; a handle is stateful and not re-entrant
+ *    (like the reference engine, whose state lives on `self`).
+ *  - tensors are row-major, images / feature maps NHWC (Keras channels_last),
+ *    dense weights (in_dim, out_dim), conv kernels HWIO, LSTM gate order i,f,g,o
+ *    — exactly the arrays `layer.get_weights()` yields at E:264-278 / E:1000-1019.
+ */
+#ifndef LRP_HIP_H
+#define LRP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LRP_ABI_VERSION 1
+
+enum {
+  LRP_OK = 0,
+  LRP_ERR_INVALID = -1,      /* bad argument (ValueError at the Python layer)          */
+  LRP_ERR_STATE = -2,        /* call order violated / weights missing                  */
+  LRP_ERR_HIP = -3,          /* a HIP runtime call failed                              */
+  LRP_ERR_NOMEM = -4,        /* workspace allocation failed                            */
+  LRP_ERR_RANGE = -5,        /* token index out of range of the caption
+                                (NotImplementedError at E:538-539 / E:1181-1182)       */
+  LRP_ERR_UNSUPPORTED = -6   /* encoder/decoder kind not built (NotImplementedError)   */
+};
+
+enum { LRP_DEC_ADAPTIVE = 0,   /* ExplainImgCaptioningAdaptiveAttention  E:260-666   */
+       LRP_DEC_GRIDTD = 1 };   /* ExplainImgCaptioningGridTDModel        E:995-1321  */
+
+enum { LRP_EXPLAIN_SEQUENCE = 0,   /* _explain_lstm_single_word_sequence  E:537-666 / E:1180-1321 */
+       LRP_EXPLAIN_SINGLE_STEP = 1 /* _explain_lstm_single_word           E:438-535 (adaptive)    */ };
+
+#define LRP_MAX_CONV 32
+
+/* Encoder = a VGG-style stack cut after the last conv's ReLU (the sub-model
+ * input_1 -> block5_conv3 of E:29-30): conv3x3 'same' + ReLU layers, each
+ * optionally followed by a 2x2/2 max-pool.  VGG16: 13 convs, pools after
+ * 2,4,7,10.  conv_name[i] is the Keras layer name used by lrp_set_weight
+ * ("<name>_W" HWIO (3,3,Cin,Cout), "<name>_b" (Cout)). */
+typedef struct lrp_config {
+  int32_t abi_version;          /* = LRP_ABI_VERSION                                    */
+  int32_t device;               /* HIP device ordinal                                   */
+  int32_t decoder;              /* LRP_DEC_*                                            */
+  int32_t img_h, img_w;         /* 224, 224                                             */
+  int32_t n_conv;
+  int32_t conv_cin[LRP_MAX_CONV];
+  int32_t conv_cout[LRP_MAX_CONV];
+  int32_t conv_pool_after[LRP_MAX_CONV];
+  char    conv_name[LRP_MAX_CONV][32];
+  int32_t L, D, H, E, V;        /* 196, 512, 512, 512, vocab  (config.py:14-15,36-40)   */
+  int32_t max_images;           /* capacity of the per-image caches                     */
+  int32_t max_tokens;           /* capacity of one explain call (heat-maps)             */
+  int32_t max_caption_len;      /* longest caption incl. EOS (config.py:34 -> 20+1)     */
+  int32_t sos_id, eos_id;       /* tokenizer ids (1-based); model column = id-1 (E:443) */
+} lrp_config;
+
+typedef struct lrp_handle lrp_handle;
+
+/* ExplainImgCaptioningAttentionModel.__init__ (E:24-40): build the engine for a
+ * model geometry; allocates all device workspace. */
+int lrp_create(const lrp_config* cfg, lrp_handle** out);
+int lrp_destroy(lrp_handle* h);
+
+/* Weight extraction (E:264-278, E:1000-1019; conv kernels = the image_model's
+ * layers, E:29-30).  `data_host` is float32 in the Keras layout; the library
+ * splits conv weights into w+ / w- (RR:256-260), packs and uploads them.
+ * Names: "<conv>_W","<conv>_b", "image_features_W/_b", "global_W/_b",
+ * "embedding", "output_W/_b"; adaptive: "lstm_Wi","lstm_Wh","lstm_b","Wv","Wg",
+ * "V","Wx","Wh","Ws"; grid-TD: "td_Wi","td_Wh","td_b","lang_Wi","lang_Wh",
+ * "lang_b","W_va","W_ha","W_a","W_x","W_h","W_s". */
+int lrp_set_weight(lrp_handle* h, const char* name, const float* data_host,
+                   int32_t ndim, const int64_t* shape);
+/* Same, from device memory on rank-local HBM (used after an RCCL broadcast). */
+int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev,
+                       int32_t ndim, const int64_t* shape, void* stream);
+
+/* `self._image_model.predict(img_input)` (E:375, E:1097) plus everything the
+ * analyzer's forward half would recompute on every analyze() call (AB:511):
+ * runs the encoder once per image and caches, per conv layer, the relevance
+ * gate G_l = argmax_mask_l * a_l / SafeDivide-denominator(Z+_l) (RR:274-322,
+ * layers.py:446-461) and the top feature map.  images_dev: (B,img_h,img_w,3)
+ * float32, BGR mean-subtracted (preprocessors.py:43-44). */
+int lrp_encode_images(lrp_handle* h, const float* images_dev, int32_t B, void* stream);
+
+/* Decoder-only use (parity tests of the E: classes with an injected feature
+ * map, mirroring a stubbed `_image_model.predict`): features_dev (B,L,D). */
+int lrp_set_features(lrp_handle* h, const float* features_dev, int32_t B, void* stream);
+/* Copy out the cached top feature map (B,L,D). */
+int lrp_get_features(lrp_handle* h, float* features_dev, int32_t B, void* stream);
+
+/* _forward_beam_search(X, caption) (E:370-436 / E:1092-1178) for B images at
+ * once: teacher-forced replay, caches ht, ct, gt, it_act, ft_act, context,
+ * attention, st, beta, c_hat, xt, caption_preds on the handle.
+ * captions_host: (B, max_caption_len) tokenizer ids, row b valid for
+ * lengths_host[b] entries (last valid one = EOS). */
+int lrp_decoder_forward(lrp_handle* h, const int32_t* captions_host,
+                        const int32_t* lengths_host, int32_t B, void* stream);
+
+/* Read a cached decoder state array (the attributes the reference leaves on
+ * `self`).  Layout (B, max_caption_len+1, dim) with row 0 = zero init, float32
+ * for ht/ct/gt/it_act/ft_act/st/attention/beta, float64 for context/c_hat;
+ * "caption_preds" (B, max_caption_len, V) float64; "xt" (B, max_caption_len, 2E).
+ * grid-TD: h1t,c1t,g1t,i1t_act,f1t_act,h2t,c2t,g2t,i2t_act,f2t_act, context,
+ * st, beta, context_hat, attention (float64 where the reference has float64). */
+int lrp_read_state(lrp_handle* h, const char* name, void* out_dev, size_t out_bytes, void* stream);
+
+/* _explain_lstm_single_word_sequence(t) (E:537-666 / E:1180-1321) for n
+ * (image, t) pairs at once.  img_idx_host[i] in [0,B), t_host[i] in
+ * [1, len(caption_i)] (LRP_ERR_RANGE otherwise).  Outputs (device):
+ *   R_feat_dev  (n, L, D)  float32   == the (1,sqrtL,sqrtL,D) return value
+ *   att_dev     (n, L)     float32   attention_t (may be NULL)
+ *   r_words_dev (n, max_caption_len) float64, entry j = self.r_words[j] for
+ *               j < t-1 (adaptive, normalised, first dropped, E:660-665) or
+ *               j < t (grid-TD, E:1320); rest 0 (may be NULL) */
+int lrp_decoder_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
+                        const int32_t* t_host, int32_t variant, float* R_feat_dev,
+                        float* att_dev, double* r_words_dev, void* stream);
+
+/* _explain_CNN(X, R) == LRPSequentialPresetA.analyze([X, R]) (E:179-181,
+ * AB:478-520) for n relevance maps at once; image i uses the caches of
+ * img_idx_host[i] from the last lrp_encode_images.  R_feat_dev (n,L,D),
+ * R_img_dev (n,img_h,img_w,3) float32. */
+int lrp_cnn_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
+                    const float* R_feat_dev, float* R_img_dev, void* stream);
+
+/* Fused a7->a10 chain for a batch: decoder explain + CNN explain without the
+ * R_feat round trip through the caller (R_feat_dev / att_dev / r_words_dev may
+ * be NULL when not wanted). */
+int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
+                       const int32_t* t_host, int32_t variant, float* R_img_dev,
+                       float* R_feat_dev, float* att_dev, double* r_words_dev, void* stream);
+
+/* Dominant-kernel timing for bench.py's roofline block: when enabled, HIP
+ * events bracket every conv-LRP launch on the caller's stream; query returns
+ * launches and summed milliseconds since the last reset (syncs the events). */
+int lrp_profile_enable(lrp_handle* h, int32_t on);
+int lrp_profile_query(lrp_handle* h, int64_t* n_launches, double* total_ms, double* total_flop);
+
+/* Workspace bytes held by the handle. */
+int64_t lrp_workspace_bytes(const lrp_handle* h);
+
+/* Operator-level entry (unit tests of the dominant kernel): implicit-GEMM
+ * 3x3 'same' (taps=9) or 1x1 (taps=1) convolution on NHWC float32 with the
+ * fp32 MFMA path.  w_hwio_host: (3,3,Cin,Cout) or (1,1,Cin,Cout).
+ * mode 0: out = relu(conv + bias); mode 1: out = conv + bias;
+ * mode 2: out = convT(in, w) * aux   (LRP backward with gate `aux`, shape of out)
+ * mode 3: like 2 with 2x nearest up-sampling of the conv result (pool routing). */
+int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias_host,
+                const float* aux_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
+                int32_t Cin, int32_t Cout, int32_t taps, int32_t mode, void* stream);
+
+const char* lrp_last_error(void);
+int lrp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LRP_HIP_H */

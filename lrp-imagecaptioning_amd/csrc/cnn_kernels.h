@@ -1,0 +1,113 @@
+// cnn_kernels.h — the HBM-bound helpers of the encoder half (everything that is
+// not a convolution).  All are pure streaming kernels: 16 B per lane, coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "conv_igemm.h"
+
+namespace lrp {
+
+// SafeDivide denominator, innvestigate/layers.py:456-458:  b + [b == 0] * K.epsilon()
+__device__ __forceinline__ float safe_den(float z) { return z + (z == 0.f ? 1e-7f : 0.f); }
+
+// Image layer as a 1-tap GEMM: A1[m][64] = [ x+ patch(27) | 0*5 | x- patch(27) | 0*5 ]
+// so that  a_1 = A1 . [w ; w]   and   Z_1 = A1 . [w+ ; w-]  (RR:279-288, both sign branches).
+__global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restrict__ img, float* __restrict__ A1,
+                                                           int NB, int H, int W) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t total = (size_t)NB * H * W * 64;
+  if (idx >= total) return;
+  const int k = (int)(idx & 63);
+  const size_t m = idx >> 6;
+  const int kk = k & 31;
+  float v = 0.f;
+  if (kk < 27) {
+    const int t = kk / 3, c = kk - 3 * t;
+    const int HW = H * W;
+    const int n = (int)(m / HW), rem = (int)(m - (size_t)n * HW);
+    const int h = rem / W, w = rem - h * W;
+    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+      const float x = img[(((size_t)n * H + hh) * W + ww) * 3 + c];
+      v = (k < 32) ? (x >= 0.f ? x : 0.f) : (x < 0.f ? x : 0.f);
+    }
+  }
+  A1[idx] = v;
+}
+
+// No pool after layer l:  G_l = a_l / safe(Z_l)     (x_{l+1} = a_l)
+__global__ __launch_bounds__(256) void gate_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ z,
+                                                   f32x4* __restrict__ g, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 av = a[i], zv = z[i];
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = av[c] / safe_den(zv[c]);
+    g[i] = o;
+  }
+}
+
+// 2x2/2 max-pool after layer l:  x_{l+1} = pool(a_l);  G_l = [first arg-max of the window] * a_l / safe(Z_l)
+// (MaxPooling2D relevance = gradient routing, RA:470-480 -> layers.py:138-157)
+__global__ __launch_bounds__(256) void pool_gate_kernel(const float* __restrict__ a, const float* __restrict__ z,
+                                                        float* __restrict__ xnext, float* __restrict__ g,
+                                                        int NB, int H, int W, int C) {
+  const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)NB * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    f32x4 av[4], zv[4];
+    size_t off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      off[p] = ((((size_t)n * H + 2 * ho + (p >> 1)) * W + 2 * wo + (p & 1)) * C) + 4 * c4;
+      av[p] = *reinterpret_cast<const f32x4*>(a + off[p]);
+      zv[p] = *reinterpret_cast<const f32x4*>(z + off[p]);
+    }
+    f32x4 mx = av[0];
+    int arg[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 1; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (av[p][c] > mx[c]) { mx[c] = av[p][c]; arg[c] = p; }
+    *reinterpret_cast<f32x4*>(xnext + (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4) = mx;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = (arg[c] == p) ? av[p][c] / safe_den(zv[p][c]) : 0.f;
+      *reinterpret_cast<f32x4*>(g + off[p]) = o;
+    }
+  }
+}
+
+// Head of the reverse walk (KG:898-900): S_top = R_feat / safe(Z_top[img])
+__global__ __launch_bounds__(256) void top_divide_kernel(const f32x4* __restrict__ R, const f32x4* __restrict__ Ztop,
+                                                         const int* __restrict__ row2img, f32x4* __restrict__ S,
+                                                         int n, size_t per_img4) {
+  const size_t total = (size_t)n * per_img4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / per_img4);
+    const size_t e = i - (size_t)t * per_img4;
+    const int img = row2img ? row2img[t] : t;
+    const f32x4 r = R[i], z = Ztop[(size_t)img * per_img4 + e];
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = r[c] / safe_den(z[c]);
+    S[i] = o;
+  }
+}
+
+inline int stream_grid(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  if (b > 256 * 8) b = 256 * 8;      // 8 blocks per CU, grid-stride the rest
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace lrp

@@ -1,0 +1,73 @@
+// common.h — error plumbing and small RAII helpers shared by the engine sources.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/lrp_hip.h"
+
+namespace lrp {
+
+std::string& last_error_ref();
+
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error_ref() = buf;
+  return code;
+}
+
+#define LRP_HIP_CHECK(expr)                                                                     \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return ::lrp::fail(LRP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define LRP_TRY(expr)         \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != LRP_OK) return _rc; \
+  } while (0)
+
+// Device allocation owned by the handle (workspace); freed in the destructor.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  int alloc(size_t n, int64_t* total) {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      return fail(LRP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+    }
+    bytes = n;
+    if (total) *total += (int64_t)n;
+    return LRP_OK;
+  }
+  template <typename T>
+  T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+}  // namespace lrp

@@ -1,0 +1,314 @@
+// conv_igemm.h — fp32 MFMA implicit-GEMM 3x3/1x1 convolution for gfx950 with
+// the LRP epilogues fused.  This one kernel family carries >95 % of the FLOPs
+// of the hot path:
+//   * encoder forward + Z+ pass           (EPI_FWD_DUAL)  — per image, cached
+//   * conv-LRP alpha1beta0 backward       (EPI_MUL / EPI_MUL_UP2 / EPI_IMG) — per token
+//     RR:274-322 restructured: S_{l-1} = up2?(convT(S_l, w_l+)) * G_{l-1}
+//   * dense layers of the decoder prologue (taps = 1)
+//
+// GEMM view: D[m][n] = sum_k A[m][k] * B[k][n],  m = output pixel (NHWC row),
+// n = output channel, k = (tap, input channel).  A is gathered on the fly
+// (im2col never materialised); B is pre-packed [n][k] so both operands are
+// "rows of 32 consecutive k" = 128 B, staged through LDS with a 144 B row
+// stride (conflict-free ds_read_b128).
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Lane l feeds
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; we let lane-half h consume
+// k = 4h+s at sub-step s so that one ds_read_b128 per operand covers 4 MFMAs
+// (any k permutation is legal as long as A and B agree).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lrp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum ConvEpi {
+  EPI_BIAS_RELU = 0,  // out = relu(acc + bias)
+  EPI_BIAS = 1,       // out = acc + bias
+  EPI_MUL = 2,        // out = acc * aux[img(row)]               (conv-LRP, no pool)
+  EPI_MUL_UP2 = 3,    // out(2x res) = acc * aux[img(row)](2x)   (conv-LRP through a 2x2 max-pool)
+  EPI_FWD_DUAL = 4,   // cols [0,split): out = relu(acc+bias); cols [split,2split): out2 = acc+bias  (a_l and Z+_l)
+  EPI_IMG = 5         // cols 0..2: conv with w+, 3..5: with w-;  out = x>=0 ? x*acc+ : x*acc-   (RR:306-312 at the image)
+};
+
+struct ConvArgs {
+  const float* in;     // [NB][H][W][Cin] fp32
+  const float* wpk;    // [n_tiles*BN][K] fp32, K = taps*CinP, CinP = roundup(Cin,32), zero padded
+  int NB, H, W, Cin, CinP;
+  int N;               // valid output columns
+  int taps;            // 9 (3x3 same) or 1
+  int M;               // NB*H*W
+  int m_tiles, n_tiles;
+  const float* bias;
+  float* out;
+  float* out2;
+  const float* aux;
+  const int* row2img;  // per input image-slot n -> cache slot (nullptr = identity)
+  int split;
+};
+
+constexpr int LDS_STRIDE = 36;   // floats per staged row: 32 data + 4 pad (144 B)
+
+template <int WM, int WN, int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int AP = BM / 32, BP = BN / 32;          // 32 rows per load pass (256 threads x 16 B)
+  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
+  static_assert(WM * WN == 4, "4 waves");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  // ---- XCD-aware block remap: the n_tiles blocks that share an A tile get
+  // consecutive logical ids and land on one XCD (one L2) [bijective form].
+  const int nblk = a.m_tiles * a.n_tiles;
+  int logical;
+  {
+    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int chunk = tid & 7, lrow = tid >> 3;
+  const int HW = a.H * a.W;
+  const int K = a.taps * a.CinP;
+  const int cpt = a.CinP >> 5;                         // 32-wide k chunks per tap
+  const int nk = a.taps * cpt;
+
+  // ---- per-thread A row metadata (rows do not change over the K loop)
+  const float* aptr[AP];
+  unsigned amask[AP];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    const int m = m0 + lrow + 32 * p;
+    unsigned mask = 0;
+    if (m < a.M) {
+      if (a.taps == 1) {
+        mask = 1u;
+      } else {
+        const int rem = m % HW, h = rem / a.W, w = rem - h * a.W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+          if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) mask |= 1u << t;
+        }
+      }
+    }
+    amask[p] = mask;
+    aptr[p] = a.in + (size_t)m * a.Cin + chunk * 4;
+  }
+  const float* bptr = a.wpk + (size_t)(n0 + lrow) * K + chunk * 4;
+
+  f32x4 ra[AP], rb[BP];
+  int tap = 0, cc = 0;                                 // position of the chunk being LOADED
+  auto load_chunk = [&]() {
+    const int c0 = cc << 5;
+    const int off = (a.taps == 1 ? 0 : ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * a.Cin) + c0;
+    const bool cvalid = (c0 + chunk * 4) < a.Cin;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (cvalid && ((amask[p] >> tap) & 1u)) v = *reinterpret_cast<const f32x4*>(aptr[p] + off);
+      ra[p] = v;
+    }
+    const int kofs = tap * a.CinP + c0;
+#pragma unroll
+    for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const f32x4*>(bptr + (size_t)(32 * p) * K + kofs);
+    if (++cc == cpt) { cc = 0; ++tap; }
+  };
+  auto store_chunk = [&](int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LDS_STRIDE;
+#pragma unroll
+    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(As + (lrow + 32 * p) * LDS_STRIDE + chunk * 4) = ra[p];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * p) * LDS_STRIDE + chunk * 4) = rb[p];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  load_chunk();
+  store_chunk(0);
+  __syncthreads();
+
+  const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+  const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+
+  for (int kc = 0; kc < nk; ++kc) {
+    const int buf = kc & 1;
+    const bool more = (kc + 1) < nk;
+    if (more) load_chunk();                            // global loads fly under the MFMAs below
+    const float* Ab = smem + buf * STAGE + a_off;
+    const float* Bb = smem + buf * STAGE + b_off;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int col_base = n0 + wn * TN * 32 + (lane & 31);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const bool rv = row < a.M;
+      if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col_base + j * 32;
+          if (rv && col < a.N) {
+            float v = acc[i][j][r] + a.bias[col];
+            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            a.out[(size_t)row * a.N + col] = v;
+          }
+        }
+      } else if constexpr (EPI == EPI_FWD_DUAL) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col_base + j * 32;
+          if (rv && col < 2 * a.split) {
+            if (col < a.split) {
+              a.out[(size_t)row * a.split + col] = fmaxf(acc[i][j][r] + a.bias[col], 0.f);
+            } else {
+              const int c = col - a.split;
+              a.out2[(size_t)row * a.split + c] = acc[i][j][r] + a.bias[c];
+            }
+          }
+        }
+      } else if constexpr (EPI == EPI_MUL) {
+        size_t grow = 0;
+        if (rv) {
+          const int n = row / HW, pix = row - n * HW;
+          const int img = a.row2img ? a.row2img[n] : n;
+          grow = (size_t)img * HW + pix;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col_base + j * 32;
+          if (rv && col < a.N) a.out[(size_t)row * a.N + col] = acc[i][j][r] * a.aux[grow * a.N + col];
+        }
+      } else if constexpr (EPI == EPI_MUL_UP2) {
+        if (rv) {
+          const int n = row / HW, pix = row - n * HW;
+          const int h = pix / a.W, w = pix - h * a.W;
+          const int img = a.row2img ? a.row2img[n] : n;
+          const int W2 = 2 * a.W, H2 = 2 * a.H;
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const size_t orow = ((size_t)n * H2 + 2 * h + dy) * W2 + 2 * w + dx;
+              const size_t grow = ((size_t)img * H2 + 2 * h + dy) * W2 + 2 * w + dx;
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const int col = col_base + j * 32;
+                if (col < a.N) a.out[orow * a.N + col] = acc[i][j][r] * a.aux[grow * a.N + col];
+              }
+            }
+        }
+      } else if constexpr (EPI == EPI_IMG) {
+        // all lanes take part in the shuffle; only cols 0..2 of the first column tile store
+        const float vpos = acc[i][0][r];
+        const float vneg = __shfl(vpos, lane + 3, 64);
+        const int col = col_base;
+        if (rv && col < 3) {
+          const int n = row / HW, pix = row - n * HW;
+          const int img = a.row2img ? a.row2img[n] : n;
+          const float x = a.aux[((size_t)img * HW + pix) * 3 + col];
+          a.out[(size_t)row * 3 + col] = x >= 0.f ? x * vpos : x * vneg;
+        }
+      }
+    }
+  }
+}
+
+// tile configurations: (WM,WN,TM,TN) -> BM x BN
+//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)
+//   n64   : 4,1,2,2 -> 256 x  64   (N == 64 layers)
+//   n32   : 4,1,2,1 -> 256 x  32   (N <= 32: image layer, tiny test nets)
+struct ConvTile { int BM, BN; };
+inline ConvTile conv_pick_tile(int N) {
+  if (N > 64) return {128, 128};
+  if (N > 32) return {256, 64};
+  return {256, 32};
+}
+inline int conv_npad(int N) { ConvTile t = conv_pick_tile(N); return (N + t.BN - 1) / t.BN * t.BN; }
+inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
+
+template <int EPI>
+inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
+  const ConvTile t = conv_pick_tile(a.N);
+  a.M = a.NB * a.H * a.W;
+  a.m_tiles = (a.M + t.BM - 1) / t.BM;
+  a.n_tiles = (a.N + t.BN - 1) / t.BN;
+  const dim3 grid(a.m_tiles * a.n_tiles), block(256);
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (t.BN == 128)
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI>), grid, block, 0, st, a);
+  else if (t.BN == 64)
+    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, EPI>), grid, block, 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, EPI>), grid, block, 0, st, a);
+  return hipGetLastError();
+}
+
+inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st) {
+  switch (epi) {
+    case EPI_BIAS_RELU: return conv_launch_epi<EPI_BIAS_RELU>(a, st);
+    case EPI_BIAS: return conv_launch_epi<EPI_BIAS>(a, st);
+    case EPI_MUL: return conv_launch_epi<EPI_MUL>(a, st);
+    case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2>(a, st);
+    case EPI_FWD_DUAL: return conv_launch_epi<EPI_FWD_DUAL>(a, st);
+    case EPI_IMG: return conv_launch_epi<EPI_IMG>(a, st);
+  }
+  return hipErrorInvalidValue;
+}
+
+// ---- host-side weight packing (one-off at lrp_set_weight time)
+// forward:  wpk[n = co][k = tap*CinP + ci] = w[kh][kw][ci][co]
+inline void pack_conv_fwd(const float* w_hwio, int taps, int Cin, int Cout, int col0, int Npad, float* wpk) {
+  const int CinP = conv_cinp(Cin), K = taps * CinP;
+  (void)Npad;
+  for (int t = 0; t < taps; ++t)
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int co = 0; co < Cout; ++co)
+        wpk[(size_t)(col0 + co) * K + t * CinP + ci] = w_hwio[((size_t)t * Cin + ci) * Cout + co];
+}
+// backward (transposed conv as a forward conv over S with flipped taps):
+//   wpk[n = ci][k = tap'*CoutP + co] = w[2-kh'][2-kw'][ci][co]
+inline void pack_conv_bwd(const float* w_hwio, int taps, int Cin, int Cout, int col0, float* wpk) {
+  const int CoutP = conv_cinp(Cout), K = taps * CoutP;
+  for (int t = 0; t < taps; ++t) {
+    const int tf = (taps == 9) ? 8 - t : 0;            // (2-kh')*3 + (2-kw') = 8 - t
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int co = 0; co < Cout; ++co)
+        wpk[(size_t)(col0 + ci) * K + t * CoutP + co] = w_hwio[((size_t)tf * Cin + ci) * Cout + co];
+  }
+}
+
+}  // namespace lrp

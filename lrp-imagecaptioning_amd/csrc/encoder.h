@@ -1,0 +1,261 @@
+// encoder.h — host-side orchestration of the CNN half:
+//   encode():  one forward per IMAGE, caching the relevance gates G_l and Z_top
+//   explain(): one reverse walk per TOKEN (batched over all tokens of the call)
+// Reference semantics: LRPSequentialPresetA.analyze([X,R]) (AB:478-520) over the
+// sub-model input_1 -> block5_conv3 (E:29-32); rules RR:274-322, RA:470-480.
+#pragma once
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cnn_kernels.h"
+#include "common.h"
+#include "conv_igemm.h"
+
+namespace lrp {
+
+struct ConvLayer {
+  std::string name;
+  int cin = 0, cout = 0, H = 0, W = 0;   // H,W = resolution this conv runs at
+  bool pool_after = false;
+  bool have_w = false, have_b = false;
+  DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)
+  DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
+  DevBuf bias;
+  DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
+  size_t act_elems() const { return (size_t)H * W * cout; }
+};
+
+struct ProfileRec {
+  hipEvent_t e0, e1;
+  double flop;
+};
+
+struct Encoder {
+  int img_h = 0, img_w = 0, max_images = 0, max_tokens = 0;
+  int top_h = 0, top_w = 0, top_c = 0;
+  std::vector<ConvLayer> layers;
+  DevBuf images;           // [max_images][H][W][3]   (x of the image layer, needed by EPI_IMG)
+  DevBuf a1;               // im2col of the image layer [max_images*H*W][64]
+  DevBuf bufX, bufA, bufZ; // forward ping-pong (per call, all images)
+  DevBuf feat;             // [max_images][top_h*top_w][top_c]  top activations (== CNN features)
+  DevBuf ztop;             // [max_images][top...] Z+ of the top layer
+  DevBuf s0, s1;           // reverse-walk ping-pong [max_tokens][biggest layer]
+  int encoded = 0;         // images currently cached
+  bool features_only = false;
+  bool profile = false;
+  std::vector<ProfileRec> prof;
+
+  int init(const lrp_config& c, int64_t* total) {
+    img_h = c.img_h; img_w = c.img_w; max_images = c.max_images; max_tokens = c.max_tokens;
+    if (c.n_conv < 1 || c.n_conv > LRP_MAX_CONV) return fail(LRP_ERR_INVALID, "n_conv=%d out of range", c.n_conv);
+    if (c.conv_cin[0] != 3) return fail(LRP_ERR_UNSUPPORTED, "first conv must read a 3-channel image");
+    int H = img_h, W = img_w;
+    size_t max_act = 0;
+    layers.resize(c.n_conv);
+    for (int i = 0; i < c.n_conv; ++i) {
+      ConvLayer& L = layers[i];
+      L.name = c.conv_name[i];
+      L.cin = c.conv_cin[i]; L.cout = c.conv_cout[i]; L.H = H; L.W = W;
+      L.pool_after = c.conv_pool_after[i] != 0;
+      if (i > 0 && L.cin != layers[i - 1].cout) return fail(LRP_ERR_INVALID, "conv %d: cin != previous cout", i);
+      if (L.cout % 4 != 0) return fail(LRP_ERR_UNSUPPORTED, "conv %d: cout must be a multiple of 4", i);
+      if (i == c.n_conv - 1 && L.pool_after) return fail(LRP_ERR_UNSUPPORTED, "encoder must end with a conv layer");
+      if (L.act_elems() > max_act) max_act = L.act_elems();
+      if (L.pool_after) {
+        if ((H & 1) || (W & 1)) return fail(LRP_ERR_UNSUPPORTED, "odd resolution before a 2x2 pool");
+        H >>= 1; W >>= 1;
+      }
+    }
+    const ConvLayer& T = layers.back();
+    top_h = T.H; top_w = T.W; top_c = T.cout;
+    if (top_h * top_w != c.L || top_c != c.D)
+      return fail(LRP_ERR_INVALID, "encoder output (%d x %d x %d) does not match L=%d, D=%d", top_h, top_w, top_c, c.L, c.D);
+    const size_t B = (size_t)max_images, NT = (size_t)max_tokens;
+    LRP_TRY(images.alloc(B * img_h * img_w * 3 * sizeof(float), total));
+    LRP_TRY(a1.alloc(B * img_h * img_w * 64 * sizeof(float), total));
+    LRP_TRY(bufX.alloc(B * max_act * sizeof(float), total));
+    LRP_TRY(bufA.alloc(B * max_act * sizeof(float), total));
+    LRP_TRY(bufZ.alloc(B * max_act * sizeof(float), total));
+    LRP_TRY(feat.alloc(B * T.act_elems() * sizeof(float), total));
+    LRP_TRY(ztop.alloc(B * T.act_elems() * sizeof(float), total));
+    LRP_TRY(s0.alloc(NT * max_act * sizeof(float), total));
+    LRP_TRY(s1.alloc(NT * max_act * sizeof(float), total));
+    for (size_t i = 0; i + 1 < layers.size(); ++i) LRP_TRY(layers[i].G.alloc(B * layers[i].act_elems() * sizeof(float), total));
+    return LRP_OK;
+  }
+
+  int find_layer(const std::string& nm) const {
+    for (size_t i = 0; i < layers.size(); ++i)
+      if (layers[i].name == nm) return (int)i;
+    return -1;
+  }
+
+  // "<name>_W": HWIO (3,3,cin,cout) -> split by sign (RR:256-260), pack, upload.
+  int set_conv_weight(int li, const float* w, int64_t* total) {
+    ConvLayer& L = layers[li];
+    const size_t nW = (size_t)9 * L.cin * L.cout;
+    std::vector<float> wp(nW), wn(nW);
+    for (size_t i = 0; i < nW; ++i) { wp[i] = w[i] >= 0.f ? w[i] : 0.f; wn[i] = w[i] < 0.f ? w[i] : 0.f; }
+    std::vector<float> pk;
+    if (li == 0) {
+      // forward: 1-tap GEMM over the im2col matrix A1[m][64]; rows = [a_1 (cout) | Z_1 (cout)]
+      const int Np = conv_npad(2 * L.cout), K = 64;
+      pk.assign((size_t)Np * K, 0.f);
+      for (int k = 0; k < 27; ++k)
+        for (int co = 0; co < L.cout; ++co) {
+          const float v = w[(size_t)k * L.cout + co];
+          pk[(size_t)co * K + k] = v;                       // a_1 = (x+ + x-) . w
+          pk[(size_t)co * K + 32 + k] = v;
+          pk[(size_t)(L.cout + co) * K + k] = wp[(size_t)k * L.cout + co];        // Z_1 = x+.w+ + x-.w-
+          pk[(size_t)(L.cout + co) * K + 32 + k] = wn[(size_t)k * L.cout + co];
+        }
+      LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      // backward at the image: 6 output columns (3 with w+, 3 with w-)
+      const int Npb = conv_npad(6), Kb = 9 * conv_cinp(L.cout);
+      pk.assign((size_t)Npb * Kb, 0.f);
+      pack_conv_bwd(wp.data(), 9, 3, L.cout, 0, pk.data());
+      pack_conv_bwd(wn.data(), 9, 3, L.cout, 3, pk.data());
+      LRP_TRY(L.w_bwd.alloc(pk.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpy(L.w_bwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else {
+      const int Np = conv_npad(2 * L.cout), K = 9 * conv_cinp(L.cin);
+      pk.assign((size_t)Np * K, 0.f);
+      pack_conv_fwd(w, 9, L.cin, L.cout, 0, Np, pk.data());
+      pack_conv_fwd(wp.data(), 9, L.cin, L.cout, L.cout, Np, pk.data());    // input >= 0: Z = x.w+ + b
+      LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      const int Npb = conv_npad(L.cin), Kb = 9 * conv_cinp(L.cout);
+      pk.assign((size_t)Npb * Kb, 0.f);
+      pack_conv_bwd(wp.data(), 9, L.cin, L.cout, 0, pk.data());
+      LRP_TRY(L.w_bwd.alloc(pk.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpy(L.w_bwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    L.have_w = true;
+    return LRP_OK;
+  }
+
+  int set_conv_bias(int li, const float* b, int64_t* total) {
+    ConvLayer& L = layers[li];
+    LRP_TRY(L.bias.alloc((size_t)L.cout * sizeof(float), total));
+    LRP_HIP_CHECK(hipMemcpy(L.bias.p, b, (size_t)L.cout * sizeof(float), hipMemcpyHostToDevice));
+    L.have_b = true;
+    return LRP_OK;
+  }
+
+  int check_ready() const {
+    for (const ConvLayer& L : layers)
+      if (!L.have_w || !L.have_b) return fail(LRP_ERR_STATE, "encoder weights for layer '%s' not set", L.name.c_str());
+    return LRP_OK;
+  }
+
+  // ---- forward once per image -------------------------------------------------------------
+  int encode(const float* images_dev, int B, hipStream_t st) {
+    if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
+    LRP_TRY(check_ready());
+    const size_t img_elems = (size_t)img_h * img_w * 3;
+    LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, B * img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
+    {
+      const size_t total = (size_t)B * img_h * img_w * 64;
+      hipLaunchKernelGGL(im2col_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                         images.as<float>(), a1.as<float>(), B, img_h, img_w);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    float* x = bufX.as<float>();
+    float* a = bufA.as<float>();
+    float* z = bufZ.as<float>();
+    for (size_t li = 0; li < layers.size(); ++li) {
+      ConvLayer& L = layers[li];
+      const bool top = li + 1 == layers.size();
+      ConvArgs ca{};
+      if (li == 0) {
+        ca.in = a1.as<float>(); ca.NB = B * L.H * L.W; ca.H = 1; ca.W = 1; ca.Cin = 64; ca.CinP = 64; ca.taps = 1;
+      } else {
+        ca.in = x; ca.NB = B; ca.H = L.H; ca.W = L.W; ca.Cin = L.cin; ca.CinP = conv_cinp(L.cin); ca.taps = 9;
+      }
+      ca.wpk = L.w_fwd.as<float>();
+      ca.N = 2 * L.cout; ca.split = L.cout; ca.bias = L.bias.as<float>();
+      ca.out = top ? feat.as<float>() : a;
+      ca.out2 = top ? ztop.as<float>() : z;
+      LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st));
+      if (top) break;
+      const size_t n = (size_t)B * L.act_elems();
+      if (L.pool_after) {
+        hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a, z, x, L.G.as<float>(), B, L.H,
+                           L.W, L.cout);
+        LRP_HIP_CHECK(hipGetLastError());
+        // x now holds pool(a): input of the next conv
+      } else {
+        hipLaunchKernelGGL(gate_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(a),
+                           reinterpret_cast<const f32x4*>(z), L.G.as<f32x4>(), n / 4);
+        LRP_HIP_CHECK(hipGetLastError());
+        float* t = x; x = a; a = t;                   // next input = a_l
+      }
+    }
+    encoded = B;
+    features_only = false;
+    return LRP_OK;
+  }
+
+  // ---- reverse walk, n relevance maps at once ---------------------------------------------
+  // R_feat_dev (n, top_h*top_w, top_c) -> R_img_dev (n, img_h, img_w, 3); row2img_dev: device int[n]
+  int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st) {
+    if (n < 1 || n > max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, max_tokens);
+    if (encoded < 1 || features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before the CNN explain");
+    const ConvLayer& T = layers.back();
+    float* S = s0.as<float>();
+    float* Snext = s1.as<float>();
+    {
+      const size_t per4 = T.act_elems() / 4;
+      hipLaunchKernelGGL(top_divide_kernel, dim3(stream_grid((size_t)n * per4)), dim3(256), 0, st,
+                         reinterpret_cast<const f32x4*>(R_feat_dev), ztop.as<f32x4>(), row2img_dev,
+                         reinterpret_cast<f32x4*>(S), n, per4);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    for (int li = (int)layers.size() - 1; li >= 0; --li) {
+      const ConvLayer& L = layers[li];
+      ConvArgs ca{};
+      ca.in = S; ca.NB = n; ca.H = L.H; ca.W = L.W; ca.Cin = L.cout; ca.CinP = conv_cinp(L.cout); ca.taps = 9;
+      ca.wpk = L.w_bwd.as<float>();
+      ca.row2img = row2img_dev;
+      int epi;
+      if (li == 0) {
+        ca.N = 6; ca.aux = images.as<float>(); ca.out = R_img_dev; epi = EPI_IMG;
+      } else {
+        const ConvLayer& P = layers[li - 1];
+        ca.N = L.cin; ca.aux = P.G.as<float>(); ca.out = Snext;
+        epi = P.pool_after ? EPI_MUL_UP2 : EPI_MUL;
+      }
+      ProfileRec pr{};
+      if (profile) {
+        (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1);
+        (void)hipEventRecord(pr.e0, st);
+      }
+      LRP_HIP_CHECK(conv_launch(epi, ca, st));
+      if (profile) {
+        (void)hipEventRecord(pr.e1, st);
+        pr.flop = 2.0 * (double)n * L.H * L.W * 9.0 * L.cout * (li == 0 ? 6 : L.cin);
+        prof.push_back(pr);
+      }
+      float* t = S; S = Snext; Snext = t;
+    }
+    return LRP_OK;
+  }
+
+  int profile_query(int64_t* launches, double* ms, double* flop) {
+    int64_t nl = 0; double tm = 0, fl = 0;
+    for (ProfileRec& p : prof) {
+      float t = 0.f;
+      if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&t, p.e0, p.e1) == hipSuccess) { tm += t; fl += p.flop; ++nl; }
+      (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    prof.clear();
+    if (launches) *launches = nl;
+    if (ms) *ms = tm;
+    if (flop) *flop = fl;
+    return LRP_OK;
+  }
+};
+
+}  // namespace lrp

@@ -1,0 +1,237 @@
+// engine.hip — the C ABI of liblrp_hip.so (include/lrp_hip.h).  Thin glue: argument
+// checks, host->device staging of the small index arrays, and dispatch into the
+// encoder (CNN half) and decoder (LSTM/attention half) orchestration.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_igemm.h"
+#include "decoder.h"
+#include "encoder.h"
+
+namespace lrp {
+std::string& last_error_ref() {
+  static thread_local std::string e;
+  return e;
+}
+}  // namespace lrp
+
+using namespace lrp;
+
+struct lrp_handle {
+  lrp_config cfg;
+  int64_t ws_bytes = 0;
+  Encoder enc;
+  Decoder dec;
+  DevBuf idx_dev;          // staged (img_idx | t) for the current explain call
+  DevBuf rfeat_tmp;        // R_feat when the caller does not want it back
+  int* idx_pinned = nullptr;
+  ~lrp_handle() {
+    if (idx_pinned) (void)hipHostFree(idx_pinned);
+  }
+};
+
+static hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int lrp_abi_version(void) { return LRP_ABI_VERSION; }
+const char* lrp_last_error(void) { return last_error_ref().c_str(); }
+
+int lrp_create(const lrp_config* cfg, lrp_handle** out) {
+  if (!cfg || !out) return fail(LRP_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (cfg->abi_version != LRP_ABI_VERSION) return fail(LRP_ERR_INVALID, "abi_version %d != %d", cfg->abi_version, LRP_ABI_VERSION);
+  if (cfg->decoder != LRP_DEC_ADAPTIVE && cfg->decoder != LRP_DEC_GRIDTD)
+    return fail(LRP_ERR_UNSUPPORTED, "unknown decoder kind %d", cfg->decoder);
+  if (cfg->max_images < 1 || cfg->max_tokens < 1 || cfg->max_caption_len < 2)
+    return fail(LRP_ERR_INVALID, "capacities must be positive (max_caption_len >= 2)");
+  LRP_HIP_CHECK(hipSetDevice(cfg->device));
+  lrp_handle* h = new lrp_handle();
+  h->cfg = *cfg;
+  int rc = h->enc.init(*cfg, &h->ws_bytes);
+  if (rc == LRP_OK) rc = h->dec.init(*cfg, &h->ws_bytes);
+  if (rc == LRP_OK) rc = h->idx_dev.alloc((size_t)cfg->max_tokens * 2 * sizeof(int), &h->ws_bytes);
+  if (rc == LRP_OK) rc = h->rfeat_tmp.alloc((size_t)cfg->max_tokens * cfg->L * cfg->D * sizeof(float), &h->ws_bytes);
+  if (rc == LRP_OK && hipHostMalloc(reinterpret_cast<void**>(&h->idx_pinned), (size_t)cfg->max_tokens * 2 * sizeof(int)) != hipSuccess)
+    rc = fail(LRP_ERR_NOMEM, "hipHostMalloc for index staging failed");
+  if (rc != LRP_OK) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return LRP_OK;
+}
+
+int lrp_destroy(lrp_handle* h) {
+  if (!h) return LRP_OK;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  delete h;
+  return LRP_OK;
+}
+
+int64_t lrp_workspace_bytes(const lrp_handle* h) { return h ? h->ws_bytes : 0; }
+
+static int set_weight_host(lrp_handle* h, const char* name, const float* data, int32_t ndim, const int64_t* shape) {
+  if (!h || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(LRP_ERR_INVALID, "bad lrp_set_weight arguments");
+  LRP_HIP_CHECK(hipSetDevice(h->cfg.device));
+  const std::string nm(name);
+  if (nm.size() > 2 && (nm.compare(nm.size() - 2, 2, "_W") == 0 || nm.compare(nm.size() - 2, 2, "_b") == 0)) {
+    const int li = h->enc.find_layer(nm.substr(0, nm.size() - 2));
+    if (li >= 0) {
+      const ConvLayer& L = h->enc.layers[li];
+      if (nm.back() == 'W') {
+        if (ndim != 4 || shape[0] != 3 || shape[1] != 3 || shape[2] != L.cin || shape[3] != L.cout)
+          return fail(LRP_ERR_INVALID, "%s: expected HWIO (3,3,%d,%d)", name, L.cin, L.cout);
+        return h->enc.set_conv_weight(li, data, &h->ws_bytes);
+      }
+      if (ndim != 1 || shape[0] != L.cout) return fail(LRP_ERR_INVALID, "%s: expected (%d,)", name, L.cout);
+      return h->enc.set_conv_bias(li, data, &h->ws_bytes);
+    }
+  }
+  return h->dec.set_weight(nm, data, ndim, shape, &h->ws_bytes);
+}
+
+int lrp_set_weight(lrp_handle* h, const char* name, const float* data_host, int32_t ndim, const int64_t* shape) {
+  return set_weight_host(h, name, data_host, ndim, shape);
+}
+
+int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev, int32_t ndim, const int64_t* shape,
+                       void* stream) {
+  if (!h || !data_dev || !shape || ndim < 1 || ndim > 4) return fail(LRP_ERR_INVALID, "bad lrp_set_weight_dev arguments");
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  std::vector<float> host(n);
+  LRP_HIP_CHECK(hipMemcpyAsync(host.data(), data_dev, n * sizeof(float), hipMemcpyDeviceToHost, S(stream)));
+  LRP_HIP_CHECK(hipStreamSynchronize(S(stream)));
+  return set_weight_host(h, name, host.data(), ndim, shape);
+}
+
+int lrp_encode_images(lrp_handle* h, const float* images_dev, int32_t B, void* stream) {
+  if (!h || !images_dev) return fail(LRP_ERR_INVALID, "null argument");
+  LRP_TRY(h->enc.encode(images_dev, B, S(stream)));
+  return h->dec.on_new_features(B);
+}
+
+int lrp_set_features(lrp_handle* h, const float* features_dev, int32_t B, void* stream) {
+  if (!h || !features_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (B < 1 || B > h->cfg.max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, h->cfg.max_images);
+  LRP_HIP_CHECK(hipMemcpyAsync(h->enc.feat.p, features_dev, (size_t)B * h->cfg.L * h->cfg.D * sizeof(float),
+                               hipMemcpyDeviceToDevice, S(stream)));
+  h->enc.encoded = B;
+  h->enc.features_only = true;
+  return h->dec.on_new_features(B);
+}
+
+int lrp_get_features(lrp_handle* h, float* features_dev, int32_t B, void* stream) {
+  if (!h || !features_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (B < 1 || B > h->enc.encoded) return fail(LRP_ERR_STATE, "only %d images are cached", h->enc.encoded);
+  LRP_HIP_CHECK(hipMemcpyAsync(features_dev, h->enc.feat.p, (size_t)B * h->cfg.L * h->cfg.D * sizeof(float),
+                               hipMemcpyDeviceToDevice, S(stream)));
+  return LRP_OK;
+}
+
+int lrp_decoder_forward(lrp_handle* h, const int32_t* captions_host, const int32_t* lengths_host, int32_t B, void* stream) {
+  if (!h || !captions_host || !lengths_host) return fail(LRP_ERR_INVALID, "null argument");
+  if (B < 1 || B > h->enc.encoded) return fail(LRP_ERR_STATE, "B=%d but %d images have features cached", B, h->enc.encoded);
+  return h->dec.forward(h->enc.feat.as<float>(), captions_host, lengths_host, B, S(stream));
+}
+
+int lrp_read_state(lrp_handle* h, const char* name, void* out_dev, size_t out_bytes, void* stream) {
+  if (!h || !name || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  return h->dec.read_state(name, out_dev, out_bytes, S(stream));
+}
+
+// stage (img_idx | t) into device memory; validates ranges against the cached captions
+static int stage_indices(lrp_handle* h, int n, const int32_t* img_idx, const int32_t* t, bool need_t, hipStream_t st) {
+  if (n < 1 || n > h->cfg.max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, h->cfg.max_tokens);
+  LRP_HIP_CHECK(hipStreamSynchronize(st));      // the pinned staging buffer may still be in flight
+  for (int i = 0; i < n; ++i) {
+    if (img_idx[i] < 0 || img_idx[i] >= h->enc.encoded)
+      return fail(LRP_ERR_INVALID, "img_idx[%d]=%d outside the %d cached images", i, img_idx[i], h->enc.encoded);
+    h->idx_pinned[i] = img_idx[i];
+    if (need_t) {
+      LRP_TRY(h->dec.check_token(img_idx[i], t[i]));
+      h->idx_pinned[n + i] = t[i];
+    }
+  }
+  LRP_HIP_CHECK(hipMemcpyAsync(h->idx_dev.p, h->idx_pinned, (size_t)n * (need_t ? 2 : 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  return LRP_OK;
+}
+
+int lrp_decoder_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const int32_t* t_host, int32_t variant,
+                        float* R_feat_dev, float* att_dev, double* r_words_dev, void* stream) {
+  if (!h || !img_idx_host || !t_host || !R_feat_dev) return fail(LRP_ERR_INVALID, "null argument");
+  LRP_TRY(stage_indices(h, n, img_idx_host, t_host, true, S(stream)));
+  return h->dec.explain(n, h->idx_dev.as<int>(), h->idx_dev.as<int>() + n, img_idx_host, t_host, variant,
+                        h->enc.feat.as<float>(), R_feat_dev, att_dev, r_words_dev, S(stream));
+}
+
+int lrp_cnn_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const float* R_feat_dev, float* R_img_dev,
+                    void* stream) {
+  if (!h || !img_idx_host || !R_feat_dev || !R_img_dev) return fail(LRP_ERR_INVALID, "null argument");
+  LRP_TRY(stage_indices(h, n, img_idx_host, nullptr, false, S(stream)));
+  return h->enc.explain(n, h->idx_dev.as<int>(), R_feat_dev, R_img_dev, S(stream));
+}
+
+int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const int32_t* t_host, int32_t variant,
+                       float* R_img_dev, float* R_feat_dev, float* att_dev, double* r_words_dev, void* stream) {
+  if (!h || !img_idx_host || !t_host || !R_img_dev) return fail(LRP_ERR_INVALID, "null argument");
+  LRP_TRY(stage_indices(h, n, img_idx_host, t_host, true, S(stream)));
+  float* rf = R_feat_dev ? R_feat_dev : h->rfeat_tmp.as<float>();
+  LRP_TRY(h->dec.explain(n, h->idx_dev.as<int>(), h->idx_dev.as<int>() + n, img_idx_host, t_host, variant,
+                         h->enc.feat.as<float>(), rf, att_dev, r_words_dev, S(stream)));
+  return h->enc.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
+}
+
+int lrp_profile_enable(lrp_handle* h, int32_t on) {
+  if (!h) return fail(LRP_ERR_INVALID, "null handle");
+  h->enc.profile = on != 0;
+  return LRP_OK;
+}
+
+int lrp_profile_query(lrp_handle* h, int64_t* n_launches, double* total_ms, double* total_flop) {
+  if (!h) return fail(LRP_ERR_INVALID, "null handle");
+  return h->enc.profile_query(n_launches, total_ms, total_flop);
+}
+
+int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias_host, const float* aux_dev, float* out_dev,
+                int32_t NB, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t taps, int32_t mode, void* stream) {
+  if (!in_dev || !w_hwio_host || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (taps != 1 && taps != 9) return fail(LRP_ERR_INVALID, "taps must be 1 or 9");
+  if (Cin % 4 != 0) return fail(LRP_ERR_UNSUPPORTED, "Cin must be a multiple of 4");
+  if (mode < 0 || mode > 3) return fail(LRP_ERR_INVALID, "mode must be 0..3");
+  const bool bwd = mode >= 2;
+  // forward: in has Cin channels, out Cout.  backward: in has Cout channels (S), out Cin (relevance of the input)
+  const int inC = bwd ? Cout : Cin, outC = bwd ? Cin : Cout;
+  if (inC % 4 != 0) return fail(LRP_ERR_UNSUPPORTED, "input channels must be a multiple of 4");
+  const int Np = conv_npad(outC), K = taps * conv_cinp(inC);
+  std::vector<float> pk((size_t)Np * K, 0.f);
+  if (bwd) pack_conv_bwd(w_hwio_host, taps, Cin, Cout, 0, pk.data());
+  else pack_conv_fwd(w_hwio_host, taps, Cin, Cout, 0, Np, pk.data());
+  DevBuf wdev, bdev;
+  LRP_TRY(wdev.alloc(pk.size() * sizeof(float), nullptr));
+  LRP_HIP_CHECK(hipMemcpy(wdev.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  ConvArgs ca{};
+  ca.in = in_dev; ca.wpk = wdev.as<float>(); ca.NB = NB; ca.H = H; ca.W = W; ca.Cin = inC; ca.CinP = conv_cinp(inC);
+  ca.N = outC; ca.taps = taps; ca.out = out_dev; ca.aux = aux_dev;
+  if (!bwd) {
+    if (!bias_host) return fail(LRP_ERR_INVALID, "bias required for forward modes");
+    LRP_TRY(bdev.alloc((size_t)Cout * sizeof(float), nullptr));
+    LRP_HIP_CHECK(hipMemcpy(bdev.p, bias_host, (size_t)Cout * sizeof(float), hipMemcpyHostToDevice));
+    ca.bias = bdev.as<float>();
+  } else if (!aux_dev) {
+    return fail(LRP_ERR_INVALID, "aux (gate) required for backward modes");
+  }
+  static const int epi_of_mode[4] = {EPI_BIAS_RELU, EPI_BIAS, EPI_MUL, EPI_MUL_UP2};
+  LRP_HIP_CHECK(conv_launch(epi_of_mode[mode], ca, S(stream)));
+  LRP_HIP_CHECK(hipStreamSynchronize(S(stream)));      // weights are freed on return
+  return LRP_OK;
+}
+
+}  // extern "C"

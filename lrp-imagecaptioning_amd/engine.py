@@ -1,0 +1,226 @@
+"""LRPEngine — thin Python owner of one `lrp_handle` (one per GPU / stream).
+
+PyTorch is plumbing only: it owns the device tensors that cross the C ABI
+(images, relevance maps) and the current stream.  All arithmetic of the hot
+path runs in liblrp_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .synthetic import VGG16_CFG
+
+
+def _i32(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class LRPEngine(object):
+    """Geometry + weights + caches for one captioning model on one GPU."""
+
+    def __init__(self, decoder="adaptive", cnn_cfg=VGG16_CFG, img_hw=(224, 224), L=196, D=512, H=512, E=512,
+                 V=10000, max_images=32, max_tokens=320, max_caption_len=21, sos_id=2, eos_id=1, device=None):
+        if decoder not in ("adaptive", "gridtd"):
+            raise NotImplementedError("decoder must be 'adaptive' or 'gridtd'")
+        self._lib = _capi.load()                      # raises if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("LRPEngine needs a ROCm GPU (no CPU fallback for the LRP hot path)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        cfg = _capi.LrpConfig()
+        cfg.abi_version = _capi.LRP_ABI_VERSION
+        cfg.device = self.device.index
+        cfg.decoder = _capi.LRP_DEC_ADAPTIVE if decoder == "adaptive" else _capi.LRP_DEC_GRIDTD
+        cfg.img_h, cfg.img_w = img_hw
+        cfg.n_conv = len(cnn_cfg)
+        for i, (name, cin, cout, pool) in enumerate(cnn_cfg):
+            cfg.conv_cin[i], cfg.conv_cout[i], cfg.conv_pool_after[i] = cin, cout, int(bool(pool))
+            cfg.conv_name[i].value = name.encode()
+        cfg.L, cfg.D, cfg.H, cfg.E, cfg.V = L, D, H, E, V
+        cfg.max_images, cfg.max_tokens, cfg.max_caption_len = max_images, max_tokens, max_caption_len
+        cfg.sos_id, cfg.eos_id = sos_id, eos_id
+        self.cfg = cfg
+        self.decoder = decoder
+        self.cnn_cfg = list(cnn_cfg)
+        self.img_hw = tuple(img_hw)
+        self.L, self.D, self.H, self.E, self.V = L, D, H, E, V
+        self.max_images, self.max_tokens, self.Tm = max_images, max_tokens, max_caption_len
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _capi.check(self._lib.lrp_create(C.byref(cfg), C.byref(self._h)))
+        self.captions = None
+        self.n_images = 0
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.lrp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self._lib.lrp_workspace_bytes(self._h))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, x, dtype=torch.float32):
+        if isinstance(x, torch.Tensor):
+            return x.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, weights):
+        """weights: dict name -> float32 array in the Keras layout (conv HWIO, dense (in,out))."""
+        for name, arr in weights.items():
+            if isinstance(arr, torch.Tensor):
+                arr = arr.detach().cpu().numpy()
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            _capi.check(self._lib.lrp_set_weight(self._h, name.encode(), a.ctypes.data_as(C.c_void_p), a.ndim, shape))
+
+    def set_weights_from_device(self, weights):
+        """Same, from CUDA tensors (e.g. after an RCCL broadcast of the frozen bundle)."""
+        for name, t in weights.items():
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _capi.check(self._lib.lrp_set_weight_dev(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.dim(), shape,
+                                                     self._stream()))
+
+    # ------------------------------------------------------------------ encoder
+    def encode_images(self, images):
+        """images (B,H,W,3) float32 BGR mean-subtracted -> caches; returns nothing."""
+        x = self._dev(images)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.img_hw[0], self.img_hw[1], 3):
+            raise ValueError("images must be (B,%d,%d,3)" % self.img_hw)
+        _capi.check(self._lib.lrp_encode_images(self._h, C.c_void_p(x.data_ptr()), x.shape[0], self._stream()))
+        self.n_images = int(x.shape[0])
+        self.captions = None
+
+    def set_features(self, feat):
+        f = self._dev(feat).reshape(-1, self.L, self.D)
+        _capi.check(self._lib.lrp_set_features(self._h, C.c_void_p(f.data_ptr()), f.shape[0], self._stream()))
+        self.n_images = int(f.shape[0])
+        self.captions = None
+
+    def get_features(self):
+        out = torch.empty((self.n_images, self.L, self.D), dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.lrp_get_features(self._h, C.c_void_p(out.data_ptr()), self.n_images, self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ decoder
+    def decoder_forward(self, captions):
+        """captions: list (per image) of tokenizer-id lists ending in EOS."""
+        B = len(captions)
+        caps = np.full((B, self.Tm), int(self.cfg.eos_id), dtype=np.int32)
+        lens = np.zeros((B,), dtype=np.int32)
+        for b, c in enumerate(captions):
+            if len(c) > self.Tm:
+                raise ValueError("caption %d longer than max_caption_len=%d" % (b, self.Tm))
+            caps[b, :len(c)] = c
+            lens[b] = len(c)
+        caps, pc = _i32(caps)
+        lens, pl = _i32(lens)
+        _capi.check(self._lib.lrp_decoder_forward(self._h, pc, pl, B, self._stream()))
+        self.captions = [list(map(int, c)) for c in captions]
+
+    _STATE_SHAPES = {
+        "ht": ("S", "H", torch.float32), "ct": ("S", "H", torch.float32), "gt": ("S", "H", torch.float32),
+        "it_act": ("S", "H", torch.float32), "ft_act": ("S", "H", torch.float32), "st": ("S", "H", torch.float32),
+        "attention": ("S", "L", torch.float32), "beta": ("S", 1, torch.float32),
+        "context": ("S", "H", torch.float64), "c_hat": ("S", "H", torch.float64),
+        "xt": ("T", "2E", torch.float32), "caption_preds": ("T", "V", torch.float64),
+        "image_features_before_act": ("L", "H", torch.float32), "average_img_feature": (1, "D", torch.float32),
+        "global_img_feature_before_act": (1, "E", torch.float32), "total_static_img_feature": ("L", "H", torch.float32),
+    }
+
+    def read_state(self, name):
+        """Cached decoder array for the images of the last forward: (B, rows, dim)."""
+        dims = {"S": self.Tm + 1, "T": self.Tm, "H": self.H, "L": self.L, "V": self.V, "D": self.D, "E": self.E,
+                "2E": 2 * self.E, 1: 1}
+        r, c, dt = self._STATE_SHAPES[name]
+        out = torch.empty((self.n_images, dims[r], dims[c]), dtype=dt, device=self.device)
+        _capi.check(self._lib.lrp_read_state(self._h, name.encode(), C.c_void_p(out.data_ptr()),
+                                             out.numel() * out.element_size(), self._stream()))
+        return out
+
+    def decoder_explain(self, img_idx, t, variant="sequence", want_attention=True, want_r_words=True):
+        n = len(img_idx)
+        ii, pi = _i32(img_idx)
+        tt, pt = _i32(t)
+        R = torch.empty((n, self.L, self.D), dtype=torch.float32, device=self.device)
+        att = torch.empty((n, self.L), dtype=torch.float32, device=self.device) if want_attention else None
+        rw = torch.empty((n, self.Tm), dtype=torch.float64, device=self.device) if want_r_words else None
+        v = _capi.LRP_EXPLAIN_SEQUENCE if variant == "sequence" else _capi.LRP_EXPLAIN_SINGLE_STEP
+        _capi.check(self._lib.lrp_decoder_explain(
+            self._h, n, pi, pt, v, C.c_void_p(R.data_ptr()),
+            C.c_void_p(att.data_ptr()) if att is not None else None,
+            C.c_void_p(rw.data_ptr()) if rw is not None else None, self._stream()))
+        return R, att, rw
+
+    # ------------------------------------------------------------------ CNN LRP
+    def cnn_explain(self, img_idx, R_feat, out=None):
+        n = len(img_idx)
+        ii, pi = _i32(img_idx)
+        R = self._dev(R_feat).reshape(n, self.L, self.D)
+        if out is None:
+            out = torch.empty((n, self.img_hw[0], self.img_hw[1], 3), dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.lrp_cnn_explain(self._h, n, pi, C.c_void_p(R.data_ptr()), C.c_void_p(out.data_ptr()),
+                                              self._stream()))
+        return out
+
+    def explain_tokens(self, img_idx, t, variant="sequence", out=None, want_R_feat=False, want_attention=False,
+                       want_r_words=False):
+        """Fused decoder-LRP -> CNN-LRP for n (image, t) pairs: (n,H,W,3) heat-map relevances."""
+        n = len(img_idx)
+        ii, pi = _i32(img_idx)
+        tt, pt = _i32(t)
+        if out is None:
+            out = torch.empty((n, self.img_hw[0], self.img_hw[1], 3), dtype=torch.float32, device=self.device)
+        R = torch.empty((n, self.L, self.D), dtype=torch.float32, device=self.device) if want_R_feat else None
+        att = torch.empty((n, self.L), dtype=torch.float32, device=self.device) if want_attention else None
+        rw = torch.empty((n, self.Tm), dtype=torch.float64, device=self.device) if want_r_words else None
+        v = _capi.LRP_EXPLAIN_SEQUENCE if variant == "sequence" else _capi.LRP_EXPLAIN_SINGLE_STEP
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        _capi.check(self._lib.lrp_explain_tokens(self._h, n, pi, pt, v, p(out), p(R), p(att), p(rw), self._stream()))
+        return out, R, att, rw
+
+    # ------------------------------------------------------------------ profiling hooks (bench.py)
+    def profile_enable(self, on=True):
+        _capi.check(self._lib.lrp_profile_enable(self._h, int(bool(on))))
+
+    def profile_query(self):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        _capi.check(self._lib.lrp_profile_query(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
+
+
+def op_conv(x, w_hwio, bias, aux, mode, taps=9):
+    """Operator-level entry for unit tests of the MFMA conv kernel (see lrp_op_conv)."""
+    lib = _capi.load()
+    dev = x.device
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    Cin, Cout = w.shape[2], w.shape[3]
+    NB, H, W, _ = x.shape
+    bwd = mode >= 2
+    if mode == 3:
+        out = torch.empty((NB, 2 * H, 2 * W, Cin), dtype=torch.float32, device=dev)
+    elif bwd:
+        out = torch.empty((NB, H, W, Cin), dtype=torch.float32, device=dev)
+    else:
+        out = torch.empty((NB, H, W, Cout), dtype=torch.float32, device=dev)
+    b = np.ascontiguousarray(bias, dtype=np.float32) if bias is not None else None
+    _capi.check(lib.lrp_op_conv(C.c_void_p(x.data_ptr()), w.ctypes.data_as(C.c_void_p),
+                                b.ctypes.data_as(C.c_void_p) if b is not None else None,
+                                C.c_void_p(aux.data_ptr()) if aux is not None else None,
+                                C.c_void_p(out.data_ptr()), NB, H, W, Cin, Cout, taps, mode,
+                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return out

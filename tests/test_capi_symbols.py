@@ -1,0 +1,59 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/lrp_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "lrp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lrp_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lrp_imagecaptioning_amd import _capi
+    from lrp_imagecaptioning_amd.build import build_library
+    build_library()
+    lib = _capi.load()
+    names = _declared()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _capi.SYMBOLS, "binding missing for " + n
+    assert sorted(_capi.SYMBOLS) == names
+    assert lib.lrp_abi_version() == _capi.LRP_ABI_VERSION
+
+
+def test_config_struct_layout_matches_header():
+    from lrp_imagecaptioning_amd import _capi
+    # 6 scalars + 3*32 ints + 32*32 chars + 5 + 3 + 2 ints
+    assert ctypes.sizeof(_capi.LrpConfig) == 4 * (6 + 3 * 32 + 5 + 3 + 2) + 32 * 32
+
+
+def test_error_path_without_gpu():
+    """Argument validation happens before any HIP call and reports through lrp_last_error."""
+    from lrp_imagecaptioning_amd import _capi
+    lib = _capi.load()
+    h = ctypes.c_void_p()
+    rc = lib.lrp_create(None, ctypes.byref(h))
+    assert rc == _capi.LRP_ERR_INVALID
+    assert b"null" in lib.lrp_last_error()
+    cfg = _capi.LrpConfig()
+    cfg.abi_version = 999
+    assert lib.lrp_create(ctypes.byref(cfg), ctypes.byref(h)) == _capi.LRP_ERR_INVALID
+    assert lib.lrp_destroy(None) == _capi.LRP_OK
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from lrp_imagecaptioning_amd import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _capi.load()
+    except _capi.LrpLibraryMissing as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the HIP library is missing")

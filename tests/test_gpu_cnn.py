@@ -1,0 +1,91 @@
+"""-m gpu: CNN half of the hot path (lrp_encode_images + lrp_cnn_explain ==
+LRPSequentialPresetA.analyze([X,R]), E:179-181) against the float64 literal
+oracle (oracle/cnn_lrp_ref.py).  Tolerance: BASELINE.json's 1e-4 relative L1."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l1
+from gpu_util import report
+from lrp_imagecaptioning_amd.synthetic import VGG16_CFG, images, vgg_weights
+from oracle import cnn_lrp_ref as C
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+TINY_CFG = [("c1", 3, 8, False), ("c2", 8, 8, True), ("c3", 8, 16, False), ("c4", 16, 16, True), ("c5", 16, 16, False)]
+MID_CFG = [("c1", 3, 64, False), ("c2", 64, 64, True), ("c3", 64, 128, True), ("c4", 128, 256, False), ("c5", 256, 128, False)]
+
+
+def _engine(cfg, hw, B, ntok, w):
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    side = hw
+    for _, _, _, p in cfg:
+        side = side // 2 if p else side
+    eng = LRPEngine(decoder="adaptive", cnn_cfg=cfg, img_hw=(hw, hw), L=side * side, D=cfg[-1][2], H=32, E=32, V=50,
+                    max_images=B, max_tokens=ntok, max_caption_len=4)
+    eng.set_weights(w)
+    return eng, side
+
+
+@pytest.mark.parametrize("name,cfg,hw,B", [("tiny", TINY_CFG, 16, 3), ("mid", MID_CFG, 32, 2)])
+def test_small_nets_match_oracle(name, cfg, hw, B):
+    rs = np.random.RandomState(7)
+    w = vgg_weights(rs, cfg, bias_std=0.3)
+    layers = C.vgg_layers(w, cfg)
+    X = rs.uniform(-120, 130, size=(B, hw, hw, 3)).astype(np.float32)
+    eng, side = _engine(cfg, hw, B, 2 * B, w)
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(B, side, side, -1)
+    feat_ref = C.forward(layers, X)
+    assert rel_l1(feat, feat_ref) < 1e-5
+    # two relevance maps per image, tokens interleaved to exercise the token -> image map
+    idx = [b for b in range(B)] + [B - 1 - b for b in range(B)]
+    R = (rs.standard_normal((2 * B,) + feat_ref.shape[1:]) * feat_ref[idx]).astype(np.float32)
+    out = eng.cnn_explain(idx, R).cpu().numpy()
+    ref = C.analyze(layers, X[idx], R)
+    errs = [rel_l1(out[i], ref[i]) for i in range(2 * B)]
+    report("cnn_" + name, max_rel_l1=max(errs))
+    assert np.isfinite(out).all()
+    assert max(errs) < TOL, errs
+
+
+def test_vgg16_full_size_matches_oracle():
+    """BASELINE geometry: 224x224, VGG16 to block5_conv3, 2 images x 2 relevance maps."""
+    rs = np.random.RandomState(0)
+    w = vgg_weights(rs)
+    layers = C.vgg_layers(w, VGG16_CFG)
+    X = images(rs, 2)
+    eng, side = _engine(VGG16_CFG, 224, 2, 4, w)
+    assert side == 14
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(2, 14, 14, 512)
+    feat_ref = C.forward(layers, X)
+    e_feat = rel_l1(feat, feat_ref)
+    idx = [0, 1, 1, 0]
+    R = (rs.standard_normal((4, 14, 14, 512)) * feat_ref[idx]).astype(np.float32)
+    out = eng.cnn_explain(idx, R).cpu().numpy()
+    ref = C.analyze(layers, X[idx], R)
+    errs = [rel_l1(out[i], ref[i]) for i in range(4)]
+    report("cnn_vgg16", feat_rel_l1=e_feat, max_rel_l1=max(errs))
+    assert e_feat < 1e-5
+    assert max(errs) < TOL, errs
+    # linearity in R (size-independent property): analyze(a*R1 + R2) = a*analyze(R1) + analyze(R2)
+    out2 = eng.cnn_explain([0, 0], np.stack([2.5 * R[0] + R[3], R[3]])).cpu().numpy()
+    assert rel_l1(out2[0], 2.5 * out[0] + out[3]) < 1e-5
+
+
+def test_state_errors():
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    rs = np.random.RandomState(1)
+    w = vgg_weights(rs, TINY_CFG)
+    eng, side = _engine(TINY_CFG, 16, 2, 2, w)
+    with pytest.raises(RuntimeError):                    # explain before encode
+        eng.cnn_explain([0], np.zeros((1, side * side, 16), np.float32))
+    eng.encode_images(rs.uniform(-100, 100, size=(2, 16, 16, 3)).astype(np.float32))
+    with pytest.raises(ValueError):                      # image index out of range
+        eng.cnn_explain([5], np.zeros((1, side * side, 16), np.float32))
+    with pytest.raises(ValueError):
+        eng.set_weights({"c1_W": np.zeros((3, 3, 3, 9), np.float32)})
+    with pytest.raises(NotImplementedError):
+        LRPEngine(decoder="transformer")
