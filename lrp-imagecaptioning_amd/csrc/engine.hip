@@ -175,6 +175,7 @@ int lrp_decoder_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, c
 int lrp_cnn_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const float* R_feat_dev, float* R_img_dev,
                     void* stream) {
   if (!h || !img_idx_host || !R_feat_dev || !R_img_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (h->enc.encoded < 1 || h->enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before lrp_cnn_explain");
   LRP_TRY(stage_indices(h, n, img_idx_host, nullptr, false, S(stream)));
   return h->enc.explain(n, h->idx_dev.as<int>(), R_feat_dev, R_img_dev, S(stream));
 }
