@@ -156,6 +156,9 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
  * launches and summed milliseconds since the last reset (syncs the events). */
 int lrp_profile_enable(lrp_handle* h, int32_t on);
 int lrp_profile_query(lrp_handle* h, int64_t* n_launches, double* total_ms, double* total_flop);
+/* Same, per launch: fills up to `cap` entries of ms_out / flop_out (in launch order) and
+ * returns the count in *n_out; the records are consumed. */
+int lrp_profile_records(lrp_handle* h, int32_t cap, double* ms_out, double* flop_out, int32_t* n_out);
 
 /* Workspace bytes held by the handle. */
 int64_t lrp_workspace_bytes(const lrp_handle* h);

@@ -43,6 +43,7 @@ SYMBOLS = {
     "lrp_explain_tokens": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, _P, _P]),
     "lrp_profile_enable": (C.c_int, [_P, C.c_int32]),
     "lrp_profile_query": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "lrp_profile_records": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "lrp_workspace_bytes": (C.c_int64, [_P]),
     "lrp_op_conv": (C.c_int, [_P, _P, _P, _P, _P] + [C.c_int32] * 7 + [_P]),
     "lrp_last_error": (C.c_char_p, []),

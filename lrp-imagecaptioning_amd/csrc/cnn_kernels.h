@@ -103,6 +103,43 @@ __global__ __launch_bounds__(256) void top_divide_kernel(const f32x4* __restrict
   }
 }
 
+// Image layer of the reverse walk (RR:306-312 with both sign branches live):
+//   R_img[p][c] = x+[p][c] * convT(S_1, w+)[p][c] + x-[p][c] * convT(S_1, w-)[p][c]
+// computed as a channel reduction FIRST (one K = C_1 GEMM on the MFMA kernel):
+//   T[q][tap*6 + c]   = sum_co S_1[q][co] * w+[tap][c][co]      (c = 0..2)
+//   T[q][tap*6 + 3+c] = sum_co S_1[q][co] * w-[tap][c][co]
+// and then this 9-tap shift-and-add:  convT(S,w)[p] = sum_tap T[p - d(tap)][tap],  d = (kh-1, kw-1).
+// (A direct N = 6 implicit GEMM would pad N to 32 and burn 5x the MFMA work.)
+constexpr int IMG_T_COLS = 54;
+__global__ __launch_bounds__(256) void img_stencil_kernel(const float* __restrict__ T, const float* __restrict__ ximg,
+                                                          const int* __restrict__ row2img, float* __restrict__ out,
+                                                          int n, int H, int W) {
+  const size_t total = (size_t)n * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int HW = H * W;
+    const int t = (int)(i / HW), pix = (int)(i - (size_t)t * HW);
+    const int h = pix / W, w = pix - h * W;
+    float pos[3] = {0.f, 0.f, 0.f}, neg[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int hh = h - (tap / 3 - 1), ww = w - (tap % 3 - 1);
+      if (hh >= 0 && hh < H && ww >= 0 && ww < W) {
+        const float* r = T + (((size_t)t * H + hh) * W + ww) * IMG_T_COLS + tap * 6;
+        const float2 a = *reinterpret_cast<const float2*>(r);
+        const float2 b = *reinterpret_cast<const float2*>(r + 2);
+        const float2 c = *reinterpret_cast<const float2*>(r + 4);
+        pos[0] += a.x; pos[1] += a.y; pos[2] += b.x;
+        neg[0] += b.y; neg[1] += c.x; neg[2] += c.y;
+      }
+    }
+    const int img = row2img ? row2img[t] : t;
+    const float* x = ximg + ((size_t)img * HW + pix) * 3;
+    float* o = out + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = x[c] >= 0.f ? x[c] * pos[c] : x[c] * neg[c];
+  }
+}
+
 inline int stream_grid(size_t work_items) {
   size_t b = (work_items + 255) / 256;
   if (b > 256 * 8) b = 256 * 8;      // 8 blocks per CU, grid-stride the rest

@@ -2,7 +2,7 @@
 // the LRP epilogues fused.  This one kernel family carries >95 % of the FLOPs
 // of the hot path:
 //   * encoder forward + Z+ pass           (EPI_FWD_DUAL)  — per image, cached
-//   * conv-LRP alpha1beta0 backward       (EPI_MUL / EPI_MUL_UP2 / EPI_IMG) — per token
+//   * conv-LRP alpha1beta0 backward       (EPI_MUL / EPI_MUL_UP2 / EPI_STORE) — per token
 //     RR:274-322 restructured: S_{l-1} = up2?(convT(S_l, w_l+)) * G_{l-1}
 //   * dense layers of the decoder prologue (taps = 1)
 //
@@ -31,7 +31,7 @@ enum ConvEpi {
   EPI_MUL = 2,        // out = acc * aux[img(row)]               (conv-LRP, no pool)
   EPI_MUL_UP2 = 3,    // out(2x res) = acc * aux[img(row)](2x)   (conv-LRP through a 2x2 max-pool)
   EPI_FWD_DUAL = 4,   // cols [0,split): out = relu(acc+bias); cols [split,2split): out2 = acc+bias  (a_l and Z+_l)
-  EPI_IMG = 5         // cols 0..2: conv with w+, 3..5: with w-;  out = x>=0 ? x*acc+ : x*acc-   (RR:306-312 at the image)
+  EPI_STORE = 5       // out = acc (row stride = N)   (image layer: tap-expanded channel reduction, see img_stencil_kernel)
 };
 
 struct ConvArgs {
@@ -53,7 +53,7 @@ struct ConvArgs {
 constexpr int LDS_STRIDE = 36;   // floats per staged row: 32 data + 4 pad (144 B)
 
 template <int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 32, BP = BN / 32;          // 32 rows per load pass (256 threads x 16 B)
   constexpr int STAGE = (BM + BN) * LDS_STRIDE;
@@ -129,13 +129,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * p) * LDS_STRIDE + chunk * 4) = rb[p];
   };
 
-  f32x16 acc[TM][TN];
+  // Two-level (blocked) summation: the MFMA is a strictly k-ordered fp32 fma chain, so a
+  // K = 4608 reduction in ONE accumulator carries ~sqrt(K) ulp of round-off.  Every FLUSH
+  // chunks (256 k) the running block is folded into `tot` and restarted: chains of 256 + K/256.
+  constexpr int FLUSH = 8;
+  f32x16 acc[TM][TN], tot[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
   load_chunk();
   store_chunk(0);
@@ -144,30 +148,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
   const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
 
+  auto mfma_step = [&](const float* Ab, const float* Bb, int kk) {
+    f32x4 af[TM], bf[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+  };
+
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
     if (more) load_chunk();                            // global loads fly under the MFMAs below
     const float* Ab = smem + buf * STAGE + a_off;
     const float* Bb = smem + buf * STAGE + b_off;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      f32x4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    }
+    mfma_step(Ab, Bb, 0);
+    mfma_step(Ab, Bb, 1);
+    // The other LDS buffer is free for the whole iteration (every wave passed the barrier
+    // after its last read of it), so the staged registers are written mid-chunk: the
+    // vmcnt wait and the ds_write issue hide under the second half's MFMAs instead of
+    // sitting between the last MFMA and the barrier.
+    __builtin_amdgcn_sched_barrier(0);
     if (more) store_chunk(buf ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_step(Ab, Bb, 2);
+    mfma_step(Ab, Bb, 3);
+    if ((kc & (FLUSH - 1)) == FLUSH - 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
     __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
 
   // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_base = n0 + wn * TN * 32 + (lane & 31);
@@ -186,6 +214,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
             a.out[(size_t)row * a.N + col] = v;
           }
+        }
+      } else if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = col_base + j * 32;
+          if (rv && col < a.N) a.out[(size_t)row * a.N + col] = acc[i][j][r];
         }
       } else if constexpr (EPI == EPI_FWD_DUAL) {
 #pragma unroll
@@ -231,31 +265,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
               }
             }
         }
-      } else if constexpr (EPI == EPI_IMG) {
-        // all lanes take part in the shuffle; only cols 0..2 of the first column tile store
-        const float vpos = acc[i][0][r];
-        const float vneg = __shfl(vpos, lane + 3, 64);
-        const int col = col_base;
-        if (rv && col < 3) {
-          const int n = row / HW, pix = row - n * HW;
-          const int img = a.row2img ? a.row2img[n] : n;
-          const float x = a.aux[((size_t)img * HW + pix) * 3 + col];
-          a.out[(size_t)row * 3 + col] = x >= 0.f ? x * vpos : x * vneg;
-        }
       }
     }
   }
 }
 
 // tile configurations: (WM,WN,TM,TN) -> BM x BN
-//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)
-//   n64   : 4,1,2,2 -> 256 x  64   (N == 64 layers)
-//   n32   : 4,1,2,1 -> 256 x  32   (N <= 32: image layer, tiny test nets)
+//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)            73.7 KB LDS, 2 blocks/CU
+//   n64   : 2,2,2,1 -> 128 x  64   (N == 64 layers)      55.3 KB LDS, 2 blocks/CU
+//   n32   : 4,1,1,1 -> 128 x  32   (N <= 32: tiny test nets)  46 KB LDS
 struct ConvTile { int BM, BN; };
 inline ConvTile conv_pick_tile(int N) {
   if (N > 64) return {128, 128};
-  if (N > 32) return {256, 64};
-  return {256, 32};
+  if (N > 32) return {128, 64};
+  return {128, 32};
 }
 inline int conv_npad(int N) { ConvTile t = conv_pick_tile(N); return (N + t.BN - 1) / t.BN * t.BN; }
 inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
@@ -271,9 +294,9 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if (t.BN == 128)
     hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI>), grid, block, 0, st, a);
   else if (t.BN == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, EPI>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 1, EPI>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, EPI>), grid, block, 0, st, a);
   return hipGetLastError();
 }
 
@@ -284,7 +307,7 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st) {
     case EPI_MUL: return conv_launch_epi<EPI_MUL>(a, st);
     case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2>(a, st);
     case EPI_FWD_DUAL: return conv_launch_epi<EPI_FWD_DUAL>(a, st);
-    case EPI_IMG: return conv_launch_epi<EPI_IMG>(a, st);
+    case EPI_STORE: return conv_launch_epi<EPI_STORE>(a, st);
   }
   return hipErrorInvalidValue;
 }

@@ -4,6 +4,7 @@
 // Reference semantics: LRPSequentialPresetA.analyze([X,R]) (AB:478-520) over the
 // sub-model input_1 -> block5_conv3 (E:29-32); rules RR:274-322, RA:470-480.
 #pragma once
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,7 +36,7 @@ struct Encoder {
   int img_h = 0, img_w = 0, max_images = 0, max_tokens = 0;
   int top_h = 0, top_w = 0, top_c = 0;
   std::vector<ConvLayer> layers;
-  DevBuf images;           // [max_images][H][W][3]   (x of the image layer, needed by EPI_IMG)
+  DevBuf images;           // [max_images][H][W][3]   (x of the image layer, needed by img_stencil_kernel)
   DevBuf a1;               // im2col of the image layer [max_images*H*W][64]
   DevBuf bufX, bufA, bufZ; // forward ping-pong (per call, all images)
   DevBuf feat;             // [max_images][top_h*top_w][top_c]  top activations (== CNN features)
@@ -72,6 +73,7 @@ struct Encoder {
     if (top_h * top_w != c.L || top_c != c.D)
       return fail(LRP_ERR_INVALID, "encoder output (%d x %d x %d) does not match L=%d, D=%d", top_h, top_w, top_c, c.L, c.D);
     const size_t B = (size_t)max_images, NT = (size_t)max_tokens;
+    const size_t max_tok_act = std::max(max_act, (size_t)img_h * img_w * IMG_T_COLS);   // T of the image layer
     LRP_TRY(images.alloc(B * img_h * img_w * 3 * sizeof(float), total));
     LRP_TRY(a1.alloc(B * img_h * img_w * 64 * sizeof(float), total));
     LRP_TRY(bufX.alloc(B * max_act * sizeof(float), total));
@@ -79,8 +81,8 @@ struct Encoder {
     LRP_TRY(bufZ.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(feat.alloc(B * T.act_elems() * sizeof(float), total));
     LRP_TRY(ztop.alloc(B * T.act_elems() * sizeof(float), total));
-    LRP_TRY(s0.alloc(NT * max_act * sizeof(float), total));
-    LRP_TRY(s1.alloc(NT * max_act * sizeof(float), total));
+    LRP_TRY(s0.alloc(NT * max_tok_act * sizeof(float), total));
+    LRP_TRY(s1.alloc(NT * max_tok_act * sizeof(float), total));
     for (size_t i = 0; i + 1 < layers.size(); ++i) LRP_TRY(layers[i].G.alloc(B * layers[i].act_elems() * sizeof(float), total));
     return LRP_OK;
   }
@@ -112,11 +114,16 @@ struct Encoder {
         }
       LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
-      // backward at the image: 6 output columns (3 with w+, 3 with w-)
-      const int Npb = conv_npad(6), Kb = 9 * conv_cinp(L.cout);
+      // backward at the image: tap-expanded channel reduction, 54 = 9 taps x (3 with w+ | 3 with w-)
+      // columns, K = cout; the 3x3 shift-and-add happens in img_stencil_kernel.
+      const int Npb = conv_npad(IMG_T_COLS), Kb = conv_cinp(L.cout);
       pk.assign((size_t)Npb * Kb, 0.f);
-      pack_conv_bwd(wp.data(), 9, 3, L.cout, 0, pk.data());
-      pack_conv_bwd(wn.data(), 9, 3, L.cout, 3, pk.data());
+      for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < 3; ++c)
+          for (int co = 0; co < L.cout; ++co) {
+            pk[(size_t)(t * 6 + c) * Kb + co] = wp[((size_t)t * 3 + c) * L.cout + co];
+            pk[(size_t)(t * 6 + 3 + c) * Kb + co] = wn[((size_t)t * 3 + c) * L.cout + co];
+          }
       LRP_TRY(L.w_bwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_bwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     } else {
@@ -221,7 +228,8 @@ struct Encoder {
       ca.row2img = row2img_dev;
       int epi;
       if (li == 0) {
-        ca.N = 6; ca.aux = images.as<float>(); ca.out = R_img_dev; epi = EPI_IMG;
+        ca.NB = n * L.H * L.W; ca.H = 1; ca.W = 1; ca.taps = 1;          // 1-tap GEMM over the pixels
+        ca.N = IMG_T_COLS; ca.out = Snext; epi = EPI_STORE;
       } else {
         const ConvLayer& P = layers[li - 1];
         ca.N = L.cin; ca.aux = P.G.as<float>(); ca.out = Snext;
@@ -240,6 +248,25 @@ struct Encoder {
       }
       float* t = S; S = Snext; Snext = t;
     }
+    {  // S now holds T (n, H, W, 54): 9-tap shift-and-add and the x+/x- selection
+      const ConvLayer& L0 = layers[0];
+      hipLaunchKernelGGL(img_stencil_kernel, dim3(stream_grid((size_t)n * L0.H * L0.W)), dim3(256), 0, st, S,
+                         images.as<float>(), row2img_dev, R_img_dev, n, L0.H, L0.W);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    return LRP_OK;
+  }
+
+  int profile_records(int cap, double* ms_out, double* flop_out, int* n_out) {
+    int k = 0;
+    for (ProfileRec& p : prof) {
+      float t = 0.f;
+      const bool ok = hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&t, p.e0, p.e1) == hipSuccess;
+      if (ok && k < cap) { ms_out[k] = t; flop_out[k] = p.flop; ++k; }
+      (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    prof.clear();
+    *n_out = k;
     return LRP_OK;
   }
 

@@ -201,6 +201,11 @@ int lrp_profile_query(lrp_handle* h, int64_t* n_launches, double* total_ms, doub
   return h->enc.profile_query(n_launches, total_ms, total_flop);
 }
 
+int lrp_profile_records(lrp_handle* h, int32_t cap, double* ms_out, double* flop_out, int32_t* n_out) {
+  if (!h || !ms_out || !flop_out || !n_out || cap < 0) return fail(LRP_ERR_INVALID, "bad lrp_profile_records arguments");
+  return h->enc.profile_records(cap, ms_out, flop_out, n_out);
+}
+
 int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias_host, const float* aux_dev, float* out_dev,
                 int32_t NB, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t taps, int32_t mode, void* stream) {
   if (!in_dev || !w_hwio_host || !out_dev) return fail(LRP_ERR_INVALID, "null argument");

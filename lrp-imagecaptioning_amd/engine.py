@@ -203,6 +203,17 @@ class LRPEngine(object):
         return n.value, ms.value, fl.value
 
 
+def _profile_records(self, cap=256):
+    ms = (C.c_double * cap)()
+    fl = (C.c_double * cap)()
+    n = C.c_int32()
+    _capi.check(self._lib.lrp_profile_records(self._h, cap, ms, fl, C.byref(n)))
+    return [(ms[i], fl[i]) for i in range(n.value)]
+
+
+LRPEngine.profile_records = _profile_records
+
+
 def op_conv(x, w_hwio, bias, aux, mode, taps=9):
     """Operator-level entry for unit tests of the MFMA conv kernel (see lrp_op_conv)."""
     lib = _capi.load()
