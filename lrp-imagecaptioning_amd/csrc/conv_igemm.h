@@ -9,8 +9,9 @@
 // GEMM view: D[m][n] = sum_k A[m][k] * B[k][n],  m = output pixel (NHWC row),
 // n = output channel, k = (tap, input channel).  A is gathered on the fly
 // (im2col never materialised); B is pre-packed [n][k] so both operands are
-// "rows of 32 consecutive k" = 128 B, staged through LDS with a 144 B row
-// stride (conflict-free ds_read_b128).
+// "rows of 32 consecutive k" = 128 B, staged through LDS unpadded with an XOR
+// swizzle of the 16 B chunk index, chunk ^ ((row>>1)&7): conflict-free for the
+// ds_read_b128 fragment reads AND the ds_write_b128 staging writes.
 //
 // MFMA: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  Lane l feeds
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; we let lane-half h consume
@@ -50,10 +51,15 @@ struct ConvArgs {
   int split;
 };
 
-constexpr int LDS_STRIDE = 36;   // floats per staged row: 32 data + 4 pad (144 B)
+constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
+
+// Out-of-image taps / ragged tails read this instead of branching around the load: the
+// select is two v_cndmask on the address, the load itself stays unconditional and the
+// eight loads of a chunk issue back to back.
+__device__ __attribute__((aligned(16))) const float lrp_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int WM, int WN, int TM, int TN, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 32, BP = BN / 32;          // 32 rows per load pass (256 threads x 16 B)
   constexpr int STAGE = (BM + BN) * LDS_STRIDE;
@@ -74,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
   const int chunk = tid & 7, lrow = tid >> 3;
+  const int wchunk = chunk ^ ((lrow >> 1) & 7);        // (row>>1)&7 is the same for rows lrow + 32p
   const int HW = a.H * a.W;
   const int K = a.taps * a.CinP;
   const int cpt = a.CinP >> 5;                         // 32-wide k chunks per tap
@@ -111,9 +118,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     const bool cvalid = (c0 + chunk * 4) < a.Cin;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (cvalid && ((amask[p] >> tap) & 1u)) v = *reinterpret_cast<const f32x4*>(aptr[p] + off);
-      ra[p] = v;
+      const float* src = (cvalid && ((amask[p] >> tap) & 1u)) ? aptr[p] + off : lrp_zero_page;
+      ra[p] = *reinterpret_cast<const f32x4*>(src);
     }
     const int kofs = tap * a.CinP + c0;
 #pragma unroll
@@ -124,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     float* As = smem + buf * STAGE;
     float* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
-    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(As + (lrow + 32 * p) * LDS_STRIDE + chunk * 4) = ra[p];
+    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(As + (lrow + 32 * p) * LDS_STRIDE + wchunk * 4) = ra[p];
 #pragma unroll
-    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * p) * LDS_STRIDE + chunk * 4) = rb[p];
+    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * p) * LDS_STRIDE + wchunk * 4) = rb[p];
   };
 
   // Two-level (blocked) summation: the MFMA is a strictly k-ordered fp32 fma chain, so a
@@ -145,15 +151,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   store_chunk(0);
   __syncthreads();
 
-  const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
-  const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE + (lane >> 5) * 4;
+  const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE;
+  const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE;
+  int koff[4];                                         // float offset of logical chunk 2kk+h in this lane's row
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) koff[kk] = (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 2);
 
   auto mfma_step = [&](const float* Ab, const float* Bb, int kk) {
     f32x4 af[TM], bf[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + kk * 8);
+    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + koff[kk]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + kk * 8);
+    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + koff[kk]);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -197,7 +206,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- conv-LRP epilogues: stage the C tile through the (now idle) LDS so that the gate loads
+  // and the relevance stores are 16 B per lane along the channel axis (a pixel's channels are
+  // contiguous in NHWC) instead of one dword per lane.
+  if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
+    static_assert(BM * BN <= 2 * STAGE, "C tile must fit the staging LDS");
+    float* Cs = smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Cs[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    __syncthreads();
+    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    const int c4 = tid % C4, rin = tid / C4;
+    const int col = n0 + c4 * 4;
+    const int tn0 = m0 / HW, tp0 = m0 - tn0 * HW;
+    const float invw = 1.0f / (float)a.W;
+    if (col < a.N) {
+#pragma unroll 4
+      for (int ps = 0; ps < BM / RPP; ++ps) {
+        const int lr = rin + ps * RPP, row = m0 + lr;
+        if (row >= a.M) break;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * 4);
+        int n = tn0, pix = tp0 + lr;
+        while (pix >= HW) { pix -= HW; ++n; }
+        const int img = a.row2img ? a.row2img[n] : n;
+        if constexpr (EPI == EPI_MUL) {
+          const f32x4 g = *reinterpret_cast<const f32x4*>(a.aux + ((size_t)img * HW + pix) * a.N + col);
+          *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + col) = v * g;
+        } else {
+          int h = (int)(((float)pix + 0.5f) * invw);
+          int w = pix - h * a.W;
+          if (w < 0) { --h; w += a.W; } else if (w >= a.W) { ++h; w -= a.W; }
+          const int W2 = 2 * a.W, H2 = 2 * a.H;
+          f32x4 g[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            g[q] = *reinterpret_cast<const f32x4*>(
+                a.aux + (((size_t)img * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(a.out + (((size_t)n * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col) =
+                v * g[q];
+        }
+      }
+    }
+    return;
+  }
+
+  // ---- scalar epilogues.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_base = n0 + wn * TN * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -234,46 +295,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
             }
           }
         }
-      } else if constexpr (EPI == EPI_MUL) {
-        size_t grow = 0;
-        if (rv) {
-          const int n = row / HW, pix = row - n * HW;
-          const int img = a.row2img ? a.row2img[n] : n;
-          grow = (size_t)img * HW + pix;
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = col_base + j * 32;
-          if (rv && col < a.N) a.out[(size_t)row * a.N + col] = acc[i][j][r] * a.aux[grow * a.N + col];
-        }
-      } else if constexpr (EPI == EPI_MUL_UP2) {
-        if (rv) {
-          const int n = row / HW, pix = row - n * HW;
-          const int h = pix / a.W, w = pix - h * a.W;
-          const int img = a.row2img ? a.row2img[n] : n;
-          const int W2 = 2 * a.W, H2 = 2 * a.H;
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-              const size_t orow = ((size_t)n * H2 + 2 * h + dy) * W2 + 2 * w + dx;
-              const size_t grow = ((size_t)img * H2 + 2 * h + dy) * W2 + 2 * w + dx;
-#pragma unroll
-              for (int j = 0; j < TN; ++j) {
-                const int col = col_base + j * 32;
-                if (col < a.N) a.out[orow * a.N + col] = acc[i][j][r] * a.aux[grow * a.N + col];
-              }
-            }
-        }
       }
     }
   }
 }
 
 // tile configurations: (WM,WN,TM,TN) -> BM x BN
-//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)            73.7 KB LDS, 2 blocks/CU
-//   n64   : 2,2,2,1 -> 128 x  64   (N == 64 layers)      55.3 KB LDS, 2 blocks/CU
-//   n32   : 4,1,1,1 -> 128 x  32   (N <= 32: tiny test nets)  46 KB LDS
+//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)            64 KB LDS, 2 blocks/CU
+//   n64   : 2,2,2,1 -> 128 x  64   (N == 64 layers)      48 KB LDS, 3 blocks/CU
+//   n32   : 4,1,1,1 -> 128 x  32   (N <= 32: tiny test nets)  40 KB LDS
 struct ConvTile { int BM, BN; };
 inline ConvTile conv_pick_tile(int N) {
   if (N > 64) return {128, 128};
@@ -285,6 +315,7 @@ inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
 
 template <int EPI>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
+  if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & 3)) return hipErrorInvalidValue;   // 16 B epilogue
   const ConvTile t = conv_pick_tile(a.N);
   a.M = a.NB * a.H * a.W;
   a.m_tiles = (a.M + t.BM - 1) / t.BM;

@@ -296,17 +296,35 @@ __global__ __launch_bounds__(256) void dec_explain_adaptive_kernel(ExplainArgs a
       q[j] = r_g / stab((double)a.gt[r1 + j]);
     }
     __syncthreads();
+    // GEMV acc[d] = sum_j WgT[j][d] * q[j].  Column indices are clamped (not branched) so the
+    // loads of 4 consecutive j are independent and all in flight together; lanes run along d
+    // (coalesced 256 B per wave-load).
     double acc[SCAN_MAXR];
+    int dcl[SCAN_MAXR];
 #pragma unroll
-    for (int r = 0; r < SCAN_MAXR; ++r) acc[r] = 0.0;
-    for (int j = 0; j < H; ++j) {
-      const double qj = q[j];
-      const float* wrow = a.WgT + (size_t)j * Nd;
+    for (int r = 0; r < SCAN_MAXR; ++r) { acc[r] = 0.0; const int d = tid + 256 * r; dcl[r] = d < Nd ? d : Nd - 1; }
+    const int nr = (Nd + 255) >> 8;                       // live accumulators (uniform)
+    int j = 0;
+    for (; j + 4 <= H; j += 4) {
+      float wv[4][SCAN_MAXR];
 #pragma unroll
-      for (int r = 0; r < SCAN_MAXR; ++r) {
-        const int d = tid + 256 * r;
-        if (d < Nd) acc[r] += (double)wrow[d] * qj;
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int r = 0; r < SCAN_MAXR; ++r)
+          if (r < nr) wv[u][r] = a.WgT[(size_t)(j + u) * Nd + dcl[r]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double qj = q[j + u];
+#pragma unroll
+        for (int r = 0; r < SCAN_MAXR; ++r)
+          if (r < nr) acc[r] += (double)wv[u][r] * qj;
       }
+    }
+    for (; j < H; ++j) {
+      const double qj = q[j];
+#pragma unroll
+      for (int r = 0; r < SCAN_MAXR; ++r)
+        if (r < nr) acc[r] += (double)a.WgT[(size_t)j * Nd + dcl[r]] * qj;
     }
     double wsum = 0.0;
 #pragma unroll
