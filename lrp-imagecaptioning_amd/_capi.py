@@ -62,6 +62,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Streams and device pointers
+    # cross this ABI, so the library MUST bind to the HIP runtime torch uses: import torch first
+    # (same SONAME -> the dynamic linker reuses the already loaded copy).  Loading in the other
+    # order leaves two runtimes in the process ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise LrpLibraryMissing(
             "%s not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "

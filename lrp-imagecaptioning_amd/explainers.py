@@ -1,0 +1,283 @@
+"""Engine classes with the reference's explainer protocol (models/explainers.py, cited E:).
+
+    ExplainImgCaptioningAttentionModel      E:22-256   (base: CNN analyzer, _explain_CNN, _explain_sentence)
+    ExplainImgCaptioningAdaptiveAttention   E:260-666
+    ExplainImgCaptioningGridTDModel         E:995-1321
+
+Same method names, argument meaning, return shapes/dtypes and error behaviour, so
+that `explain_image.Explainer`-style harnesses (explain_image.py:4-183) can drive
+them unchanged.  What differs is construction: there is no Keras model to pull
+weights from, so `model` is a `CaptionModelSpec` (geometry + a dict of arrays in
+the Keras layouts) and `weight_path` may name an `.npz` bundle of those arrays
+(hdf5 is not available).  All arithmetic runs in liblrp_hip.so through LRPEngine;
+these classes hold no math of their own.
+"""
+import numpy as np
+
+from .engine import LRPEngine
+from .synthetic import VGG16_CFG
+
+EPS = 0.01      # E:18  (CNN analyzer epsilon; only Dense layers use it, none in the truncated VGG16)
+ALPHA = 1       # E:19
+BETA = 0        # E:20
+
+
+class CaptionPreprocessorStub(object):
+    """The two attributes of models/preprocessors.py:CaptionPreprocessorAttention the hot path reads."""
+
+    def __init__(self, sos=2, eos=1, word_of=None):
+        self.SOS_TOKEN_LABEL_ENCODED = sos
+        self.EOS_TOKEN_LABEL_ENCODED = eos
+        self._word_of = word_of or {}
+
+    def decode_captions_from_list1d(self, ids):
+        return " ".join(self._word_of.get(int(i), "<%d>" % int(i)) for i in ids if int(i) != self.EOS_TOKEN_LABEL_ENCODED)
+
+
+class DatasetProviderStub(object):
+    def __init__(self, caption_preprocessor=None, image_preprocessor=None):
+        self.caption_preprocessor = caption_preprocessor or CaptionPreprocessorStub()
+        self.image_preprocessor = image_preprocessor
+
+
+class CaptionModelSpec(object):
+    """What the reference reads off `model` (E:26-39): encoder kind, dims, and the weights."""
+
+    def __init__(self, weights, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512,
+                 vocab_size=None, cnn_cfg=VGG16_CFG, img_hw=(224, 224)):
+        if img_encoder not in ("vgg16",):
+            raise NotImplementedError("the img_encode is not valid, [vgg16]")     # explain_image.py:25-26
+        self.weights = dict(weights)
+        self.img_encoder = img_encoder
+        self._hidden_dim, self._embedding_dim = hidden_dim, embedding_dim
+        self.L, self.D = L, D
+        self.vocab_size = vocab_size if vocab_size is not None else int(self.weights["output_W"].shape[1])
+        self.cnn_cfg = list(cnn_cfg)
+        self.img_hw = tuple(img_hw)
+
+
+class ExplainImgCaptioningAttentionModel(object):
+    _decoder_kind = None
+
+    def __init__(self, model, weight_path=None, dataset_provider=None, max_caption_length=20, max_images=1,
+                 device=None):
+        if weight_path:
+            with np.load(weight_path) as z:               # stands in for keras load_weights (E:27)
+                model.weights.update({k: z[k] for k in z.files})
+        self._model = model
+        self._img_encoder = model.img_encoder
+        self._dataset_provider = dataset_provider or DatasetProviderStub()
+        self._preprocessor = self._dataset_provider.caption_preprocessor
+        self._max_caption_length = max_caption_length
+        self._hidden_dim, self._embedding_dim = model._hidden_dim, model._embedding_dim
+        self.L, self.D = model.L, model.D
+        self._weight_path = (weight_path or "").strip("npz")
+        Tm = max_caption_length + 1
+        self._engine = LRPEngine(decoder=self._decoder_kind, cnn_cfg=model.cnn_cfg, img_hw=model.img_hw, L=model.L,
+                                 D=model.D, H=model._hidden_dim, E=model._embedding_dim, V=model.vocab_size,
+                                 max_images=max_images, max_tokens=max_images * Tm, max_caption_len=Tm,
+                                 sos_id=self._preprocessor.SOS_TOKEN_LABEL_ENCODED,
+                                 eos_id=self._preprocessor.EOS_TOKEN_LABEL_ENCODED, device=device)
+        self._engine.set_weights(model.weights)
+        self._CNN_explainer = _EngineAnalyzer(self._engine)      # LRPSequentialPresetA(image_model, EPS, 'replace'), E:32
+        self._state_cache = {}
+        self.caption = None
+        self.r_words = None
+
+    # -------------------------------------------------------------- cached forward state as attributes
+    _STATE_ATTRS = ()
+
+    def __getattr__(self, name):
+        if name.startswith("__") or name not in type(self)._STATE_ATTRS:
+            raise AttributeError(name)
+        if self.caption is None:
+            raise AttributeError("%s is only available after _forward_beam_search" % name)
+        if name not in self._state_cache:
+            self._state_cache[name] = self._fetch_state(name)
+        return self._state_cache[name]
+
+    def _fetch_state(self, name):
+        raise NotImplementedError()
+
+    # -------------------------------------------------------------- protocol
+    def _forward_beam_search(self, X, beam_search_captions):
+        """E:370-436 / E:1092-1178: cache everything LRP needs for a given caption.
+        X = (sequence_input, img_input); img_input (1,H,W,3) BGR mean-subtracted."""
+        _, img_input = X
+        self.caption = [int(c) for c in beam_search_captions]
+        self._state_cache = {}
+        self._img_input = np.asarray(img_input, dtype=np.float32)
+        self._engine.encode_images(self._img_input[:1])
+        self._engine.decoder_forward([self.caption])
+
+    def _check_t(self, t):
+        if self.caption is None:
+            raise RuntimeError("_forward_beam_search must run first")
+        if t > len(self.caption) or t < 1:
+            raise NotImplementedError("index out of range of captions")          # E:538-539
+
+    def _explain_lstm_single_word_sequence(self, t=0):
+        """E:537-666 / E:1180-1321 -> (R (1,sqrtL,sqrtL,D) float32, attention_t (L,)); sets self.r_words."""
+        self._check_t(t)
+        R, att, rw = self._engine.decoder_explain([0], [t], variant="sequence")
+        g = int(np.sqrt(self.L))
+        self.r_words = self._r_words_from(rw[0].cpu().numpy(), t)
+        return R.cpu().numpy().reshape(1, g, g, self.D), att[0].cpu().numpy()
+
+    def _explain_lstm_single_word(self, t=0):
+        """E:438-535 (one-step variant)."""
+        self._check_t(t)
+        R, att, _ = self._engine.decoder_explain([0], [t], variant="single_step", want_r_words=False)
+        g = int(np.sqrt(self.L))
+        return R.cpu().numpy().reshape(1, g, g, self.D), att[0].cpu().numpy()
+
+    def _r_words_from(self, row, t):
+        raise NotImplementedError()
+
+    def _explain_CNN(self, X, relevance_value):
+        """E:179-181: `self._CNN_explainer.analyze([X, R])`.  The reference re-runs the whole
+        encoder forward on every call (AB:511); when X is the image `_forward_beam_search`
+        already encoded, the cached relevance gates are reused instead."""
+        X = np.asarray(X, dtype=np.float32)
+        R = np.asarray(relevance_value, dtype=np.float32)
+        cached = getattr(self, "_img_input", None)
+        if (self.caption is not None and cached is not None and X.shape[0] == 1 and X.shape == cached[:1].shape
+                and np.array_equal(X, cached[:1])):
+            n = R.shape[0]
+            return self._engine.cnn_explain([0] * n, R.reshape(n, self.L, self.D)).cpu().numpy()
+        out = self._CNN_explainer.analyze([X, R])        # another image: the caches now belong to it
+        self.caption = None
+        self._state_cache = {}
+        return out
+
+    def _explain_sentence(self):
+        """E:183-189, but all tokens in ONE batched launch chain."""
+        n = len(self.caption) - 1
+        ts = list(range(1, n + 1))
+        R, att, rw = self._engine.decoder_explain([0] * n, ts, variant="sequence")
+        g = int(np.sqrt(self.L))
+        Rn = R.cpu().numpy()
+        if n:
+            self.r_words = self._r_words_from(rw[n - 1].cpu().numpy(), n)
+        rel = [Rn[i].reshape(1, g, g, self.D) for i in range(n)]
+        return rel, self.attention[1:-1]
+
+    # -------------------------------------------------------------- batched entry points (new)
+    def explain_batch(self, images, captions, return_R_feat=False):
+        """images (B,H,W,3), captions: list of id lists ending in EOS.  Returns
+        (R_img (sum_b T_b, H, W, 3) torch tensor on the GPU, index list [(b, t)], attention, r_words)."""
+        self._engine.encode_images(images)
+        self._engine.decoder_forward(captions)
+        pairs = [(b, t) for b, c in enumerate(captions) for t in range(1, len(c))]
+        out, R, att, rw = self._engine.explain_tokens([p[0] for p in pairs], [p[1] for p in pairs],
+                                                      want_R_feat=return_R_feat, want_attention=True, want_r_words=True)
+        return out, pairs, att, rw, R
+
+    def _beam_search(self, X, beam_size=3):
+        """Caption generation (E:51-120) on top of the teacher-forced decoder replay: step s
+        re-plays the current beams and reads the logits of position s.  Upstream of the LRP
+        path (captions are an input to it); provided so harnesses run end to end."""
+        _, imgs_input = X
+        imgs_input = np.asarray(imgs_input, dtype=np.float32)
+        EOS, SOS = self._preprocessor.EOS_TOKEN_LABEL_ENCODED, self._preprocessor.SOS_TOKEN_LABEL_ENCODED
+        results = []
+        for img in imgs_input:
+            eng = self._engine
+            beams = [([], 0.0)]                  # (word ids so far, log prob)
+            complete = []
+            eng.encode_images(img[None])
+            for s in range(self._max_caption_length):
+                cand = []
+                for words, lp in beams:
+                    eng.decoder_forward([words + [EOS]])
+                    logits = eng.read_state("caption_preds")[0, s].cpu().numpy()
+                    logp = logits - logits.max()
+                    logp = logp - np.log(np.exp(logp).sum())
+                    top = np.argpartition(logp, -beam_size)[-beam_size:]
+                    for k in top:
+                        w = int(k) + 1                      # model column -> tokenizer id (E:92)
+                        if w == EOS:
+                            complete.append((words, lp + float(logp[k])))
+                        cand.append((words + [w], lp + float(logp[k])))
+                cand.sort(key=lambda c: -c[1])
+                beams = [c for c in cand if c[0][-1] != EOS][:beam_size] or cand[:beam_size]
+            complete.sort(key=lambda c: -c[1])
+            beams.sort(key=lambda c: -c[1])
+            out = []
+            for i in range(beam_size):
+                if i < len(complete):
+                    out.append(complete[i][0] + [EOS])
+                elif i < len(beams):
+                    out.append(beams[i][0] + [EOS])
+            results.append(out)
+        self.caption = None
+        return results[0] if len(results) == 1 else results
+
+
+class _EngineAnalyzer(object):
+    """`analyze([X, R])` of LRPSequentialPresetA (AB:478-520) on an engine's encoder."""
+
+    def __init__(self, engine):
+        self._engine = engine
+
+    def analyze(self, X):
+        X = list(X) if isinstance(X, (list, tuple)) else [X]
+        if len(X) != 2:
+            raise ValueError("neuron_selection_mode 'replace' expects [X, R]")
+        img, R = np.asarray(X[0], dtype=np.float32), np.asarray(X[1], dtype=np.float32)
+        n = img.shape[0]
+        if R.shape[0] != n:
+            raise ValueError("X and R must have the same batch size")
+        e = self._engine
+        out = np.empty_like(img)
+        for lo in range(0, n, e.max_images):
+            hi = min(n, lo + e.max_images, lo + e.max_tokens)
+            e.encode_images(img[lo:hi])
+            out[lo:hi] = e.cnn_explain(list(range(hi - lo)), R[lo:hi].reshape(hi - lo, e.L, e.D)).cpu().numpy()
+        return out
+
+
+class ExplainImgCaptioningAdaptiveAttention(ExplainImgCaptioningAttentionModel):
+    """E:260-666."""
+    _decoder_kind = "adaptive"
+    _STATE_ATTRS = ("ht", "ct", "gt", "it_act", "ft_act", "context", "attention", "st", "beta", "c_hat", "xt",
+                    "caption_preds", "_image_features_before_act", "_average_img_feature",
+                    "_global_img_feature_before_act", "_total_static_img_feature", "_img_feature_input")
+    _ENGINE_NAME = {"_image_features_before_act": "image_features_before_act",
+                    "_average_img_feature": "average_img_feature",
+                    "_global_img_feature_before_act": "global_img_feature_before_act",
+                    "_total_static_img_feature": "total_static_img_feature"}
+
+    def _fetch_state(self, name):
+        n = len(self.caption)
+        if name == "_img_feature_input":
+            return self._engine.get_features()[0].cpu().numpy()
+        a = self._engine.read_state(self._ENGINE_NAME.get(name, name))[0].cpu().numpy()
+        if name in ("xt", "caption_preds"):
+            return a[:n]
+        if name.startswith("_"):
+            return a[0] if a.shape[0] == 1 else a
+        return a[:n + 1]                              # row 0 = zero init (E:389-398)
+
+    def _r_words_from(self, row, t):
+        return row[:t - 1]                            # normalised, first dropped (E:660-665)
+
+
+class ExplainImgCaptioningGridTDModel(ExplainImgCaptioningAttentionModel):
+    """E:995-1321."""
+    _decoder_kind = "gridtd"
+    _STATE_ATTRS = ("h1t", "c1t", "g1t", "i1t_act", "f1t_act", "h2t", "c2t", "g2t", "i2t_act", "f2t_act", "x1t", "x2t",
+                    "context", "st", "beta", "context_hat", "attention", "caption_preds")
+
+    def _fetch_state(self, name):
+        n = len(self.caption)
+        a = self._engine.read_state(name)[0].cpu().numpy()
+        if name in ("x1t", "x2t", "caption_preds"):
+            return a[:n]
+        return a[:n + 1]
+
+    def _r_words_from(self, row, t):
+        return row[:t]                                # un-normalised (E:1320)
+
+    def _explain_lstm_single_word(self, t=0):
+        raise NotImplementedError()                   # E:167-172: the grid-TD class does not override it

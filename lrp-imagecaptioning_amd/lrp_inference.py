@@ -1,0 +1,83 @@
+"""Batched driver of the hot path used during LRP-inference fine-tuning
+(models/model.py:1379-1691 LRPInferenceLayerAdaptive, call() at :1641-1691):
+for every image and every non-stop-word position of its predicted caption one
+heat-map -> one scalar score -> lrp_weight[b, i, word] = 1 + score.
+
+The reference loops image by image, word by word (B x <=20 sequential LRP passes);
+here all (image, position) units of the batch go through ONE explain call."""
+import numpy as np
+import torch
+
+
+class LRPInferenceLayerAdaptive(object):
+    def __init__(self, explainer, lrp_inference_mode="mean", stop_words=(), color_conversion="BGRtoRGB"):
+        if lrp_inference_mode not in ("mean", "pos_mean", "quantile"):
+            raise NotImplementedError("the lrp inference mode is not available")      # model.py:1685-1686
+        self._explainer = explainer
+        self._engine = explainer._engine
+        self._preprocessor = explainer._preprocessor
+        self._EOS_ENCODED = self._preprocessor.EOS_TOKEN_LABEL_ENCODED
+        self._lrp_inference_mode = lrp_inference_mode
+        self._stop_words = set(stop_words)
+        self._color_conversion = color_conversion
+
+    def _positions(self, caption_encoded):
+        """model.py:1664-1671: skip stop words, stop at EOS."""
+        out = []
+        for i, w in enumerate(caption_encoded):
+            word = self._preprocessor._word_of.get(int(w)) if getattr(self._preprocessor, "_word_of", None) else None
+            if word is not None and word in self._stop_words:
+                continue
+            if int(w) == self._EOS_ENCODED:
+                break
+            out.append(i)
+        return out
+
+    def call(self, inputs):
+        assert len(inputs) == 3
+        _, img_inputs, y_preds = inputs
+        y_preds = np.asarray(y_preds)
+        B, T, V = y_preds.shape
+        eng = self._engine
+        if B > eng.max_images:
+            raise ValueError("batch larger than the engine's max_images")
+        caps, pairs = [], []
+        for b in range(B):
+            cap = (np.argmax(y_preds[b], axis=-1) + 1).astype(np.int64)             # model.py:1661-1662
+            # the replay needs a caption that ends in EOS: cut at the first EOS (positions after it are never explained)
+            eos = np.where(cap == self._EOS_ENCODED)[0]
+            n = int(eos[0]) + 1 if len(eos) else T
+            c = [int(x) for x in cap[:n]]
+            if c[-1] != self._EOS_ENCODED:
+                c = c[:eng.Tm - 1] + [self._EOS_ENCODED]
+            caps.append(c)
+            for i in self._positions(cap):
+                if i < len(c):
+                    pairs.append((b, i, int(cap[i])))
+        out = np.zeros(y_preds.shape, dtype=np.float64)
+        if pairs:
+            eng.encode_images(img_inputs)
+            eng.decoder_forward(caps)
+            for lo in range(0, len(pairs), eng.max_tokens):
+                chunk = pairs[lo:lo + eng.max_tokens]
+                R, _, _, _ = eng.explain_tokens([p[0] for p in chunk], [p[1] + 1 for p in chunk])
+                scores = self._scores(R)
+                for (b, i, w), s in zip(chunk, scores):
+                    if w < V:
+                        out[b, i, w] = s                                            # model.py:1687 (index = tokenizer id)
+        return 1 + out                                                              # model.py:1690
+
+    def _scores(self, R):
+        """model.py:1675-1686 on the device tensor R (n,H,W,3): the BGR->RGB flip does not change a
+        channel mean, so it is omitted; hp = mean_c(R) / max|.|."""
+        hp = R.mean(dim=-1)
+        m = hp.abs().amax(dim=(1, 2), keepdim=True)
+        hp = torch.where(m > 0, hp / m.clamp_min(1e-45), torch.zeros_like(hp)).double()
+        flat = hp.reshape(hp.shape[0], -1)
+        if self._lrp_inference_mode == "mean":
+            s = flat.mean(dim=1)
+        elif self._lrp_inference_mode == "pos_mean":
+            s = flat.clamp_min(0).mean(dim=1)
+        else:
+            s = torch.quantile(flat, 0.9, dim=1)
+        return s.cpu().numpy()

@@ -1,0 +1,165 @@
+"""-m gpu: the reference-facing Python surface (explainer classes, analyzer, harness,
+LRP-inference driver) end to end against the CPU oracles."""
+import numpy as np
+import pytest
+
+from conftest import rel_l1
+from gpu_util import report
+from lrp_imagecaptioning_amd.synthetic import adaptive_weights, vgg_weights
+from oracle import cnn_lrp_ref as C
+from oracle.decoder_ref import AdaptiveOracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CFG = [("c1", 3, 8, False), ("c2", 8, 8, True), ("c3", 8, 16, True), ("c4", 16, 16, False)]
+HW, L, D, H, V = 16, 16, 16, 32, 40
+
+
+def _weights(seed=0):
+    rs = np.random.RandomState(seed)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update(adaptive_weights(rs, L, D, H, H, V))
+    return w, rs
+
+
+def _spec(w):
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec
+    return CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V,
+                            cnn_cfg=CFG, img_hw=(HW, HW))
+
+
+def _oracle(w, X, cap):
+    layers = C.vgg_layers(w, CFG)
+    feat = C.forward(layers, X).astype(np.float32)
+    o = AdaptiveOracle(w, L, D, H, H)
+    o.forward(feat, cap)
+    return layers, o
+
+
+def test_explainer_protocol_matches_oracle():
+    from lrp_imagecaptioning_amd.explainers import ExplainImgCaptioningAdaptiveAttention
+    w, rs = _weights()
+    X = rs.uniform(-120, 130, size=(1, HW, HW, 3)).astype(np.float32)
+    cap = [7, 12, 33, 5, 1]
+    ex = ExplainImgCaptioningAdaptiveAttention(_spec(w), None, None, max_caption_length=8)
+    ex._forward_beam_search((None, X), cap)
+    layers, o = _oracle(w, X, cap)
+    assert ex.ht.shape == (len(cap) + 1, H) and ex.ht.dtype == np.float32
+    assert ex.context.dtype == np.float64 and ex.caption_preds.shape == (len(cap), V)
+    assert rel_l1(ex.ht, o.ht) < 1e-5 and rel_l1(ex.caption_preds, o.caption_preds) < 1e-5
+    rel, att = ex._explain_sentence()
+    assert len(rel) == len(cap) - 1 and att.shape == (len(cap) - 1, L)
+    worst = 0.0
+    for i, R in enumerate(rel):
+        assert R.shape == (1, 4, 4, D) and R.dtype == np.float32
+        Rref, _ = o.explain(i + 1)
+        img = ex._explain_CNN(X, R)
+        ref = C.analyze(layers, X, Rref)
+        assert img.shape == X.shape
+        worst = max(worst, rel_l1(img, ref))
+    report("api_protocol", max_rel_l1=worst)
+    assert worst < TOL
+    np.testing.assert_allclose(ex.r_words, o.r_words, rtol=1e-4, atol=1e-8)
+    R1, a1 = ex._explain_lstm_single_word_sequence(2)
+    assert rel_l1(R1, o.explain(2)[0]) < TOL
+    np.testing.assert_allclose(ex.r_words, o.r_words, rtol=1e-4, atol=1e-8)
+    R2, _ = ex._explain_lstm_single_word(2)
+    assert rel_l1(R2, o.explain_single_step(2)[0]) < TOL
+    with pytest.raises(NotImplementedError):
+        ex._explain_lstm_single_word_sequence(len(cap) + 1)
+
+
+def test_explain_batch_and_beam_search():
+    from lrp_imagecaptioning_amd.explainers import ExplainImgCaptioningAdaptiveAttention
+    w, rs = _weights(3)
+    X = rs.uniform(-120, 130, size=(2, HW, HW, 3)).astype(np.float32)
+    caps = [[9, 4, 1], [3, 17, 25, 30, 1]]
+    ex = ExplainImgCaptioningAdaptiveAttention(_spec(w), None, None, max_caption_length=6, max_images=2)
+    out, pairs, att, rw, _ = ex.explain_batch(X, caps)
+    assert pairs == [(0, 1), (0, 2), (1, 1), (1, 2), (1, 3), (1, 4)]
+    out = out.cpu().numpy()
+    worst = 0.0
+    for b in range(2):
+        layers, o = _oracle(w, X[b:b + 1], caps[b])
+        for j, (bb, t) in enumerate(pairs):
+            if bb == b:
+                worst = max(worst, rel_l1(out[j], C.analyze(layers, X[b:b + 1], o.explain(t)[0])[0]))
+    assert worst < TOL
+    beams = ex._beam_search((None, X[:1]), beam_size=3)
+    assert len(beams) == 3 and all(b[-1] == 1 for b in beams)
+    # greedy check of the best beam's first word against the oracle's step-0 logits
+    _, o = _oracle(w, X[:1], [5, 1])
+    first_words = {b[0] for b in beams}
+    assert int(np.argmax(o.caption_preds[0])) + 1 in first_words
+
+
+def test_analyzer_interface():
+    from lrp_imagecaptioning_amd.analyzer import ImageModelSpec, LRPSequentialPresetA
+    w, rs = _weights(5)
+    with pytest.raises(ValueError):
+        LRPSequentialPresetA(ImageModelSpec(w, CFG, (HW, HW)), epsilon=0.01, neuron_selection_mode="bogus")
+    an = LRPSequentialPresetA(ImageModelSpec(w, CFG, (HW, HW)), epsilon=0.01, neuron_selection_mode="replace", max_batch=2)
+    X = rs.uniform(-120, 130, size=(3, HW, HW, 3)).astype(np.float32)
+    layers = C.vgg_layers(w, CFG)
+    feat = C.forward(layers, X)
+    R = (rs.standard_normal(feat.shape) * feat).astype(np.float32)
+    out = an.analyze([X, R])                       # N=3 with max_batch=2: two chunks
+    ref = C.analyze(layers, X, R)
+    assert out.shape == X.shape and out.dtype == np.float32
+    assert max(rel_l1(out[i], ref[i]) for i in range(3)) < TOL
+    with pytest.raises(ValueError):
+        an.analyze([X, R], neuron_selection=3)
+
+
+def test_lrp_inference_layer_matches_reference_loop():
+    from lrp_imagecaptioning_amd.explainers import (CaptionPreprocessorStub, DatasetProviderStub,
+                                                    ExplainImgCaptioningAdaptiveAttention)
+    from lrp_imagecaptioning_amd.lrp_inference import LRPInferenceLayerAdaptive
+    from lrp_imagecaptioning_amd.postprocess import lrp_inference_score
+    w, rs = _weights(8)
+    B, T = 2, 5
+    X = rs.uniform(-120, 130, size=(B, HW, HW, 3)).astype(np.float32)
+    y = rs.standard_normal((B, T, V))
+    y[0, 3, 0] = 50.0                              # image 0: EOS (id 1 = column 0) at position 3
+    word_of = {i: "w%d" % i for i in range(1, V + 1)}
+    stop = {"w%d" % (int(np.argmax(y[1, 1])) + 1)}  # make image 1 / position 1 a stop word
+    prov = DatasetProviderStub(CaptionPreprocessorStub(2, 1, word_of))
+    ex = ExplainImgCaptioningAdaptiveAttention(_spec(w), None, prov, max_caption_length=T, max_images=B)
+    for mode in ("mean", "pos_mean", "quantile"):
+        layer = LRPInferenceLayerAdaptive(ex, mode, stop_words=stop)
+        got = layer.call([None, X, y])
+        assert got.shape == y.shape
+        want = np.zeros(y.shape)
+        for b in range(B):                          # the reference loop, model.py:1657-1689, on the oracles
+            cap = list(np.argmax(y[b], axis=-1) + 1)
+            eos = cap.index(1) if 1 in cap else None
+            full = [int(c) for c in (cap[:eos + 1] if eos is not None else cap + [1])]
+            layers, o = _oracle(w, X[b:b + 1], full)
+            for i in range(T):
+                if word_of[int(cap[i])] in stop:
+                    continue
+                if cap[i] == 1:
+                    break
+                rel = C.analyze(layers, X[b:b + 1], o.explain(i + 1)[0])
+                if cap[i] < V:
+                    want[b, i, cap[i]] = lrp_inference_score(rel, mode)
+        np.testing.assert_allclose(got, 1 + want, rtol=2e-3, atol=2e-5)
+        assert (got[0, 3:] == 1).all()              # nothing after EOS
+
+
+def test_harness_returns_arrays():
+    from lrp_imagecaptioning_amd.explainers import ExplainImgCaptioningAdaptiveAttention
+    from lrp_imagecaptioning_amd.harness import Explainer
+    w, rs = _weights(2)
+    spec = _spec(w)
+    ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=6)
+    hz = Explainer(spec, None, ex, 6, beam_size=2)
+    X = (2, rs.uniform(-120, 130, size=(1, HW, HW, 3)).astype(np.float32))
+    caps = hz._predict_caption(X)
+    res = hz._explain_captions(X, caps)
+    n = len(caps) - 1
+    assert res["relevance"].shape == (n, HW, HW, 3) and res["heatmaps"].shape == (n, HW, HW, 3)
+    assert res["attention"].shape == (n, L)
+    assert np.isfinite(res["relevance"]).all()
+    one = hz._explain_single_word(X, caps, None, 1)
+    assert one["heatmap"].shape == (HW, HW, 3) and one["heatmap"].max() <= 255
