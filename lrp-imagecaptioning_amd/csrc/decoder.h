@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "conv_igemm.h"
+#include "decoder_gridtd_kernels.h"
 #include "decoder_kernels.h"
 
 namespace lrp {
@@ -38,6 +39,8 @@ struct Decoder {
   bool have_forward = false;
   // explain scratch
   DevBuf rctx, ravg;
+  // grid-TD only
+  DevBuf Wcat2, bcat2, Wg2T, xh1d, xh2d, zg1d, zg2d, hprojd, sprojd, h2u, rho;
 
   int init(const lrp_config& c, int64_t* total) {
     kind = c.decoder; L = c.L; D = c.D; H = c.H; E = c.E; V = c.V; Tm = c.max_caption_len;
@@ -60,6 +63,24 @@ struct Decoder {
       LRP_TRY(st("c_hat", B * S * H, 8));
       LRP_TRY(st("xt", B * Tm * 2 * E, 4));
       LRP_TRY(st("caption_preds", B * Tm * V, 8));
+    }
+    if (kind == LRP_DEC_GRIDTD) {
+      for (const char* nm : {"h1t", "c1t", "g1t", "i1t_act", "f1t_act", "h2t", "c2t", "g2t", "i2t_act", "f2t_act",
+                             "context", "st", "context_hat"})
+        LRP_TRY(st(nm, B * S * H, 8));
+      LRP_TRY(st("attention", B * S * L, 8));
+      LRP_TRY(st("beta", B * S, 8));
+      LRP_TRY(st("x1t", B * Tm * (H + 2 * E), 8));
+      LRP_TRY(st("x2t", B * Tm * 2 * H, 8));
+      LRP_TRY(st("caption_preds", B * Tm * V, 8));
+      LRP_TRY(xh1d.alloc(B * (2 * H + 2 * E) * 8, total));
+      LRP_TRY(xh2d.alloc(B * 3 * H * 8, total));
+      LRP_TRY(zg1d.alloc(B * 5 * H * 8, total));
+      LRP_TRY(zg2d.alloc(B * 4 * H * 8, total));
+      LRP_TRY(hprojd.alloc(B * H * 8, total));
+      LRP_TRY(sprojd.alloc(B * H * 8, total));
+      LRP_TRY(h2u.alloc(B * Tm * H * 8, total));
+      LRP_TRY(rho.alloc((size_t)NT_max * Tm * H * 8, total));
     }
     LRP_TRY(vfeat.alloc(B * L * H * 4, total));
     LRP_TRY(if_pre.alloc(B * L * H * 4, total));
@@ -122,20 +143,17 @@ struct Decoder {
     return LRP_OK;
   }
 
-  int finalize(int64_t* total) {
-    if (finalized) return LRP_OK;
-    if (kind != LRP_DEC_ADAPTIVE) return fail(LRP_ERR_UNSUPPORTED, "grid-TD decoder not built yet");
+  // weights shared by both decoders: image_features (dual 1-tap conv), attention projection of the
+  // features (Wv / W_va), global feature, embedding, output layer, transposed copies for the LRP tail
+  int finalize_common(const char* proj_name, int64_t* total) {
     LRP_TRY(need("image_features_W", {D, H})); LRP_TRY(need("image_features_b", {H}));
     LRP_TRY(need("global_W", {D, E})); LRP_TRY(need("global_b", {E}));
     LRP_TRY(need("embedding", {V, E}));
-    LRP_TRY(need("lstm_Wi", {2 * E, 4 * H})); LRP_TRY(need("lstm_Wh", {H, 4 * H})); LRP_TRY(need("lstm_b", {4 * H}));
-    LRP_TRY(need("Wv", {H, H})); LRP_TRY(need("Wg", {H, H})); LRP_TRY(need("V", {H}));
-    LRP_TRY(need("Wx", {2 * E, H})); LRP_TRY(need("Wh", {H, H})); LRP_TRY(need("Ws", {H, H}));
+    LRP_TRY(need(proj_name, {H, H}));
     LRP_TRY(need("output_W", {H, V})); LRP_TRY(need("output_b", {V}));
-    const std::vector<float>&Wif = raw["image_features_W"], &Wi = raw["lstm_Wi"], &Wh = raw["lstm_Wh"], &Wx = raw["Wx"],
-                            &Whs = raw["Wh"], &Wgl = raw["global_W"];
+    const std::vector<float>&Wif = raw["image_features_W"], &Wgl = raw["global_W"];
     std::vector<float> pk;
-    {  // image_features as a 1-tap dual conv: cols [0,H) -> relu (V), cols [H,2H) -> pre-activation
+    {
       const int Np = conv_npad(2 * H), K = conv_cinp(D);
       pk.assign((size_t)Np * K, 0.f);
       pack_conv_fwd(Wif.data(), 1, D, H, 0, Np, pk.data());
@@ -145,35 +163,11 @@ struct Decoder {
     {
       const int Np = conv_npad(H), K = conv_cinp(H);
       pk.assign((size_t)Np * K, 0.f);
-      pack_conv_fwd(raw["Wv"].data(), 1, H, H, 0, Np, pk.data());
+      pack_conv_fwd(raw[proj_name].data(), 1, H, H, 0, Np, pk.data());
       LRP_TRY(upload(w_v, pk, total));
     }
     LRP_TRY(upload(zero_bias, std::vector<float>(std::max(H, E), 0.f), total));
     LRP_TRY(upload(b_if, raw["image_features_b"], total));
-    {  // [x | h_prev] . [[Wi | Wx] ; [Wh | Wh_sentinel]]  -> 4H gate pre-activations + H sentinel gate
-      const int Kd = 2 * E + H, N5 = 5 * H;
-      pk.assign((size_t)Kd * N5, 0.f);
-      for (int k = 0; k < Kd; ++k)
-        for (int n = 0; n < N5; ++n) {
-          float v;
-          if (k < 2 * E) v = n < 4 * H ? Wi[(size_t)k * 4 * H + n] : Wx[(size_t)k * H + n - 4 * H];
-          else v = n < 4 * H ? Wh[(size_t)(k - 2 * E) * 4 * H + n] : Whs[(size_t)(k - 2 * E) * H + n - 4 * H];
-          pk[(size_t)k * N5 + n] = v;
-        }
-      LRP_TRY(upload(Wcat, pk, total));
-      std::vector<float> bc(N5, 0.f);
-      std::copy(raw["lstm_b"].begin(), raw["lstm_b"].end(), bc.begin());
-      LRP_TRY(upload(bcat, bc, total));
-      // transposed gate-g block for the LRP scan: WgT[j][d] = [Wi;Wh][d][2H+j]   (E:556-558)
-      pk.assign((size_t)H * Kd, 0.f);
-      for (int d = 0; d < Kd; ++d)
-        for (int j = 0; j < H; ++j)
-          pk[(size_t)j * Kd + d] = d < 2 * E ? Wi[(size_t)d * 4 * H + 2 * H + j] : Wh[(size_t)(d - 2 * E) * 4 * H + 2 * H + j];
-      LRP_TRY(upload(WgT, pk, total));
-    }
-    LRP_TRY(upload(Wg, raw["Wg"], total));
-    LRP_TRY(upload(Ws, raw["Ws"], total));
-    LRP_TRY(upload(vvec, raw["V"], total));
     LRP_TRY(upload(Wglob, Wgl, total));
     LRP_TRY(upload(bglob, raw["global_b"], total));
     LRP_TRY(upload(Wout, raw["output_W"], total));
@@ -187,6 +181,63 @@ struct Decoder {
     for (int d = 0; d < D; ++d)
       for (int j = 0; j < H; ++j) pk[(size_t)j * D + d] = Wif[(size_t)d * H + j];
     LRP_TRY(upload(WifT, pk, total));
+    return LRP_OK;
+  }
+
+  // [x | h] . [[Wi | Wsent_x] ; [Wh | Wsent_h]] packed (Kx+H) x (4H [+H]) and the transposed gate-g block
+  int pack_lstm(const std::vector<float>& Wi, const std::vector<float>& Wh, const std::vector<float>* Wsx,
+                const std::vector<float>* Wsh, const std::vector<float>& bias, int Kx, DevBuf& Wc, DevBuf& bc, DevBuf& WgT_,
+                int64_t* total) {
+    const int Kd = Kx + H, Nn = Wsx ? 5 * H : 4 * H;
+    std::vector<float> pk((size_t)Kd * Nn, 0.f);
+    for (int k = 0; k < Kd; ++k)
+      for (int n = 0; n < Nn; ++n) {
+        float v;
+        if (k < Kx) v = n < 4 * H ? Wi[(size_t)k * 4 * H + n] : (*Wsx)[(size_t)k * H + n - 4 * H];
+        else v = n < 4 * H ? Wh[(size_t)(k - Kx) * 4 * H + n] : (*Wsh)[(size_t)(k - Kx) * H + n - 4 * H];
+        pk[(size_t)k * Nn + n] = v;
+      }
+    LRP_TRY(upload(Wc, pk, total));
+    std::vector<float> bcv(Nn, 0.f);
+    std::copy(bias.begin(), bias.end(), bcv.begin());
+    LRP_TRY(upload(bc, bcv, total));
+    pk.assign((size_t)H * Kd, 0.f);                                  // WgT[j][d] = [Wi;Wh][d][2H+j]
+    for (int d = 0; d < Kd; ++d)
+      for (int j = 0; j < H; ++j)
+        pk[(size_t)j * Kd + d] = d < Kx ? Wi[(size_t)d * 4 * H + 2 * H + j] : Wh[(size_t)(d - Kx) * 4 * H + 2 * H + j];
+    LRP_TRY(upload(WgT_, pk, total));
+    return LRP_OK;
+  }
+
+  int finalize_gridtd(int64_t* total) {
+    LRP_TRY(finalize_common("W_va", total));
+    const int K1 = H + 2 * E;
+    LRP_TRY(need("td_Wi", {K1, 4 * H})); LRP_TRY(need("td_Wh", {H, 4 * H})); LRP_TRY(need("td_b", {4 * H}));
+    LRP_TRY(need("lang_Wi", {2 * H, 4 * H})); LRP_TRY(need("lang_Wh", {H, 4 * H})); LRP_TRY(need("lang_b", {4 * H}));
+    LRP_TRY(need("W_ha", {H, H})); LRP_TRY(need("W_a", {H})); LRP_TRY(need("W_x", {K1, H}));
+    LRP_TRY(need("W_h", {H, H})); LRP_TRY(need("W_s", {H, H}));
+    LRP_TRY(pack_lstm(raw["td_Wi"], raw["td_Wh"], &raw["W_x"], &raw["W_h"], raw["td_b"], K1, Wcat, bcat, WgT, total));
+    LRP_TRY(pack_lstm(raw["lang_Wi"], raw["lang_Wh"], nullptr, nullptr, raw["lang_b"], 2 * H, Wcat2, bcat2, Wg2T, total));
+    LRP_TRY(upload(Wg, raw["W_ha"], total));
+    LRP_TRY(upload(Ws, raw["W_s"], total));
+    LRP_TRY(upload(vvec, raw["W_a"], total));
+    finalized = true;
+    return LRP_OK;
+  }
+
+  int finalize(int64_t* total) {
+    if (finalized) return LRP_OK;
+    if (kind == LRP_DEC_GRIDTD) return finalize_gridtd(total);
+    LRP_TRY(finalize_common("Wv", total));
+    LRP_TRY(need("lstm_Wi", {2 * E, 4 * H})); LRP_TRY(need("lstm_Wh", {H, 4 * H})); LRP_TRY(need("lstm_b", {4 * H}));
+    LRP_TRY(need("Wg", {H, H})); LRP_TRY(need("V", {H}));
+    LRP_TRY(need("Wx", {2 * E, H})); LRP_TRY(need("Wh", {H, H})); LRP_TRY(need("Ws", {H, H}));
+    // [x | h_prev] . [[Wi | Wx] ; [Wh | Wh_sentinel]] -> 4H gate pre-activations + H sentinel gate;
+    // transposed gate-g block for the LRP scan (E:556-558)
+    LRP_TRY(pack_lstm(raw["lstm_Wi"], raw["lstm_Wh"], &raw["Wx"], &raw["Wh"], raw["lstm_b"], 2 * E, Wcat, bcat, WgT, total));
+    LRP_TRY(upload(Wg, raw["Wg"], total));
+    LRP_TRY(upload(Ws, raw["Ws"], total));
+    LRP_TRY(upload(vvec, raw["V"], total));
     finalized = true;
     return LRP_OK;
   }
@@ -202,7 +253,7 @@ struct Decoder {
   template <typename T>
   T* S_(const char* nm) { return state[nm].buf.as<T>(); }
 
-  // _forward_beam_search for B images (E:370-436)
+  // _forward_beam_search for B images (E:370-436 / E:1092-1178)
   int forward(const float* feat_dev, const int32_t* caps, const int32_t* lens, int B, hipStream_t st) {
     int64_t dummy = 0;
     LRP_TRY(finalize(&dummy));
@@ -240,6 +291,7 @@ struct Decoder {
     LRP_HIP_CHECK(hipGetLastError());
     LRP_HIP_CHECK((skinny<float, float, float>(avg.as<float>(), D, Wglob.as<float>(), E, bglob.as<float>(),
                                                glob_pre.as<float>(), E, B, D, E, 0, st)));
+    if (kind == LRP_DEC_GRIDTD) return forward_gridtd_steps(B, Tmax, st);
     // ---- step loop (E:399-436)
     const int S = Tm + 1, Kd = 2 * E + H;
     float* ht = S_<float>("ht");
@@ -271,6 +323,71 @@ struct Decoder {
     return LRP_OK;
   }
 
+  // grid-TD step loop (E:1126-1176): top-down LSTM -> attention/sentinel on h1 -> language LSTM
+  int forward_gridtd_steps(int B, int Tmax, hipStream_t st) {
+    const int S = Tm + 1, K1 = H + 2 * E;
+    LRP_HIP_CHECK(hipMemsetAsync(h2u.p, 0, h2u.bytes, st));
+    double *h1 = S_<double>("h1t"), *h2 = S_<double>("h2t"), *stt = S_<double>("st");
+    for (int i = 0; i < Tmax; ++i) {
+      hipLaunchKernelGGL(gtd_prep_x1_kernel, dim3(B), dim3(256), 0, st, emb.as<float>(), glob_pre.as<float>(), h1, h2,
+                         cap_dev.as<int>(), xh1d.as<double>(), S_<double>("x1t"), i, Tm, E, H, V, sos);
+      LRP_HIP_CHECK(hipGetLastError());
+      LRP_HIP_CHECK((skinny<double, double, double>(xh1d.as<double>(), K1 + H, Wcat.as<float>(), 5 * H, bcat.as<float>(),
+                                                    zg1d.as<double>(), 5 * H, B, K1 + H, 5 * H, 0, st)));
+      hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg1d.as<double>(), 5 * H, h1, S_<double>("c1t"),
+                         S_<double>("g1t"), S_<double>("i1t_act"), S_<double>("f1t_act"), stt, (double*)nullptr, i, Tm, H);
+      LRP_HIP_CHECK(hipGetLastError());
+      LRP_HIP_CHECK((skinny<double, double, double>(h1 + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
+                                                    hprojd.as<double>(), H, B, H, H, 0, st)));
+      LRP_HIP_CHECK((skinny<double, double, double>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
+                                                    sprojd.as<double>(), H, B, H, H, 0, st)));
+      const size_t lds = (size_t)(2 * H + L + 8) * sizeof(double);
+      hipLaunchKernelGGL(gtd_attention_kernel, dim3(B), dim3(256), lds, st, hprojd.as<double>(), sprojd.as<double>(),
+                         stat.as<float>(), vvec.as<float>(), if_pre.as<float>(), h1, h2, stt, S_<double>("attention"),
+                         S_<double>("beta"), S_<double>("context"), S_<double>("context_hat"), xh2d.as<double>(),
+                         S_<double>("x2t"), i, Tm, L, H);
+      LRP_HIP_CHECK(hipGetLastError());
+      LRP_HIP_CHECK((skinny<double, double, double>(xh2d.as<double>(), 3 * H, Wcat2.as<float>(), 4 * H, bcat2.as<float>(),
+                                                    zg2d.as<double>(), 4 * H, B, 3 * H, 4 * H, 0, st)));
+      hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg2d.as<double>(), 4 * H, h2, S_<double>("c2t"),
+                         S_<double>("g2t"), S_<double>("i2t_act"), S_<double>("f2t_act"), (double*)nullptr,
+                         h2u.as<double>(), i, Tm, H);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    // logits from h2 alone (E:1154 — the reference quirk), every step at once
+    LRP_HIP_CHECK((skinny<double, double, double>(h2u.as<double>(), H, Wout.as<float>(), V, bout.as<float>(),
+                                                  S_<double>("caption_preds"), V, B * Tm, H, V, 0, st)));
+    B_cur = B;
+    have_forward = true;
+    return LRP_OK;
+  }
+
+  int explain_gridtd(int n, const int* img_dev, const int* t_dev, const float* feat_dev, float* R_feat_dev, float* att_dev,
+                     double* rwords_dev, hipStream_t st) {
+    GtdExplainArgs a{};
+    a.img_idx = img_dev; a.tpos = t_dev; a.cap = cap_dev.as<int>();
+    a.h1t = S_<double>("h1t"); a.c1t = S_<double>("c1t"); a.g1t = S_<double>("g1t"); a.i1t = S_<double>("i1t_act");
+    a.f1t = S_<double>("f1t_act"); a.h2t = S_<double>("h2t"); a.c2t = S_<double>("c2t"); a.g2t = S_<double>("g2t");
+    a.i2t = S_<double>("i2t_act"); a.f2t = S_<double>("f2t_act"); a.x1t = S_<double>("x1t"); a.x2t = S_<double>("x2t");
+    a.ctx = S_<double>("context"); a.st = S_<double>("st"); a.chat = S_<double>("context_hat"); a.beta = S_<double>("beta");
+    a.att = S_<double>("attention"); a.preds = S_<double>("caption_preds");
+    a.Wout = Wout.as<float>(); a.Wg1T = WgT.as<float>(); a.Wg2T = Wg2T.as<float>(); a.WglobT = WglobT.as<float>();
+    a.avg = avg.as<float>(); a.glob_pre = glob_pre.as<float>();
+    a.rho = rho.as<double>(); a.ravg = ravg.as<double>();
+    a.att_out = att_dev; a.rwords_out = rwords_dev;
+    a.Tm = Tm; a.L = L; a.D = D; a.H = H; a.E = E; a.V = V;
+    const size_t lds = (size_t)(7 * H + std::max(H, E) + E + 8) * sizeof(double);
+    hipLaunchKernelGGL(gtd_explain_kernel, dim3(n), dim3(256), lds, st, a);
+    LRP_HIP_CHECK(hipGetLastError());
+    GtdTailArgs ta{};
+    ta.img_idx = img_dev; ta.tpos = t_dev; ta.F = feat_dev; ta.if_pre = if_pre.as<float>(); ta.att = a.att;
+    ta.avg = a.avg; ta.WifT = WifT.as<float>(); ta.rho = a.rho; ta.ravg = a.ravg; ta.R_feat = R_feat_dev;
+    ta.Tm = Tm; ta.L = L; ta.D = D; ta.H = H;
+    hipLaunchKernelGGL(gtd_tail_kernel, dim3(n, (L + 63) / 64, (D + 63) / 64), dim3(256), 0, st, ta);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+
   int check_token(int b, int t) const {
     if (!have_forward) return fail(LRP_ERR_STATE, "lrp_decoder_forward must run before explain");
     if (b < 0 || b >= B_cur) return fail(LRP_ERR_INVALID, "image index %d outside the %d forwarded captions", b, B_cur);
@@ -280,8 +397,12 @@ struct Decoder {
 
   int explain(int n, const int* img_dev, const int* t_dev, const int32_t*, const int32_t*, int variant,
               const float* feat_dev, float* R_feat_dev, float* att_dev, double* rwords_dev, hipStream_t st) {
-    if (kind != LRP_DEC_ADAPTIVE) return fail(LRP_ERR_UNSUPPORTED, "grid-TD decoder not built yet");
     if (variant != LRP_EXPLAIN_SEQUENCE && variant != LRP_EXPLAIN_SINGLE_STEP) return fail(LRP_ERR_INVALID, "bad variant");
+    if (kind == LRP_DEC_GRIDTD) {
+      if (variant != LRP_EXPLAIN_SEQUENCE)      // E:167-172: the grid-TD class does not override _explain_lstm_single_word
+        return fail(LRP_ERR_UNSUPPORTED, "the grid-TD decoder has no single-step variant");
+      return explain_gridtd(n, img_dev, t_dev, feat_dev, R_feat_dev, att_dev, rwords_dev, st);
+    }
     ExplainArgs a{};
     a.img_idx = img_dev; a.tpos = t_dev; a.cap = cap_dev.as<int>();
     a.ht = S_<float>("ht"); a.ct = S_<float>("ct"); a.gt = S_<float>("gt"); a.it = S_<float>("it_act");
@@ -313,7 +434,7 @@ struct Decoder {
     else if (nm == "image_features_before_act") src = &if_pre;
     else if (nm == "average_img_feature") src = &avg;
     else if (nm == "global_img_feature_before_act") src = &glob_pre;
-    else if (nm == "total_static_img_feature") src = &stat;
+    else if (nm == "total_static_img_feature" || nm == "image_features_proj") src = &stat;
     if (!src) return fail(LRP_ERR_INVALID, "unknown state array '%s'", name);
     if (out_bytes > src->bytes) return fail(LRP_ERR_INVALID, "state '%s' holds %zu bytes, %zu requested", name, src->bytes, out_bytes);
     LRP_HIP_CHECK(hipMemcpyAsync(out_dev, src->p, out_bytes, hipMemcpyDeviceToDevice, st));

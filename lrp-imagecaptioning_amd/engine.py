@@ -142,11 +142,20 @@ class LRPEngine(object):
         "global_img_feature_before_act": (1, "E", torch.float32), "total_static_img_feature": ("L", "H", torch.float32),
     }
 
+    _STATE_SHAPES_GRIDTD = dict(
+        [(n, ("S", "H", torch.float64)) for n in ("h1t", "c1t", "g1t", "i1t_act", "f1t_act", "h2t", "c2t", "g2t", "i2t_act",
+                                                  "f2t_act", "context", "st", "context_hat")] +
+        [("attention", ("S", "L", torch.float64)), ("beta", ("S", 1, torch.float64)),
+         ("x1t", ("T", "H+2E", torch.float64)), ("x2t", ("T", "2H", torch.float64)),
+         ("caption_preds", ("T", "V", torch.float64)),
+         ("image_features_before_act", ("L", "H", torch.float32)), ("average_img_feature", (1, "D", torch.float32)),
+         ("global_img_feature_before_act", (1, "E", torch.float32)), ("image_features_proj", ("L", "H", torch.float32))])
+
     def read_state(self, name):
         """Cached decoder array for the images of the last forward: (B, rows, dim)."""
         dims = {"S": self.Tm + 1, "T": self.Tm, "H": self.H, "L": self.L, "V": self.V, "D": self.D, "E": self.E,
-                "2E": 2 * self.E, 1: 1}
-        r, c, dt = self._STATE_SHAPES[name]
+                "2E": 2 * self.E, "2H": 2 * self.H, "H+2E": self.H + 2 * self.E, 1: 1}
+        r, c, dt = (self._STATE_SHAPES_GRIDTD if self.decoder == "gridtd" else self._STATE_SHAPES)[name]
         out = torch.empty((self.n_images, dims[r], dims[c]), dtype=dt, device=self.device)
         _capi.check(self._lib.lrp_read_state(self._h, name.encode(), C.c_void_p(out.data_ptr()),
                                              out.numel() * out.element_size(), self._stream()))

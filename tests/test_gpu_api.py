@@ -163,3 +163,32 @@ def test_harness_returns_arrays():
     assert np.isfinite(res["relevance"]).all()
     one = hz._explain_single_word(X, caps, None, 1)
     assert one["heatmap"].shape == (HW, HW, 3) and one["heatmap"].max() <= 255
+
+
+def test_gridtd_explainer_class():
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningGridTDModel
+    from lrp_imagecaptioning_amd.synthetic import gridtd_weights
+    from oracle.decoder_ref import GridTDOracle
+    rs = np.random.RandomState(4)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V, cnn_cfg=CFG,
+                            img_hw=(HW, HW))
+    X = rs.uniform(-120, 130, size=(1, HW, HW, 3)).astype(np.float32)
+    cap = [11, 4, 29, 1]
+    ex = ExplainImgCaptioningGridTDModel(spec, None, None, max_caption_length=6)
+    ex._forward_beam_search((None, X), cap)
+    layers = C.vgg_layers(w, CFG)
+    o = GridTDOracle(w, L, D, H, H)
+    o.forward(C.forward(layers, X).astype(np.float32), cap)
+    assert ex.h2t.shape == (len(cap) + 1, H) and ex.h2t.dtype == np.float64
+    assert rel_l1(ex.h2t, o.h2t) < 1e-5 and rel_l1(ex.x2t, o.x2t) < 1e-5
+    rel, att = ex._explain_sentence()
+    worst = 0.0
+    for i, R in enumerate(rel):
+        img = ex._explain_CNN(X, R)
+        worst = max(worst, rel_l1(img, C.analyze(layers, X, o.explain(i + 1)[0])))
+    assert worst < TOL
+    np.testing.assert_allclose(ex.r_words, o.r_words, rtol=1e-4, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        ex._explain_lstm_single_word(1)
