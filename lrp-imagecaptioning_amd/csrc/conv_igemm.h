@@ -56,7 +56,7 @@ constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; sw
 // Out-of-image taps / ragged tails read this instead of branching around the load: the
 // select is two v_cndmask on the address, the load itself stays unconditional and the
 // eight loads of a chunk issue back to back.
-__device__ __attribute__((aligned(16))) const float lrp_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float lrp_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the GLOBAL address space (a const page makes the select generic -> flat_load, which also counts on lgkmcnt)
 
 template <int WM, int WN, int TM, int TN, int EPI>
 __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel(ConvArgs a) {
@@ -124,7 +124,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     const int kofs = tap * a.CinP + c0;
 #pragma unroll
     for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const f32x4*>(bptr + (size_t)(32 * p) * K + kofs);
-    if (++cc == cpt) { cc = 0; ++tap; }
+    // taps innermost: the 9 taps of one 32-channel chunk touch the same ~(BM + halo) pixel rows
+    // (24 KB), so 8 of 9 re-reads hit L1/L2; tap-major order streamed BM x Cin x 4 B per tap
+    // through a 64 KB-per-block share of the XCD's L2 and missed on every tap (FETCH_SIZE 7x).
+    if (++tap == a.taps) { tap = 0; ++cc; }
   };
   auto store_chunk = [&](int buf) {
     float* As = smem + buf * STAGE;

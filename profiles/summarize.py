@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/prof_<tag>/ directory (profiles/run_profile.sh) into the small files
+committed under profiles/: <tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats) and
+<tag>_pmc_summary.json (per-kernel SQ / FETCH_SIZE / WRITE_SIZE aggregates, per launch)."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+
+def agg(path, key_len=80):
+    out = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"][:key_len]
+        out[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[k].add(r["Dispatch_Id"])
+    return out, {k: len(v) for k, v in n.items()}
+
+
+def main(tag):
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(os.path.dirname(here), "gpurun_out", "prof_" + tag)
+    shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats.csv"))
+    summ = {}
+    sq, nsq = agg(os.path.join(src, "pmc_sq", "p_counter_collection.csv"))
+    fe, nfe = agg(os.path.join(src, "pmc_fetch", "p_counter_collection.csv"))
+    wr, nwr = agg(os.path.join(src, "pmc_write", "p_counter_collection.csv"))
+    for k, v in sq.items():
+        if not ("lrp::" in k):
+            continue
+        gui = v.get("GRBM_GUI_ACTIVE", 0.0)
+        d = {"launches": nsq[k]}
+        if gui:
+            # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs each able to hold one MFMA-cycle per cycle
+            d["mfma_busy_frac"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024), 4)
+        wc = v.get("SQ_WAVE_CYCLES", 0.0)
+        if wc:
+            d["wait_any_frac"] = round(v.get("SQ_WAIT_ANY", 0.0) / wc, 4)
+            d["wait_inst_frac"] = round(v.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
+            d["active_frac"] = round(v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4)
+            d["lds_bank_conflict_per_wave_cycle"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0.0) / wc, 5)
+        if k in fe:
+            # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 reports half of a 16 B/lane coalesced read stream (x2)
+            d["fetch_bytes_per_launch_x2corr"] = round(2 * fe[k]["FETCH_SIZE"] * 1024 / nfe[k])
+        if k in wr:
+            d["write_bytes_per_launch"] = round(wr[k]["WRITE_SIZE"] * 1024 / nwr[k])
+        summ[k] = d
+    json.dump(summ, open(os.path.join(here, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    print(json.dumps(summ, indent=1, sort_keys=True)[:3000])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
