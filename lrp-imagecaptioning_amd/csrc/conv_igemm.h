@@ -160,38 +160,51 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) koff[kk] = (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 2);
 
-  auto mfma_step = [&](const float* Ab, const float* Bb, int kk) {
-    f32x4 af[TM], bf[TN];
+  // Fragment registers are double-buffered one kk-step ahead, and the first fragments of the
+  // NEXT chunk are fetched right after the barrier: the last 16 MFMAs of the current chunk run
+  // on registers while those reads are in flight, so no wave sits behind an LDS round trip
+  // after the barrier.  (All reads of `buf` are issued before the barrier => the mid-chunk
+  // store of the following iteration cannot race them.)
+  struct Frag { f32x4 a[TM], b[TN]; };
+  auto read_frag = [&](Frag& f, const float* Ab, const float* Bb, int kk) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + koff[kk]);
+    for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + koff[kk]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + koff[kk]);
+    for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + koff[kk]);
+  };
+  auto mfma_frag = [&](const Frag& f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
   };
 
+  Frag f0, f1;
+  read_frag(f0, smem + a_off, smem + b_off, 0);
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
     if (more) load_chunk();                            // global loads fly under the MFMAs below
     const float* Ab = smem + buf * STAGE + a_off;
     const float* Bb = smem + buf * STAGE + b_off;
-    mfma_step(Ab, Bb, 0);
-    mfma_step(Ab, Bb, 1);
+    read_frag(f1, Ab, Bb, 1);
+    mfma_frag(f0);                                     // kk = 0
+    read_frag(f0, Ab, Bb, 2);
+    mfma_frag(f1);                                     // kk = 1
     // The other LDS buffer is free for the whole iteration (every wave passed the barrier
     // after its last read of it), so the staged registers are written mid-chunk: the
-    // vmcnt wait and the ds_write issue hide under the second half's MFMAs instead of
-    // sitting between the last MFMA and the barrier.
+    // vmcnt wait and the ds_write issue hide under the second half's MFMAs.
     __builtin_amdgcn_sched_barrier(0);
     if (more) store_chunk(buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_step(Ab, Bb, 2);
-    mfma_step(Ab, Bb, 3);
+    read_frag(f1, Ab, Bb, 3);
+    mfma_frag(f0);                                     // kk = 2
+    __syncthreads();
+    if (more) read_frag(f0, smem + (buf ^ 1) * STAGE + a_off, smem + (buf ^ 1) * STAGE + b_off, 0);
+    mfma_frag(f1);                                     // kk = 3
     if ((kc & (FLUSH - 1)) == FLUSH - 1) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -202,8 +215,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
           for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         }
     }
-    __syncthreads();
   }
+  __syncthreads();                                     // LDS is reused by the epilogue
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -28,9 +28,9 @@ struct Decoder {
   // packed device weights
   DevBuf w_if_dual, w_v, zero_bias, b_if, Wcat, bcat, Wg, Ws, vvec, Wglob, bglob, Wout, bout, emb, WgT, WglobT, WifT;
   // per-image static part
-  DevBuf vfeat, if_pre, stat, avg, glob_pre;
+  DevBuf vfeat, if_pre, ipre, stat, avg, glob_pre;
   // per-step scratch
-  DevBuf xh, zgate, hproj, sproj, u;
+  DevBuf xh, zgate, hproj, sproj, u, att_pre;
   // cached state (what the reference leaves on `self`)
   std::map<std::string, StateBuf> state;
   DevBuf cap_dev;
@@ -84,13 +84,15 @@ struct Decoder {
     }
     LRP_TRY(vfeat.alloc(B * L * H * 4, total));
     LRP_TRY(if_pre.alloc(B * L * H * 4, total));
+    if (kind == LRP_DEC_ADAPTIVE) LRP_TRY(ipre.alloc(B * L * H * 8, total));
     LRP_TRY(stat.alloc(B * L * H * 4, total));
     LRP_TRY(avg.alloc(B * D * 4, total));
     LRP_TRY(glob_pre.alloc(B * E * 4, total));
     LRP_TRY(xh.alloc(B * (2 * E + 2 * H) * 4, total));
-    LRP_TRY(zgate.alloc(B * 5 * H * 4, total));
-    LRP_TRY(hproj.alloc(B * H * 4, total));
-    LRP_TRY(sproj.alloc(B * H * 4, total));
+    LRP_TRY(zgate.alloc(B * 5 * H * 4 * KS_GATE, total));
+    LRP_TRY(hproj.alloc(B * H * 4 * KS_PROJ, total));
+    LRP_TRY(sproj.alloc(B * H * 4 * KS_PROJ, total));
+    LRP_TRY(att_pre.alloc(B * (L + 1) * 4, total));
     LRP_TRY(u.alloc(B * Tm * H * 8, total));
     LRP_TRY(cap_dev.alloc(B * Tm * sizeof(int), total));
     LRP_TRY(rctx.alloc((size_t)NT_max * H * 8, total));
@@ -242,13 +244,17 @@ struct Decoder {
     return LRP_OK;
   }
 
+  // ks > 1: split-K into `ks` slabs of `slab` elements each (the consumer sums them)
   template <typename TX, typename TA, typename TY>
   static hipError_t skinny(const TX* X, int ldx, const float* W, int ldw, const float* bias, TY* Y, int ldy, int R, int K,
-                           int N, int relu, hipStream_t st) {
-    const dim3 grid((N + 63) / 64, (R + 31) / 32);
-    hipLaunchKernelGGL((skinny_gemm_kernel<TX, TA, TY>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, R, K, N, relu);
+                           int N, int relu, hipStream_t st, int ks = 1, size_t slab = 0) {
+    int kchunk = ((K + ks - 1) / ks + 63) / 64 * 64;
+    const dim3 grid((N + 63) / 64, (R + 31) / 32, ks);
+    hipLaunchKernelGGL((skinny_gemm_kernel<TX, TA, TY>), grid, dim3(256), 0, st, X, ldx, W, ldw, bias, Y, ldy, R, K, N, relu,
+                       kchunk, slab);
     return hipGetLastError();
   }
+  static constexpr int KS_GATE = 8, KS_PROJ = 4;
 
   template <typename T>
   T* S_(const char* nm) { return state[nm].buf.as<T>(); }
@@ -287,6 +293,12 @@ struct Decoder {
       cv.wpk = w_v.as<float>(); cv.N = H; cv.bias = zero_bias.as<float>(); cv.out = stat.as<float>();
       LRP_HIP_CHECK(conv_launch(EPI_BIAS, cv, st));
     }
+    if (kind == LRP_DEC_ADAPTIVE) {
+      const size_t ne = (size_t)B * L * H;
+      hipLaunchKernelGGL(dec_ipre_kernel, dim3((unsigned)std::min<size_t>((ne + 255) / 256, 2048)), dim3(256), 0, st,
+                         if_pre.as<float>(), ipre.as<double>(), ne);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(mean_rows_kernel, dim3(B), dim3(256), 0, st, feat_dev, avg.as<float>(), L, D);
     LRP_HIP_CHECK(hipGetLastError());
     LRP_HIP_CHECK((skinny<float, float, float>(avg.as<float>(), D, Wglob.as<float>(), E, bglob.as<float>(),
@@ -300,19 +312,23 @@ struct Decoder {
       hipLaunchKernelGGL(dec_prep_x_kernel, dim3(B), dim3(256), 0, st, emb.as<float>(), glob_pre.as<float>(), ht,
                          cap_dev.as<int>(), xh.as<float>(), S_<float>("xt"), i, Tm, E, H, V, sos);
       LRP_HIP_CHECK(hipGetLastError());
+      const size_t zslab = (size_t)B_max * 5 * H, pslab = (size_t)B_max * H;
       LRP_HIP_CHECK((skinny<float, float, float>(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, bcat.as<float>(),
-                                                 zgate.as<float>(), 5 * H, B, Kd, 5 * H, 0, st)));
-      hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B), dim3(256), 0, st, zgate.as<float>(), ht, S_<float>("ct"),
-                         S_<float>("gt"), S_<float>("it_act"), S_<float>("ft_act"), stt, i, Tm, H);
+                                                 zgate.as<float>(), 5 * H, B, Kd, 5 * H, 0, st, KS_GATE, zslab)));
+      hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B), dim3(256), 0, st, zgate.as<float>(), KS_GATE, zslab, ht,
+                         S_<float>("ct"), S_<float>("gt"), S_<float>("it_act"), S_<float>("ft_act"), stt, i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
       LRP_HIP_CHECK((skinny<float, float, float>(ht + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
-                                                 hproj.as<float>(), H, B, H, H, 0, st)));
+                                                 hproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
       LRP_HIP_CHECK((skinny<float, float, float>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
-                                                 sproj.as<float>(), H, B, H, H, 0, st)));
-      const size_t lds = (size_t)(2 * H + L + 8) * sizeof(float);
-      hipLaunchKernelGGL(dec_attention_kernel, dim3(B), dim3(256), lds, st, hproj.as<float>(), sproj.as<float>(),
-                         stat.as<float>(), vvec.as<float>(), if_pre.as<float>(), ht, stt, S_<float>("attention"),
-                         S_<float>("beta"), S_<double>("context"), S_<double>("c_hat"), u.as<double>(), i, Tm, L, H);
+                                                 sproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
+      hipLaunchKernelGGL(dec_att_scores_kernel, dim3(B, (L + 1 + ATT_ROWS - 1) / ATT_ROWS), dim3(256),
+                         (size_t)2 * H * sizeof(float), st, hproj.as<float>(), sproj.as<float>(), KS_PROJ, pslab,
+                         stat.as<float>(), vvec.as<float>(), att_pre.as<float>(), L, H);
+      LRP_HIP_CHECK(hipGetLastError());
+      hipLaunchKernelGGL(dec_att_finish_kernel, dim3(B), dim3(256), (size_t)(L + 8) * sizeof(float), st,
+                         att_pre.as<float>(), if_pre.as<float>(), ht, stt, S_<float>("attention"), S_<float>("beta"),
+                         S_<double>("context"), S_<double>("c_hat"), u.as<double>(), i, Tm, L, H);
       LRP_HIP_CHECK(hipGetLastError());
     }
     // ---- output layer for every step at once (E:421-422), float64 like the reference
@@ -418,7 +434,8 @@ struct Decoder {
     hipLaunchKernelGGL(dec_explain_adaptive_kernel, dim3(n), dim3(256), lds, st, a);
     LRP_HIP_CHECK(hipGetLastError());
     TailArgs ta{};
-    ta.img_idx = img_dev; ta.tpos = t_dev; ta.F = feat_dev; ta.if_pre = if_pre.as<float>(); ta.att = a.att; ta.ctx = a.ctx;
+    ta.img_idx = img_dev; ta.tpos = t_dev; ta.F = feat_dev; ta.vfeat = vfeat.as<float>(); ta.ipre = ipre.as<double>();
+    ta.att = a.att;
     ta.avg = a.avg; ta.WifT = WifT.as<float>(); ta.rctx = a.rctx; ta.ravg = a.ravg; ta.R_feat = R_feat_dev;
     ta.Tm = Tm; ta.L = L; ta.D = D; ta.H = H;
     hipLaunchKernelGGL(dec_tail_kernel, dim3(n, (L + 63) / 64, (D + 63) / 64), dim3(256), 0, st, ta);

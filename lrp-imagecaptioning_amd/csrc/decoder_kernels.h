@@ -23,22 +23,29 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // (images or image*step), W in the Keras (in,out) layout -> lanes run along n (coalesced).
 // Block = 64 columns x 32 rows, 4 waves split K; partial sums meet in LDS.
 // ------------------------------------------------------------------------------------------
+// Split-K: blockIdx.z owns K-range [z*kchunk, (z+1)*kchunk) and writes its partial sums to slab z
+// (Y + z*slab); the consumer kernel adds the slabs in a fixed order (bit-reproducible, no atomics).
+// These GEMMs are latency-bound chains of dependent loads, so more, shorter blocks is the lever.
 template <typename TX, typename TA, typename TY>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__ X, int ldx, const float* __restrict__ W,
                                                           int ldw, const float* __restrict__ bias, TY* __restrict__ Y,
-                                                          int ldy, int R, int K, int N, int relu) {
+                                                          int ldy, int R, int K, int N, int relu, int kchunk, size_t slab) {
   __shared__ TA xs[64][32];
   __shared__ TA red[3][32][64];
   const int tid = threadIdx.x, col = tid & 63, kg = tid >> 6;
   const int n = blockIdx.x * 64 + col, r0 = blockIdx.y * 32;
+  const int kbeg = blockIdx.z * kchunk;
+  const int Kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  Y += (size_t)blockIdx.z * slab;
+  if (blockIdx.z) bias = nullptr;
   TA acc[32];
 #pragma unroll
   for (int r = 0; r < 32; ++r) acc[r] = (TA)0;
-  for (int k0 = 0; k0 < K; k0 += 64) {
+  for (int k0 = kbeg; k0 < Kend; k0 += 64) {
     for (int e = tid; e < 2048; e += 256) {
       const int k = e & 63, r = e >> 6;
       TA v = (TA)0;
-      if (r0 + r < R && k0 + k < K) v = (TA)X[(size_t)(r0 + r) * ldx + k0 + k];
+      if (r0 + r < R && k0 + k < Kend) v = (TA)X[(size_t)(r0 + r) * ldx + k0 + k];
       xs[k][r] = v;
     }
     __syncthreads();
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__
 #pragma unroll 4
       for (int kk = 0; kk < 16; ++kk) {
         const int k = kg * 16 + kk, gk = k0 + k;
-        if (gk < K) {
+        if (gk < Kend) {
           const TA w = (TA)W[(size_t)gk * ldw + n];
 #pragma unroll
           for (int r = 0; r < 32; ++r) acc[r] += xs[k][r] * w;
@@ -71,6 +78,12 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__
       }
     }
   }
+}
+
+// ipre = 1 / stab(if_pre): the denominator of the image_features rule (E:654-659), once per image
+__global__ __launch_bounds__(256) void dec_ipre_kernel(const float* __restrict__ if_pre, double* __restrict__ ipre, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    ipre[i] = 1.0 / stab((double)if_pre[i]);
 }
 
 // avg[b][d] = mean_l F[b][l][d]   (np.mean(axis=0) in float32: sequential row adds, then / L; E:382)
@@ -104,7 +117,8 @@ __global__ __launch_bounds__(256) void dec_prep_x_kernel(const float* __restrict
 
 // LSTM pointwise (E:129-138) + visual sentinel s = tanh(c) * sigmoid(x.Wx + h_prev.Wh) (E:415).
 // z[b] = [ i | f | g | o | sentinel-gate ] pre-activations (5H).  Writes state row step+1.
-__global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restrict__ z, float* __restrict__ ht,
+__global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restrict__ z, int ks, size_t slab,
+                                                            float* __restrict__ ht,
                                                             float* __restrict__ ct, float* __restrict__ gt,
                                                             float* __restrict__ it, float* __restrict__ ft,
                                                             float* __restrict__ st, int step, int Tm, int H) {
@@ -112,7 +126,14 @@ __global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restr
   const float* zb = z + (size_t)b * 5 * H;
   const size_t prev = ((size_t)b * S + step) * H, cur = prev + H;
   for (int j = threadIdx.x; j < H; j += 256) {
-    const float i_ = sigmoidf_(zb[j]), f_ = sigmoidf_(zb[H + j]), g_ = zb[2 * H + j], o_ = sigmoidf_(zb[3 * H + j]);
+    float zz[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+      float v = zb[g * H + j];
+      for (int q = 1; q < ks; ++q) v += zb[(size_t)q * slab + g * H + j];          // split-K slabs, fixed order
+      zz[g] = v;
+    }
+    const float i_ = sigmoidf_(zz[0]), f_ = sigmoidf_(zz[1]), g_ = zz[2], o_ = sigmoidf_(zz[3]);
     const float c = f_ * ct[prev + j] + i_ * tanhf(g_);
     const float tc = tanhf(c);
     ht[cur + j] = o_ * tc;
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restr
     gt[cur + j] = g_;
     it[cur + j] = i_;
     ft[cur + j] = f_;
-    st[cur + j] = tc * sigmoidf_(zb[4 * H + j]);
+    st[cur + j] = tc * sigmoidf_(zz[4]);
   }
 }
 
@@ -140,27 +161,35 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// Attention softmax + sentinel mix for one step, one workgroup per image (E:412-421):
-//   alpha = softmax_L( tanh(h.Wg + V.Wv) . v )   float32
-//   beta  = last entry of softmax over [alpha logits ; tanh(s.Ws + h.Wg).v]
-//   ctx   = sum_l alpha_l * relu(if_pre_l)   float64
-//   c_hat = beta*s + (1-beta)*ctx            float64 ;  u = h + c_hat (input of the output layer)
-// dynamic LDS: float hp[H], sp[H], pre[L+1]
-__global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restrict__ hproj, const float* __restrict__ sproj,
-                                                            const float* __restrict__ stat, const float* __restrict__ vvec,
-                                                            const float* __restrict__ if_pre, const float* __restrict__ ht,
-                                                            const float* __restrict__ st, float* __restrict__ att,
-                                                            float* __restrict__ beta, double* __restrict__ ctx,
-                                                            double* __restrict__ chat, double* __restrict__ u, int step,
-                                                            int Tm, int L, int H) {
+// Attention softmax + sentinel mix for one step (E:412-421), two launches so that more than B
+// workgroups are in flight:
+//   scores:  pre[b][l] = tanh(h.Wg + V.Wv)[l] . v  for l < L,  pre[b][L] = tanh(s.Ws + h.Wg) . v
+//            grid (B, ceil((L+1)/ROWS)), one wave per row, lanes along H      float32
+//   finish:  alpha = softmax_L(pre), beta = last entry of softmax over [pre ; sentinel],
+//            ctx = sum_l alpha_l relu(if_pre_l) (float64), c_hat = beta*s + (1-beta)*ctx, u = h + c_hat
+// hproj / sproj arrive as split-K slabs (summed here in fixed order).
+constexpr int ATT_ROWS = 16;
+__global__ __launch_bounds__(256) void dec_att_scores_kernel(const float* __restrict__ hproj, const float* __restrict__ sproj,
+                                                             int ks, size_t slab, const float* __restrict__ stat,
+                                                             const float* __restrict__ vvec, float* __restrict__ pre,
+                                                             int L, int H) {
   extern __shared__ float fsm[];
   float* hp = fsm;
   float* sp = fsm + H;
-  float* pre = fsm + 2 * H;       // L+1 entries (+ padding)
-  const int b = blockIdx.x, S = Tm + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int j = tid; j < H; j += 256) { hp[j] = hproj[(size_t)b * H + j]; sp[j] = sproj[(size_t)b * H + j]; }
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l0 = blockIdx.y * ATT_ROWS;
+  const bool need_s = l0 + ATT_ROWS > L;                 // only the block that owns row L needs s.Ws
+  for (int j = tid; j < H; j += 256) {
+    float h = 0.f, sv = 0.f;
+    for (int q = 0; q < ks; ++q) {
+      h += hproj[(size_t)q * slab + (size_t)b * H + j];
+      if (need_s) sv += sproj[(size_t)q * slab + (size_t)b * H + j];
+    }
+    hp[j] = h;
+    sp[j] = sv;
+  }
   __syncthreads();
-  for (int l = wave; l <= L; l += 4) {
+  for (int l = l0 + wave; l < l0 + ATT_ROWS && l <= L; l += 4) {
     float p = 0.f;
     if (l < L) {
       const float* srow = stat + ((size_t)b * L + l) * H;
@@ -169,8 +198,20 @@ __global__ __launch_bounds__(256) void dec_attention_kernel(const float* __restr
       for (int j = lane; j < H; j += 64) p += tanhf(sp[j] + hp[j]) * vvec[j];
     }
     p = wave_sum(p);
-    if (lane == 0) pre[l] = p;
+    if (lane == 0) pre[(size_t)b * (L + 1) + l] = p;
   }
+}
+
+// dynamic LDS: float pre[L+1]
+__global__ __launch_bounds__(256) void dec_att_finish_kernel(const float* __restrict__ pre_g, const float* __restrict__ if_pre,
+                                                             const float* __restrict__ ht, const float* __restrict__ st,
+                                                             float* __restrict__ att, float* __restrict__ beta,
+                                                             double* __restrict__ ctx, double* __restrict__ chat,
+                                                             double* __restrict__ u, int step, int Tm, int L, int H) {
+  extern __shared__ float fsm[];
+  float* pre = fsm;
+  const int b = blockIdx.x, S = Tm + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int l = tid; l <= L; l += 256) pre[l] = pre_g[(size_t)b * (L + 1) + l];
   __syncthreads();
   const size_t row = (size_t)b * S + step + 1;
   if (wave == 0) {
@@ -226,7 +267,7 @@ struct ExplainArgs {
   const float* WgT;                               // [H][2E+H]
   const float* WglobT;                            // [E][D]
   const float *avg, *glob_pre;
-  double *rctx, *ravg;                            // [n][H], [n][D]
+  double *rctx, *ravg;                            // rho = r_ctx/stab(ctx) [n][H], r_avg [n][D]
   float* att_out;                                 // [n][L] or null
   double* rwords_out;                             // [n][Tm] or null
   int Tm, L, D, H, E, V, single_step;
@@ -271,7 +312,7 @@ __global__ __launch_bounds__(256) void dec_explain_adaptive_kernel(ExplainArgs a
     const double sch = stab(ch);
     const double r_ctx = (bt32_1m * a.ctx[rowt * H + j]) / sch * r_ch;
     const double r_s = (double)(btf * a.st[rowt * H + j]) / sch * r_ch;
-    a.rctx[(size_t)n * H + j] = r_ctx;
+    a.rctx[(size_t)n * H + j] = r_ctx / stab(a.ctx[rowt * H + j]);      // rho_j, consumed by dec_tail_kernel
     rc[j] = r_s;                                  // r_ct[t] = r_st            (E:602)
     rh[j] = r_h;
   }
@@ -377,12 +418,12 @@ __global__ __launch_bounds__(256) void dec_explain_adaptive_kernel(ExplainArgs a
 struct TailArgs {
   const int* img_idx; const int* tpos;
   const float* F;          // [B][L][D]
-  const float* if_pre;     // [B][L][H]
+  const float* vfeat;      // [B][L][H]   relu(if_pre)
+  const double* ipre;      // [B][L][H]   1 / stab(if_pre)   (per image, so the tail has no divides)
   const float* att;        // [B][S][L]
-  const double* ctx;       // [B][S][H]
   const float* avg;        // [B][D]
   const float* WifT;       // [H][D]
-  const double *rctx, *ravg;
+  const double *rctx, *ravg;   // rctx holds rho = r_ctx / stab(ctx)
   float* R_feat;           // [n][L][D]
   int Tm, L, D, H;
 };
@@ -409,10 +450,10 @@ __global__ __launch_bounds__(256) void dec_tail_kernel(TailArgs a) {
       const int l = l0 + ll, j = j0 + jj;
       double v = 0.0;
       if (l < L && j < H) {
-        const float pre = a.if_pre[((size_t)b * L + l) * H + j];
-        const double vf = (double)fmaxf(pre, 0.f) * (double)a.att[rowt * L + l];
-        const float rV = (float)(vf / stab(a.ctx[rowt * H + j]) * a.rctx[(size_t)n * H + j]);
-        v = (double)rV / stab((double)pre);
+        const size_t o = ((size_t)b * L + l) * H + j;
+        const double vf = (double)a.vfeat[o] * (double)a.att[rowt * L + l];
+        const float rV = (float)(vf * a.rctx[(size_t)n * H + j]);           // float32 store into r_V (E:554, :648)
+        v = (double)rV * a.ipre[o];
       }
       As[jj][ll] = v;
     }
