@@ -14,6 +14,7 @@ Prints ONE json line (rank 0).  See DESIGN.md §measurement for the roofline ter
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -143,6 +144,7 @@ def main():
     eng.profile_enable(False)
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
+    traffic, traffic_src = pmc_traffic_per_launch()
     if rank == 0:
         heatmaps = world * B * T * args.steps
         res = {
@@ -154,7 +156,9 @@ def main():
                        "heatmaps_per_step": world * B * T, "parallelism": "image-sharded x%d, RCCL weight broadcast" % world},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (conv-LRP alpha1beta0 backward, 13 launches/step)",
                          "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM+MALL bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                         "traffic_source": traffic_src,
                          "launches": n_launch, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
                          "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2)},
         }
@@ -164,6 +168,26 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic_per_launch():
+    """rocprofv3 cannot run inside this process: the per-launch fabric traffic of the reverse-walk
+    conv launches comes from the newest committed PMC summary (profiles/run_profile.sh: separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    tot = n = 0.0
+    for k, v in d.items():
+        # reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5)
+        m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+)>", k)
+        if m and m.group(1) in ("2", "3", "5"):
+            if "fetch_bytes_per_launch_x2corr" in v and "write_bytes_per_launch" in v:
+                tot += (v["fetch_bytes_per_launch_x2corr"] + v["write_bytes_per_launch"]) * v["launches"]
+                n += v["launches"]
+    return (int(tot / n), os.path.relpath(files[-1], ROOT)) if n else (None, None)
 
 
 def synth_weights_shapes(V):

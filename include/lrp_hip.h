@@ -173,6 +173,21 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
                 const float* aux_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
                 int32_t Cin, int32_t Cout, int32_t taps, int32_t mode, void* stream);
 
+/* Operator-level entries for the other rules LRPSequentialPresetA can reach (not on the
+ * truncated-VGG16 path; ResNet-101 "next" row).  All pointers device memory unless `_host`.
+ * EpsilonRule with bias=False (RR:113-144, RA:706-711): x (N,Din), W_host (Din,Dout) Keras
+ * layout, R (N,Dout) -> out (N,Din).  Din, Dout multiples of 4. */
+int lrp_op_epsilon_dense(const float* x_dev, const float* W_host, const float* R_dev, float* out_dev,
+                         int32_t N, int32_t Din, int32_t Dout, float epsilon, void* stream);
+/* BatchNormalizationReverseLayer (RA:197-257): channels-last x, R, out of n elements, C channels;
+ * gamma/beta/mean/var device vectors of length C. */
+int lrp_op_batchnorm_lrp(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* mean_dev,
+                         const float* var_dev, float bn_eps, const float* R_dev, float* out_dev, int64_t n,
+                         int32_t C, void* stream);
+/* AddReverseLayer (RA:260-286): R_a = a*SafeDivide(R,a+b), R_b = b*SafeDivide(R,a+b). */
+int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, float* Ra_dev, float* Rb_dev,
+                   int64_t n, void* stream);
+
 const char* lrp_last_error(void);
 int lrp_abi_version(void);
 

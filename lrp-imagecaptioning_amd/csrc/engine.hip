@@ -12,6 +12,7 @@
 #include "conv_igemm.h"
 #include "decoder.h"
 #include "encoder.h"
+#include "rules_kernels.h"
 
 namespace lrp {
 std::string& last_error_ref() {
@@ -237,6 +238,58 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
   static const int epi_of_mode[4] = {EPI_BIAS_RELU, EPI_BIAS, EPI_MUL, EPI_MUL_UP2};
   LRP_HIP_CHECK(conv_launch(epi_of_mode[mode], ca, S(stream)));
   LRP_HIP_CHECK(hipStreamSynchronize(S(stream)));      // weights are freed on return
+  return LRP_OK;
+}
+
+int lrp_op_epsilon_dense(const float* x_dev, const float* W_host, const float* R_dev, float* out_dev, int32_t N,
+                         int32_t Din, int32_t Dout, float epsilon, void* stream) {
+  if (!x_dev || !W_host || !R_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (N < 1 || (Din & 3) || (Dout & 3) || !(epsilon > 0.f)) return fail(LRP_ERR_INVALID, "need N>=1, Din%%4==0, Dout%%4==0, epsilon>0");
+  hipStream_t st = S(stream);
+  // Z = x.W  (1-tap GEMM, B operand packed [Dout][Din]);  C = S.W^T  (packed [Din][Dout])
+  const int Np = conv_npad(Dout), K = conv_cinp(Din), Npb = conv_npad(Din), Kb = conv_cinp(Dout);
+  std::vector<float> pk((size_t)Np * K, 0.f), pkb((size_t)Npb * Kb, 0.f);
+  pack_conv_fwd(W_host, 1, Din, Dout, 0, Np, pk.data());
+  pack_conv_bwd(W_host, 1, Din, Dout, 0, pkb.data());
+  DevBuf wf, wb, Z, Sb;
+  LRP_TRY(wf.alloc(pk.size() * sizeof(float), nullptr));
+  LRP_TRY(wb.alloc(pkb.size() * sizeof(float), nullptr));
+  LRP_TRY(Z.alloc((size_t)N * Dout * sizeof(float), nullptr));
+  LRP_TRY(Sb.alloc((size_t)N * Dout * sizeof(float), nullptr));
+  LRP_HIP_CHECK(hipMemcpy(wf.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+  LRP_HIP_CHECK(hipMemcpy(wb.p, pkb.data(), pkb.size() * sizeof(float), hipMemcpyHostToDevice));
+  ConvArgs cz{};
+  cz.in = x_dev; cz.wpk = wf.as<float>(); cz.NB = N; cz.H = 1; cz.W = 1; cz.Cin = Din; cz.CinP = K; cz.N = Dout; cz.taps = 1;
+  cz.out = Z.as<float>();
+  LRP_HIP_CHECK(conv_launch(EPI_STORE, cz, st));
+  const size_t ne = (size_t)N * Dout;
+  hipLaunchKernelGGL(eps_divide_kernel, dim3(stream_grid(ne)), dim3(256), 0, st, R_dev, Z.as<float>(), Sb.as<float>(), epsilon, ne);
+  LRP_HIP_CHECK(hipGetLastError());
+  ConvArgs cb{};
+  cb.in = Sb.as<float>(); cb.wpk = wb.as<float>(); cb.NB = N; cb.H = 1; cb.W = 1; cb.Cin = Dout; cb.CinP = Kb; cb.N = Din;
+  cb.taps = 1; cb.aux = x_dev; cb.out = out_dev;
+  LRP_HIP_CHECK(conv_launch(EPI_MUL, cb, st));                       // R_in = x * (S . W^T)
+  LRP_HIP_CHECK(hipStreamSynchronize(st));
+  return LRP_OK;
+}
+
+int lrp_op_batchnorm_lrp(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* mean_dev,
+                         const float* var_dev, float bn_eps, const float* R_dev, float* out_dev, int64_t n, int32_t C,
+                         void* stream) {
+  if (!x_dev || !gamma_dev || !beta_dev || !mean_dev || !var_dev || !R_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (n < 1 || C < 1 || n % C) return fail(LRP_ERR_INVALID, "n must be a positive multiple of C");
+  hipLaunchKernelGGL(bn_lrp_kernel, dim3(stream_grid((size_t)n)), dim3(256), 0, S(stream), x_dev, gamma_dev, beta_dev,
+                     mean_dev, var_dev, bn_eps, R_dev, out_dev, (size_t)n, C);
+  LRP_HIP_CHECK(hipGetLastError());
+  return LRP_OK;
+}
+
+int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, float* Ra_dev, float* Rb_dev, int64_t n,
+                   void* stream) {
+  if (!a_dev || !b_dev || !R_dev || !Ra_dev || !Rb_dev || n < 1) return fail(LRP_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(add_lrp_kernel, dim3(stream_grid((size_t)n)), dim3(256), 0, S(stream), a_dev, b_dev, R_dev, Ra_dev,
+                     Rb_dev, (size_t)n);
+  LRP_HIP_CHECK(hipGetLastError());
   return LRP_OK;
 }
 

@@ -244,3 +244,37 @@ def op_conv(x, w_hwio, bias, aux, mode, taps=9):
                                 C.c_void_p(out.data_ptr()), NB, H, W, Cin, Cout, taps, mode,
                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return out
+
+
+def _cur_stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def op_epsilon_dense(x, W, R, epsilon):
+    """EpsilonRule(bias=False) for a Dense layer (RR:113-144): x (N,Din), W (Din,Dout) numpy, R (N,Dout)."""
+    lib = _capi.load()
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    out = torch.empty_like(x)
+    _capi.check(lib.lrp_op_epsilon_dense(C.c_void_p(x.data_ptr()), W.ctypes.data_as(C.c_void_p), C.c_void_p(R.data_ptr()),
+                                         C.c_void_p(out.data_ptr()), x.shape[0], W.shape[0], W.shape[1], float(epsilon),
+                                         _cur_stream(x.device)))
+    return out
+
+
+def op_batchnorm_lrp(x, gamma, beta, mean, var, bn_eps, R):
+    """BatchNormalizationReverseLayer (RA:197-257), channels-last tensors on the GPU."""
+    lib = _capi.load()
+    out = torch.empty_like(x)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _capi.check(lib.lrp_op_batchnorm_lrp(p(x), p(gamma), p(beta), p(mean), p(var), float(bn_eps), p(R), p(out), x.numel(),
+                                         x.shape[-1], _cur_stream(x.device)))
+    return out
+
+
+def op_add_lrp(a, b, R):
+    """AddReverseLayer (RA:260-286)."""
+    lib = _capi.load()
+    Ra, Rb = torch.empty_like(a), torch.empty_like(b)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _capi.check(lib.lrp_op_add_lrp(p(a), p(b), p(R), p(Ra), p(Rb), a.numel(), _cur_stream(a.device)))
+    return Ra, Rb
