@@ -87,26 +87,35 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
   const int nk = a.taps * cpt;
 
   // ---- per-thread A row metadata (rows do not change over the K loop)
+  // One division pair for the first row; rows +32, +64, ... follow by carry (short-K layers spend
+  // a visible share of a block in this prologue).  The 9-bit tap mask comes from 4 edge predicates.
   const float* aptr[AP];
   unsigned amask[AP];
+  {
+    const int mfirst = m0 + lrow;
+    int rem = mfirst % HW;
+    int h = rem / a.W, w = rem - h * a.W;
 #pragma unroll
-  for (int p = 0; p < AP; ++p) {
-    const int m = m0 + lrow + 32 * p;
-    unsigned mask = 0;
-    if (m < a.M) {
-      if (a.taps == 1) {
-        mask = 1u;
-      } else {
-        const int rem = m % HW, h = rem / a.W, w = rem - h * a.W;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-          if (hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) mask |= 1u << t;
+    for (int p = 0; p < AP; ++p) {
+      const int m = mfirst + 32 * p;
+      unsigned mask = 0;
+      if (m < a.M) {
+        if (a.taps == 1) {
+          mask = 1u;
+        } else {
+          const unsigned row_ok = (h > 0 ? 0x007u : 0u) | 0x038u | (h < a.H - 1 ? 0x1C0u : 0u);   // taps 0-2 / 3-5 / 6-8
+          const unsigned col_ok = (w > 0 ? 0x049u : 0u) | 0x092u | (w < a.W - 1 ? 0x124u : 0u);   // taps 0,3,6 / 1,4,7 / 2,5,8
+          mask = row_ok & col_ok;
         }
       }
+      amask[p] = mask;
+      aptr[p] = a.in + (size_t)m * a.Cin + chunk * 4;
+      if (a.taps != 1) {                                  // next pass: 32 pixels further
+        w += 32;
+        while (w >= a.W) { w -= a.W; ++h; }
+        while (h >= a.H) h -= a.H;
+      }
     }
-    amask[p] = mask;
-    aptr[p] = a.in + (size_t)m * a.Cin + chunk * 4;
   }
   const float* bptr = a.wpk + (size_t)(n0 + lrow) * K + chunk * 4;
 
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
   // ---- conv-LRP epilogues: stage the C tile through the (now idle) LDS so that the gate loads
   // and the relevance stores are 16 B per lane along the channel axis (a pixel's channels are
   // contiguous in NHWC) instead of one dword per lane.
-  if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
+  if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_FWD_DUAL) {
     static_assert(BM * BN <= 2 * STAGE, "C tile must fit the staging LDS");
     float* Cs = smem;
 #pragma unroll
@@ -242,6 +251,27 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     const int col = n0 + c4 * 4;
     const int tn0 = m0 / HW, tp0 = m0 - tn0 * HW;
     const float invw = 1.0f / (float)a.W;
+    if constexpr (EPI == EPI_FWD_DUAL) {
+      // cols [0,split) -> out = relu(acc + bias)  (a_l);  cols [split,2 split) -> out2 = acc + bias  (Z+_l)
+      if (col < 2 * a.split) {
+        const bool isz = col >= a.split;
+        const int c = isz ? col - a.split : col;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
+        float* dst = (isz ? a.out2 : a.out) + c;
+#pragma unroll 4
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+          const int lr = rin + ps * RPP, row = m0 + lr;
+          if (row >= a.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * 4) + bv;
+          if (!isz) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(dst + (size_t)row * a.split) = v;
+        }
+      }
+      return;
+    }
     if (col < a.N) {
 #pragma unroll 4
       for (int ps = 0; ps < BM / RPP; ++ps) {
@@ -298,19 +328,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
           const int col = col_base + j * 32;
           if (rv && col < a.N) a.out[(size_t)row * a.N + col] = acc[i][j][r];
         }
-      } else if constexpr (EPI == EPI_FWD_DUAL) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = col_base + j * 32;
-          if (rv && col < 2 * a.split) {
-            if (col < a.split) {
-              a.out[(size_t)row * a.split + col] = fmaxf(acc[i][j][r] + a.bias[col], 0.f);
-            } else {
-              const int c = col - a.split;
-              a.out2[(size_t)row * a.split + c] = acc[i][j][r] + a.bias[c];
-            }
-          }
-        }
       }
     }
   }
@@ -332,6 +349,7 @@ inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
 template <int EPI>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & 3)) return hipErrorInvalidValue;   // 16 B epilogue
+  if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
   const ConvTile t = conv_pick_tile(a.N);
   a.M = a.NB * a.H * a.W;
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
