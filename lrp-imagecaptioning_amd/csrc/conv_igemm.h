@@ -79,25 +79,29 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
-  const int chunk = tid & 7, lrow = tid >> 3;
-  const int wchunk = chunk ^ ((lrow >> 1) & 7);        // (row>>1)&7 is the same for rows lrow + 32p
   const int HW = a.H * a.W;
   const int K = a.taps * a.CinP;
   const int cpt = a.CinP >> 5;                         // 32-wide k chunks per tap
   const int nk = a.taps * cpt;
 
-  // ---- per-thread A row metadata (rows do not change over the K loop)
-  // One division pair for the first row; rows +32, +64, ... follow by carry (short-K layers spend
-  // a visible share of a block in this prologue).  The 9-bit tap mask comes from 4 edge predicates.
+  // ---- staging: global -> LDS directly (global_load_lds_dwordx4), no VGPR round trip.
+  // One wave instruction moves 64 x 16 B = 1 KiB = 8 staged rows; the LDS side is linear
+  // (M0 base + lane*16), so the XOR swizzle is applied on the per-lane SOURCE address: lane i of
+  // piece q fills row 8q + (i>>3), physical chunk i&7, with logical chunk (i&7) ^ ((row>>1)&7).
+  // Wave w issues pieces w*AP .. w*AP+AP-1 of the A tile and w*BP .. of the B tile.
+  const int prow = lane >> 3, pchk = lane & 7;
+  const int wave_s = __builtin_amdgcn_readfirstlane(wave);
   const float* aptr[AP];
   unsigned amask[AP];
+  int alc[AP];                                         // logical chunk (x4 floats) this lane fetches for piece p
   {
-    const int mfirst = m0 + lrow;
+    const int rfirst = wave_s * AP * 8 + prow;         // tile row of piece p = 0
+    const int mfirst = m0 + rfirst;
     int rem = mfirst % HW;
     int h = rem / a.W, w = rem - h * a.W;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const int m = mfirst + 32 * p;
+      const int r = rfirst + 8 * p, m = m0 + r;
       unsigned mask = 0;
       if (m < a.M) {
         if (a.taps == 1) {
@@ -109,42 +113,44 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
         }
       }
       amask[p] = mask;
-      aptr[p] = a.in + (size_t)m * a.Cin + chunk * 4;
-      if (a.taps != 1) {                                  // next pass: 32 pixels further
-        w += 32;
+      alc[p] = (pchk ^ ((r >> 1) & 7)) << 2;
+      aptr[p] = a.in + (size_t)m * a.Cin + alc[p];
+      if (a.taps != 1) {                                  // next piece: 8 pixels further
+        w += 8;
         while (w >= a.W) { w -= a.W; ++h; }
         while (h >= a.H) h -= a.H;
       }
     }
   }
-  const float* bptr = a.wpk + (size_t)(n0 + lrow) * K + chunk * 4;
+  const float* bptr[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int r = (wave_s * BP + p) * 8 + prow;
+    bptr[p] = a.wpk + (size_t)(n0 + r) * K + ((pchk ^ ((r >> 1) & 7)) << 2);
+  }
 
-  f32x4 ra[AP], rb[BP];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
   int tap = 0, cc = 0;                                 // position of the chunk being LOADED
-  auto load_chunk = [&]() {
+  auto issue_chunk = [&](int buf) {
     const int c0 = cc << 5;
     const int off = (a.taps == 1 ? 0 : ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * a.Cin) + c0;
-    const bool cvalid = (c0 + chunk * 4) < a.Cin;
+    float* As = smem + buf * STAGE;
+    float* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const float* src = (cvalid && ((amask[p] >> tap) & 1u)) ? aptr[p] + off : lrp_zero_page;
-      ra[p] = *reinterpret_cast<const f32x4*>(src);
+      const bool ok = ((amask[p] >> tap) & 1u) && (c0 + alc[p] < a.Cin);
+      const float* src = ok ? aptr[p] + off : lrp_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave_s * AP + p) * 8 * LDS_STRIDE), 16, 0, 0);
     }
     const int kofs = tap * a.CinP + c0;
 #pragma unroll
-    for (int p = 0; p < BP; ++p) rb[p] = *reinterpret_cast<const f32x4*>(bptr + (size_t)(32 * p) * K + kofs);
+    for (int p = 0; p < BP; ++p)
+      __builtin_amdgcn_global_load_lds((gptr_t)(bptr[p] + kofs), (lptr_t)(Bs + (wave_s * BP + p) * 8 * LDS_STRIDE), 16, 0, 0);
     // taps innermost: the 9 taps of one 32-channel chunk touch the same ~(BM + halo) pixel rows
     // (24 KB), so 8 of 9 re-reads hit L1/L2; tap-major order streamed BM x Cin x 4 B per tap
     // through a 64 KB-per-block share of the XCD's L2 and missed on every tap (FETCH_SIZE 7x).
     if (++tap == a.taps) { tap = 0; ++cc; }
-  };
-  auto store_chunk = [&](int buf) {
-    float* As = smem + buf * STAGE;
-    float* Bs = As + BM * LDS_STRIDE;
-#pragma unroll
-    for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(As + (lrow + 32 * p) * LDS_STRIDE + wchunk * 4) = ra[p];
-#pragma unroll
-    for (int p = 0; p < BP; ++p) *reinterpret_cast<f32x4*>(Bs + (lrow + 32 * p) * LDS_STRIDE + wchunk * 4) = rb[p];
   };
 
   // Two-level (blocked) summation: the MFMA is a strictly k-ordered fp32 fma chain, so a
@@ -159,9 +165,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
-  load_chunk();
-  store_chunk(0);
-  __syncthreads();
+  issue_chunk(0);
+  __syncthreads();                                     // (drains vmcnt: the DMA of chunk 0 has landed)
 
   const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE;
   const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE;
@@ -196,19 +201,16 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
-    if (more) load_chunk();                            // global loads fly under the MFMAs below
+    // The other LDS buffer is free for the whole iteration (every wave issued AND completed its
+    // reads of it before the previous barrier), so the DMA of chunk kc+1 is launched first and has
+    // the full 64-MFMA chunk (~1.7 us) to land; the barrier below waits for it (vmcnt(0)).
+    if (more) issue_chunk(buf ^ 1);
     const float* Ab = smem + buf * STAGE + a_off;
     const float* Bb = smem + buf * STAGE + b_off;
     read_frag(f1, Ab, Bb, 1);
     mfma_frag(f0);                                     // kk = 0
     read_frag(f0, Ab, Bb, 2);
     mfma_frag(f1);                                     // kk = 1
-    // The other LDS buffer is free for the whole iteration (every wave passed the barrier
-    // after its last read of it), so the staged registers are written mid-chunk: the
-    // vmcnt wait and the ds_write issue hide under the second half's MFMAs.
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) store_chunk(buf ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
     read_frag(f1, Ab, Bb, 3);
     mfma_frag(f0);                                     // kk = 2
     __syncthreads();
