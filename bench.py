@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                                                        "the N>1 control path with several ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -82,12 +84,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    local = local % max(torch.cuda.device_count(), 1)      # (rehearsal: more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from lrp_imagecaptioning_amd.engine import LRPEngine
     from lrp_imagecaptioning_amd.parallel import broadcast_weights, shard_range
@@ -131,7 +137,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=X.device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=X.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all()
