@@ -188,6 +188,12 @@ int lrp_op_batchnorm_lrp(const float* x_dev, const float* gamma_dev, const float
 int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, float* Ra_dev, float* Rb_dev,
                    int64_t n, void* stream);
 
+/* Score reduction of the LRP-inference layer (models/model.py:1675-1686) for n heat-maps:
+ * hp = mean over channels, hp /= max|hp|, then mode 0 = mean, 1 = mean(max(hp,0)), 2 = np.quantile(hp, 0.9).
+ * R_img_dev (n, npix, C) float32, scores_dev (n) float64. */
+int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, int32_t npix, int32_t C, int32_t mode,
+                       void* stream);
+
 const char* lrp_last_error(void);
 int lrp_abi_version(void);
 

@@ -13,6 +13,7 @@
 #include "decoder.h"
 #include "encoder.h"
 #include "rules_kernels.h"
+#include "score_kernels.h"
 
 namespace lrp {
 std::string& last_error_ref() {
@@ -289,6 +290,16 @@ int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, f
   if (!a_dev || !b_dev || !R_dev || !Ra_dev || !Rb_dev || n < 1) return fail(LRP_ERR_INVALID, "bad argument");
   hipLaunchKernelGGL(add_lrp_kernel, dim3(stream_grid((size_t)n)), dim3(256), 0, S(stream), a_dev, b_dev, R_dev, Ra_dev,
                      Rb_dev, (size_t)n);
+  LRP_HIP_CHECK(hipGetLastError());
+  return LRP_OK;
+}
+
+int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, int32_t npix, int32_t C, int32_t mode,
+                       void* stream) {
+  if (!R_img_dev || !scores_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (n < 1 || npix < 1 || C < 1) return fail(LRP_ERR_INVALID, "n, npix, C must be positive");
+  if (mode < 0 || mode > 2) return fail(LRP_ERR_UNSUPPORTED, "the lrp inference mode is not available");
+  hipLaunchKernelGGL(heatmap_score_kernel, dim3(n), dim3(256), 0, S(stream), R_img_dev, scores_dev, npix, C, mode);
   LRP_HIP_CHECK(hipGetLastError());
   return LRP_OK;
 }

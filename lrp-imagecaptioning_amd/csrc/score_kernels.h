@@ -1,0 +1,105 @@
+// score_kernels.h — heat-map -> scalar score of the LRP-inference layer (models/model.py:1675-1686),
+// one workgroup per heat-map, HBM-bound (each pass streams the 600 KB map from L2/HBM):
+//   hp = mean_c(R) ;  hp /= max|hp| (0 if the map is all zero) ;
+//   mode 0 "mean": mean(hp)   mode 1 "pos_mean": mean(max(hp,0))   mode 2 "quantile": np.quantile(hp, 0.9)
+// (postprocess()'s BGR->RGB flip does not change a channel mean.)  The quantile is exact: a 3-pass
+// 11/11/10-bit radix select on the order-preserving integer image of the float keys finds the two order
+// statistics numpy interpolates between (method 'linear': index (n-1)*0.9).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "decoder_kernels.h"
+
+namespace lrp {
+
+__device__ __forceinline__ unsigned f2key(float f) {           // monotone float -> uint
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+  const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+  return __uint_as_float(u);
+}
+__device__ __forceinline__ float hp_at(const float* __restrict__ R, size_t p, int C) {
+  // np.mean(hp, axis=-1) on float32: sequential float32 adds, then / C
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += R[p * C + c];
+  return s / (float)C;
+}
+
+// k-th smallest (0-based) of hp over the map, exact, via radix select; all threads of the block call it
+__device__ float select_kth(const float* __restrict__ R, int npix, int C, unsigned k, unsigned* hist /*2048*/,
+                            unsigned* bcast /*2*/) {
+  const int tid = threadIdx.x;
+  unsigned prefix = 0, mask = 0;
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  for (int pass = 0; pass < 3; ++pass) {
+    const int nb = 1 << bits[pass];
+    for (int i = tid; i < 2048; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < npix; p += 256) {
+      const unsigned key = f2key(hp_at(R, p, C));
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned acc = 0;
+      int b = 0;
+      for (; b < nb; ++b) {
+        if (acc + hist[b] > k) break;
+        acc += hist[b];
+      }
+      bcast[0] = (unsigned)b;
+      bcast[1] = acc;
+    }
+    __syncthreads();
+    prefix |= bcast[0] << shifts[pass];
+    mask |= (unsigned)(nb - 1) << shifts[pass];
+    k -= bcast[1];
+    __syncthreads();
+  }
+  return key2f(prefix);
+}
+
+__global__ __launch_bounds__(256) void heatmap_score_kernel(const float* __restrict__ Rall, double* __restrict__ scores,
+                                                            int npix, int C, int mode) {
+  __shared__ unsigned hist[2048];
+  __shared__ unsigned bcast[2];
+  __shared__ double red[4];
+  __shared__ float fred[4];
+  const float* R = Rall + (size_t)blockIdx.x * npix * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // pass 1: max |hp|
+  float mx = 0.f;
+  for (int p = tid; p < npix; p += 256) mx = fmaxf(mx, fabsf(hp_at(R, p, C)));
+  mx = wave_max(mx);
+  if (lane == 0) fred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+  __syncthreads();
+  if (mx == 0.f) {                                   // project(): all-zero map -> zeros
+    if (tid == 0) scores[blockIdx.x] = 0.0;
+    return;
+  }
+  if (mode == 2) {
+    // np.quantile(hp/mx, 0.9), linear interpolation between the two neighbouring order statistics
+    const double pos = (double)(npix - 1) * 0.9;
+    const unsigned k0 = (unsigned)pos;
+    const double frac = pos - (double)k0;
+    const float v0 = select_kth(R, npix, C, k0, hist, bcast);
+    const float v1 = (k0 + 1 < (unsigned)npix) ? select_kth(R, npix, C, k0 + 1, hist, bcast) : v0;
+    if (tid == 0) {
+      const double a = (double)(v0 / mx), b = (double)(v1 / mx);      // hp = 1.0 * hp / absmax in float32
+      scores[blockIdx.x] = a + (b - a) * frac;
+    }
+    return;
+  }
+  double s = 0.0;
+  for (int p = tid; p < npix; p += 256) {
+    const float v = hp_at(R, p, C) / mx;
+    s += (double)(mode == 1 ? fmaxf(v, 0.f) : v);
+  }
+  s = block_sum_d(s, red);
+  if (tid == 0) scores[blockIdx.x] = s / (double)npix;
+}
+
+}  // namespace lrp

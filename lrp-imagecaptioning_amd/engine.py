@@ -278,3 +278,17 @@ def op_add_lrp(a, b, R):
     p = lambda t: C.c_void_p(t.data_ptr())
     _capi.check(lib.lrp_op_add_lrp(p(a), p(b), p(R), p(Ra), p(Rb), a.numel(), _cur_stream(a.device)))
     return Ra, Rb
+
+
+def heatmap_scores(R_img, mode):
+    """LRP-inference score per heat-map (model.py:1675-1686) on the device: R_img (n,H,W,C) -> (n,) float64."""
+    lib = _capi.load()
+    m = {"mean": 0, "pos_mean": 1, "quantile": 2}.get(mode)
+    if m is None:
+        raise NotImplementedError("the lrp inference mode is not available")
+    R = R_img.contiguous()
+    n, C_ = R.shape[0], R.shape[-1]
+    out = torch.empty((n,), dtype=torch.float64, device=R.device)
+    _capi.check(lib.lrp_heatmap_scores(C.c_void_p(R.data_ptr()), C.c_void_p(out.data_ptr()), n, R[0].numel() // C_, C_, m,
+                                       _cur_stream(R.device)))
+    return out

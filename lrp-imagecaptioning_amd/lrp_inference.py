@@ -6,7 +6,6 @@ heat-map -> one scalar score -> lrp_weight[b, i, word] = 1 + score.
 The reference loops image by image, word by word (B x <=20 sequential LRP passes);
 here all (image, position) units of the batch go through ONE explain call."""
 import numpy as np
-import torch
 
 
 class LRPInferenceLayerAdaptive(object):
@@ -68,16 +67,6 @@ class LRPInferenceLayerAdaptive(object):
         return 1 + out                                                              # model.py:1690
 
     def _scores(self, R):
-        """model.py:1675-1686 on the device tensor R (n,H,W,3): the BGR->RGB flip does not change a
-        channel mean, so it is omitted; hp = mean_c(R) / max|.|."""
-        hp = R.mean(dim=-1)
-        m = hp.abs().amax(dim=(1, 2), keepdim=True)
-        hp = torch.where(m > 0, hp / m.clamp_min(1e-45), torch.zeros_like(hp)).double()
-        flat = hp.reshape(hp.shape[0], -1)
-        if self._lrp_inference_mode == "mean":
-            s = flat.mean(dim=1)
-        elif self._lrp_inference_mode == "pos_mean":
-            s = flat.clamp_min(0).mean(dim=1)
-        else:
-            s = torch.quantile(flat, 0.9, dim=1)
-        return s.cpu().numpy()
+        """model.py:1675-1686 for the device tensor R (n,H,W,3), in liblrp_hip.so (lrp_heatmap_scores)."""
+        from .engine import heatmap_scores
+        return heatmap_scores(R, self._lrp_inference_mode).cpu().numpy()

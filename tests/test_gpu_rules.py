@@ -51,3 +51,30 @@ def test_add_reverse():
     ra, rb = C.add_reverse([a, b], R, dtype=torch.float32)
     assert rel_l1(Ra.cpu().numpy(), ra) < 1e-5 and rel_l1(Rb.cpu().numpy(), rb) < 1e-5
     assert np.isfinite(Ra.cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("mode", ["mean", "pos_mean", "quantile"])
+def test_heatmap_scores_match_numpy(mode):
+    """lrp_heatmap_scores against the host restatement of model.py:1675-1686 (postprocess.lrp_inference_score)."""
+    from lrp_imagecaptioning_amd.engine import heatmap_scores
+    from lrp_imagecaptioning_amd.postprocess import lrp_inference_score
+    rs = np.random.RandomState(3)
+    R = (rs.standard_normal((5, 37, 41, 3)) * rs.uniform(0.1, 10, size=(5, 1, 1, 1))).astype(np.float32)
+    R[3] = 0.0                                        # all-zero map -> score 0
+    R[4, :, :, :] = np.abs(R[4])                      # positive-only map
+    got = heatmap_scores(torch.as_tensor(R).cuda(), mode).cpu().numpy()
+    want = np.array([lrp_inference_score(R[i:i + 1], mode) for i in range(5)])
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
+    with pytest.raises(NotImplementedError):
+        heatmap_scores(torch.as_tensor(R).cuda(), "median")
+
+
+def test_heatmap_scores_full_size_quantile_with_ties():
+    from lrp_imagecaptioning_amd.engine import heatmap_scores
+    from lrp_imagecaptioning_amd.postprocess import lrp_inference_score
+    rs = np.random.RandomState(9)
+    R = rs.standard_normal((2, 224, 224, 3)).astype(np.float32)
+    R[1] = np.round(R[1] * 4) / 4                     # heavy ties around the selected order statistics
+    got = heatmap_scores(torch.as_tensor(R).cuda(), "quantile").cpu().numpy()
+    want = np.array([lrp_inference_score(R[i:i + 1], "quantile") for i in range(2)])
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
