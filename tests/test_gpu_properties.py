@@ -1,0 +1,121 @@
+"""-m gpu: size-independent properties at the BASELINE geometry (VGG16 224x224, L=196, D=H=E=512)
+and edge cases: batch invariance, bitwise reproducibility, linearity, zero relevance, capacity
+errors, longest caption (20 words + EOS)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l1
+from gpu_util import report
+from lrp_imagecaptioning_amd.synthetic import adaptive_weights, captions, decoder_case, images, vgg_weights
+from oracle.decoder_ref import AdaptiveOracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full_engine():
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    rs = np.random.RandomState(0)
+    V = 3000
+    w = vgg_weights(rs)
+    w.update(adaptive_weights(rs, 196, 512, 512, 512, V))
+    eng = LRPEngine(decoder="adaptive", V=V, max_images=4, max_tokens=24, max_caption_len=21)
+    eng.set_weights(w)
+    return eng, w, V
+
+
+def test_batch_invariance_and_reproducibility(full_engine):
+    """Heat-maps of an image do not depend on what else is in the batch, and the path is
+    bit-reproducible run to run (no atomics anywhere on it)."""
+    eng, w, V = full_engine
+    rs = np.random.RandomState(11)
+    X = images(rs, 3)
+    caps = captions(rs, 3, 5, V)
+    eng.encode_images(X)
+    eng.decoder_forward(caps)
+    idx = [0, 0, 1, 2, 2, 1]
+    tt = [1, 5, 3, 2, 4, 1]
+    out1, R1, _, _ = eng.explain_tokens(idx, tt, want_R_feat=True)
+    out1, R1 = out1.clone(), R1.clone()
+    out2, R2, _, _ = eng.explain_tokens(idx, tt, want_R_feat=True)
+    assert torch.equal(out1, out2) and torch.equal(R1, R2)                 # bitwise
+    # image 2 alone, different slot and batch size
+    eng.encode_images(X[2:3])
+    eng.decoder_forward([caps[2]])
+    solo, _, _, _ = eng.explain_tokens([0, 0], [2, 4])
+    a, b = out1[3].cpu().numpy(), out1[4].cpu().numpy()
+    assert rel_l1(solo[0].cpu().numpy(), a) < 1e-6 and rel_l1(solo[1].cpu().numpy(), b) < 1e-6
+    assert np.isfinite(a).all()
+
+
+def test_cnn_linearity_and_zero(full_engine):
+    eng, w, V = full_engine
+    rs = np.random.RandomState(5)
+    X = images(rs, 1)
+    eng.encode_images(X)
+    feat = eng.get_features()[0].cpu().numpy()
+    Ra = (rs.standard_normal(feat.shape) * feat).astype(np.float32)
+    Rb = (rs.standard_normal(feat.shape) * feat).astype(np.float32)
+    out = eng.cnn_explain([0, 0, 0, 0], np.stack([Ra, Rb, 3 * Ra - 2 * Rb, np.zeros_like(Ra)])).cpu().numpy()
+    assert rel_l1(out[2], 3 * out[0] - 2 * out[1]) < 2e-5
+    assert (out[3] == 0).all()                                            # zero relevance in -> zero out
+    # relevance only reaches pixels through positive paths: where the features are zero nothing flows
+    assert np.isfinite(out).all()
+
+
+def test_longest_caption_full_size(full_engine):
+    """max_caption_length = 20 words + EOS (config.py:34): the deepest reverse scan, t = 20, vs the oracle."""
+    eng, w, V = full_engine
+    rs = np.random.RandomState(21)
+    feat = np.maximum(rs.standard_normal((1, 14, 14, 512)), 0).astype(np.float32)
+    cap = [int(c) for c in rs.randint(3, V + 1, size=20)] + [1]
+    eng.set_features(feat.reshape(1, 196, 512))
+    eng.decoder_forward([cap])
+    R, att, rw = eng.decoder_explain([0], [20])
+    o = AdaptiveOracle(w, 196, 512, 512, 512)
+    o.forward(feat, cap)
+    Rref, aref = o.explain(20)
+    err = rel_l1(R[0].cpu().numpy(), Rref.reshape(196, 512))
+    report("dec_full_t20", rel_l1=err)
+    assert err < 1e-4
+    np.testing.assert_allclose(att[0].cpu().numpy(), aref, rtol=1e-4, atol=1e-8)
+    assert rel_l1(rw[0, :19].cpu().numpy(), o.r_words) < 1e-3
+
+
+def test_capacity_and_argument_errors(full_engine):
+    eng, w, V = full_engine
+    rs = np.random.RandomState(2)
+    X = images(rs, 1)
+    eng.encode_images(X)
+    eng.decoder_forward([[5, 9, 1]])
+    with pytest.raises(ValueError):
+        eng.explain_tokens([0] * 25, [1] * 25)                             # n > max_tokens
+    with pytest.raises(ValueError):
+        eng.encode_images(images(rs, 5))                                   # B > max_images
+    with pytest.raises(ValueError):
+        eng.decoder_forward([[5, V + 7, 1]])                               # token id outside the vocabulary
+    with pytest.raises(ValueError):
+        eng.decoder_forward([list(range(3, 30))])                          # longer than max_caption_len
+    with pytest.raises(NotImplementedError):
+        eng.explain_tokens([0], [4])                                       # t beyond the caption (E:538-539)
+    with pytest.raises(ValueError):
+        eng.encode_images(np.zeros((1, 100, 100, 3), np.float32))
+
+
+def test_caption_of_one_word():
+    """T = 1 (a single word + EOS): the scan has one step, r_words is empty (E:660-665)."""
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    L, D, H, V = 16, 32, 32, 60
+    w, feat, _ = decoder_case("adaptive", 4, L, D, H, V, 1)
+    eng = LRPEngine(decoder="adaptive", cnn_cfg=[("c1", 3, D, False)], img_hw=(4, 4), L=L, D=D, H=H, E=H, V=V,
+                    max_images=1, max_tokens=2, max_caption_len=3)
+    eng.set_weights(w)
+    eng.set_features(feat.reshape(1, L, D))
+    cap = [17, 1]
+    eng.decoder_forward([cap])
+    R, _, rw = eng.decoder_explain([0], [1])
+    o = AdaptiveOracle(w, L, D, H, H)
+    o.forward(feat, cap)
+    assert rel_l1(R[0].cpu().numpy(), o.explain(1)[0].reshape(L, D)) < 1e-4
+    assert len(o.r_words) == 0 and (rw.cpu().numpy() == 0).all()
