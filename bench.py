@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "LRP heatmaps/sec (per predicted token) VGG16+adaptive-attn, 224x224"
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X_MICROARCH.md: bf16 MFMA dense (v_mfma_f32_32x32x16_bf16)
 
 
 def synth_weights(seed, V):
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=3)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+                    help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                         "the N>1 control path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -101,6 +104,7 @@ def main():
 
     B, T, V = args.batch, args.tokens, args.vocab
     eng = LRPEngine(decoder="adaptive", V=V, max_images=B, max_tokens=B * T, max_caption_len=T + 1, device=local)
+    eng.set_precision(args.precision)
     # frozen weights: rank 0 owns them, everyone else receives them over RCCL/xGMI
     w_host = synth_weights(0, V) if rank == 0 else None
     if world > 1:
@@ -153,20 +157,31 @@ def main():
     traffic, traffic_src = pmc_traffic_per_launch()
     if rank == 0:
         heatmaps = world * B * T * args.steps
+        if args.precision == "bf16x3":
+            peak, dtype = PEAK_BF16_MFMA_TFLOPS, "bf16x3"
+            kname = ("conv_igemm_kernel<..., PREC_BF16X3> (conv-LRP alpha1beta0 backward, 13 launches/step; every fp32 "
+                     "product = 3 bf16 MFMAs hi*hi+hi*lo+lo*hi, fp32 accumulate; forward/decoder stay fp32/fp64)")
+        else:
+            peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
+            kname = "conv_igemm_kernel<..., PREC_FP32> (conv-LRP alpha1beta0 backward, 13 launches/step)"
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_unit": "HBM+MALL bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+                "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
+                "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2)}
+        if args.precision == "bf16x3":
+            roof["mfma_flop_per_algorithmic_flop"] = 3
+            roof["issued_mfma_frac"] = round(3 * achieved / peak, 4)
+            roof["vs_fp32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 3)
         res = {
             "metric": METRIC, "value": round(heatmaps / dt, 2), "unit": "heatmaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "batch=%d synthetic 224x224 per GPU, VGG16 + adaptive-attention, LRP per-token "
                                    "heat-maps, %d words/caption, V=%d (BASELINE configs[1])" % (B, T, V),
-                       "heatmaps_per_step": world * B * T, "parallelism": "image-sharded x%d, RCCL weight broadcast" % world},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (conv-LRP alpha1beta0 backward, 13 launches/step)",
-                         "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM+MALL bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-                         "traffic_source": traffic_src,
-                         "launches": n_launch, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
-                         "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2)},
+                       "heatmaps_per_step": world * B * T, "parallelism": "image-sharded x%d, RCCL weight broadcast" % world,
+                       "reverse_walk_precision": args.precision},
+            "roofline": roof,
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(w_host, V, T, args.cpu_sample_tokens)

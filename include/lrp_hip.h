@@ -151,6 +151,16 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
                        const int32_t* t_host, int32_t variant, float* R_img_dev,
                        float* R_feat_dev, float* att_dev, double* r_words_dev, void* stream);
 
+/* Arithmetic of the per-token reverse walk through the encoder (lrp_cnn_explain / lrp_explain_tokens).
+ * LRP_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * LRP_PREC_BF16X3 split-bf16: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
+ *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+ *                 Default.  Measured parity of the heat-maps vs the float64 reference graph: 5.9e-6 relative L1
+ *                 (fp32 mode: 3.9e-6; bar 1e-4).  Conv widths % 8 != 0 silently use the fp32 path.
+ * The per-image forward (lrp_encode_images) and the decoder are not affected. */
+enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1 };
+int lrp_set_precision(lrp_handle* h, int32_t mode);
+
 /* Dominant-kernel timing for bench.py's roofline block: when enabled, HIP
  * events bracket every conv-LRP launch on the caller's stream; query returns
  * launches and summed milliseconds since the last reset (syncs the events). */

@@ -11,6 +11,7 @@ LRP_ABI_VERSION = 1
 LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANGE, LRP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
 LRP_EXPLAIN_SEQUENCE, LRP_EXPLAIN_SINGLE_STEP = 0, 1
+LRP_PREC_FP32, LRP_PREC_BF16X3 = 0, 1
 LRP_MAX_CONV = 32
 
 
@@ -41,6 +42,7 @@ SYMBOLS = {
     "lrp_decoder_explain": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, _P]),
     "lrp_cnn_explain": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P, _P]),
     "lrp_explain_tokens": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, _P, _P]),
+    "lrp_set_precision": (C.c_int, [_P, C.c_int32]),
     "lrp_profile_enable": (C.c_int, [_P, C.c_int32]),
     "lrp_profile_query": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lrp_profile_records": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

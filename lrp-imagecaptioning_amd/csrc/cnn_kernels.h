@@ -103,6 +103,24 @@ __global__ __launch_bounds__(256) void top_divide_kernel(const f32x4* __restrict
   }
 }
 
+// Same head, writing the split8 operand format of the bf16x3 reverse walk (8 channels per thread)
+__global__ __launch_bounds__(256) void top_divide_split_kernel(const float* __restrict__ R, const float* __restrict__ Ztop,
+                                                               const int* __restrict__ row2img, float* __restrict__ S,
+                                                               int n, size_t per_img8) {
+  const size_t total = (size_t)n * per_img8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / per_img8);
+    const size_t e = i - (size_t)t * per_img8;
+    const int img = row2img ? row2img[t] : t;
+    const float* r = R + i * 8;
+    const float* z = Ztop + ((size_t)img * per_img8 + e) * 8;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = r[c] / safe_den(z[c]);
+    split8_store(o, S + i * 8);
+  }
+}
+
 // Image layer of the reverse walk (RR:306-312 with both sign branches live):
 //   R_img[p][c] = x+[p][c] * convT(S_1, w+)[p][c] + x-[p][c] * convT(S_1, w-)[p][c]
 // computed as a channel reduction FIRST (one K = C_1 GEMM on the MFMA kernel):

@@ -20,11 +20,35 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 namespace lrp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// PREC_FP32 : operands fp32, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+// PREC_BF16X3: operands stored as "split8" — per 8 consecutive channels 32 B = [8 x bf16 hi | 8 x bf16 lo] with
+//   x ~= hi + lo (16 mantissa bits), same bytes as fp32.  Each product is hi*hi' + hi*lo' + lo*hi' on
+//   v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs of 32 cycles per 16 k instead of 8 of 64
+//   (5.3x fewer matrix-pipe cycles).  Used for the per-token reverse walk only; the per-image forward
+//   stays exact fp32 (measured: forward fp32 + backward split = 2-3.5e-6 relative L1 vs the float64
+//   graph; splitting the forward too = 2.4e-5, because errors in Z / a are systematic, errors in S average out).
+enum ConvPrec { PREC_FP32 = 0, PREC_BF16X3 = 1 };
+
+__device__ __forceinline__ void split8_store(const float* r, float* dst) {   // 8 fp32 -> 32 B [hi8 | lo8]
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    hi[q] = (__bf16)r[q];
+    lo[q] = (__bf16)(r[q] - (float)hi[q]);
+  }
+  u32x4* d = reinterpret_cast<u32x4*>(dst);
+  d[0] = __builtin_bit_cast(u32x4, hi);
+  d[1] = __builtin_bit_cast(u32x4, lo);
+}
 
 enum ConvEpi {
   EPI_BIAS_RELU = 0,  // out = relu(acc + bias)
@@ -58,7 +82,7 @@ constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; sw
 // eight loads of a chunk issue back to back.
 __device__ __attribute__((aligned(16))) float lrp_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the GLOBAL address space (a const page makes the select generic -> flat_load, which also counts on lgkmcnt)
 
-template <int WM, int WN, int TM, int TN, int EPI>
+template <int WM, int WN, int TM, int TN, int EPI, int PREC>
 __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 32, BP = BN / 32;          // 32 rows per load pass (256 threads x 16 B)
@@ -139,7 +163,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     float* Bs = As + BM * LDS_STRIDE;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const bool ok = ((amask[p] >> tap) & 1u) && (c0 + alc[p] < a.Cin);
+      // first channel covered by this lane's 16 B chunk: 4*chunk (fp32) or 8*(chunk/2) (split8 group)
+      const int cfirst = PREC == PREC_BF16X3 ? ((alc[p] >> 3) << 3) : alc[p];
+      const bool ok = ((amask[p] >> tap) & 1u) && (c0 + cfirst < a.Cin);
       const float* src = ok ? aptr[p] + off : lrp_zero_page;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave_s * AP + p) * 8 * LDS_STRIDE), 16, 0, 0);
     }
@@ -170,30 +196,61 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
 
   const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE;
   const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE;
-  int koff[4];                                         // float offset of logical chunk 2kk+h in this lane's row
+  // Fragment registers are double-buffered one step ahead, and the first fragments of the NEXT
+  // chunk are fetched right after the barrier: the last MFMA group of the current chunk runs on
+  // registers while those reads are in flight.  (All reads of `buf` are issued AND completed
+  // before the barrier => the DMA of the following iteration cannot race them.)
+  // fp32 : 4 steps of 8 k per chunk; lane-half h consumes k = 4h+s -> logical chunk 2kk+h.
+  // bf16x3: 2 steps of 16 k; lane-half h consumes k = 8h+j -> split8 group 2s+h = chunks 4s+2h (hi), 4s+2h+1 (lo).
+  constexpr int NSTEP = PREC == PREC_BF16X3 ? 2 : 4;
+  const int swz = (lane >> 1) & 7, hh = lane >> 5;
+  int koff[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) koff[kk] = (((2 * kk + (lane >> 5)) ^ ((lane >> 1) & 7)) << 2);
-
-  // Fragment registers are double-buffered one kk-step ahead, and the first fragments of the
-  // NEXT chunk are fetched right after the barrier: the last 16 MFMAs of the current chunk run
-  // on registers while those reads are in flight, so no wave sits behind an LDS round trip
-  // after the barrier.  (All reads of `buf` are issued before the barrier => the mid-chunk
-  // store of the following iteration cannot race them.)
-  struct Frag { f32x4 a[TM], b[TN]; };
-  auto read_frag = [&](Frag& f, const float* Ab, const float* Bb, int kk) {
+  for (int q = 0; q < 4; ++q)
+    koff[q] = PREC == PREC_BF16X3 ? (((4 * (q >> 1) + 2 * hh + (q & 1)) ^ swz) << 2)     // q = 2*step + {hi,lo}
+                                  : (((2 * q + hh) ^ swz) << 2);
+  struct Frag { u32x4 a[PREC == PREC_BF16X3 ? 2 * TM : TM], b[PREC == PREC_BF16X3 ? 2 * TN : TN]; };
+  auto read_frag = [&](Frag& f, const float* Ab, const float* Bb, int st) {
+    if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + koff[kk]);
+      for (int i = 0; i < TM; ++i) {
+        f.a[2 * i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[2 * st]);
+        f.a[2 * i + 1] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[2 * st + 1]);
+      }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + koff[kk]);
+      for (int j = 0; j < TN; ++j) {
+        f.b[2 * j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st]);
+        f.b[2 * j + 1] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[st]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[st]);
+    }
   };
   auto mfma_frag = [&](const Frag& f) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+    if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, f.a[2 * i]), al = __builtin_bit_cast(bf16x8, f.a[2 * i + 1]);
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, f.b[2 * j]), bl = __builtin_bit_cast(bf16x8, f.b[2 * j + 1]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);    // small terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(f32x4, f.a[i])[s],
+                                                             __builtin_bit_cast(f32x4, f.b[j])[s], acc[i][j], 0, 0, 0);
+    }
   };
 
   Frag f0, f1;
@@ -201,21 +258,25 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
-    // The other LDS buffer is free for the whole iteration (every wave issued AND completed its
-    // reads of it before the previous barrier), so the DMA of chunk kc+1 is launched first and has
-    // the full 64-MFMA chunk (~1.7 us) to land; the barrier below waits for it (vmcnt(0)).
+    // The other LDS buffer is free for the whole iteration, so the DMA of chunk kc+1 is launched
+    // first and has the whole chunk to land; the barrier below waits for it (vmcnt(0)).
     if (more) issue_chunk(buf ^ 1);
     const float* Ab = smem + buf * STAGE + a_off;
     const float* Bb = smem + buf * STAGE + b_off;
-    read_frag(f1, Ab, Bb, 1);
-    mfma_frag(f0);                                     // kk = 0
-    read_frag(f0, Ab, Bb, 2);
-    mfma_frag(f1);                                     // kk = 1
-    read_frag(f1, Ab, Bb, 3);
-    mfma_frag(f0);                                     // kk = 2
+    if constexpr (NSTEP == 4) {
+      read_frag(f1, Ab, Bb, 1);
+      mfma_frag(f0);                                   // step 0
+      read_frag(f0, Ab, Bb, 2);
+      mfma_frag(f1);                                   // step 1
+      read_frag(f1, Ab, Bb, 3);
+      mfma_frag(f0);                                   // step 2
+    } else {
+      read_frag(f1, Ab, Bb, 1);
+      mfma_frag(f0);                                   // step 0
+    }
     __syncthreads();
     if (more) read_frag(f0, smem + (buf ^ 1) * STAGE + a_off, smem + (buf ^ 1) * STAGE + b_off, 0);
-    mfma_frag(f1);                                     // kk = 3
+    mfma_frag(f1);                                     // last step
     if ((kc & (FLUSH - 1)) == FLUSH - 1) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -248,9 +309,11 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
         for (int j = 0; j < TN; ++j) Cs[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
       }
     __syncthreads();
-    constexpr int C4 = BN / 4, RPP = 256 / C4;
+    constexpr bool SPLIT_OUT = PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2);
+    constexpr int CW = SPLIT_OUT ? 8 : 4;               // channels per thread (split8 output is written per group)
+    constexpr int C4 = BN / CW, RPP = 256 / C4;
     const int c4 = tid % C4, rin = tid / C4;
-    const int col = n0 + c4 * 4;
+    const int col = n0 + c4 * CW;
     const int tn0 = m0 / HW, tp0 = m0 - tn0 * HW;
     const float invw = 1.0f / (float)a.W;
     if constexpr (EPI == EPI_FWD_DUAL) {
@@ -279,27 +342,36 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
       for (int ps = 0; ps < BM / RPP; ++ps) {
         const int lr = rin + ps * RPP, row = m0 + lr;
         if (row >= a.M) break;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * 4);
+        float v[CW];
+#pragma unroll
+        for (int q4 = 0; q4 < CW / 4; ++q4)
+          *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * CW + 4 * q4);
         int n = tn0, pix = tp0 + lr;
         while (pix >= HW) { pix -= HW; ++n; }
         const int img = a.row2img ? a.row2img[n] : n;
+        // out = acc * gate (fp32), stored as fp32 or re-split into [hi8 | lo8] for the next layer's MFMAs
+        auto emit = [&](const float* gsrc, float* dst) {
+          float r[CW];
+#pragma unroll
+          for (int q4 = 0; q4 < CW / 4; ++q4) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 4 * q4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[4 * q4 + q] = v[4 * q4 + q] * g[q];
+          }
+          if constexpr (SPLIT_OUT) split8_store(r, dst);
+          else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+        };
         if constexpr (EPI == EPI_MUL) {
-          const f32x4 g = *reinterpret_cast<const f32x4*>(a.aux + ((size_t)img * HW + pix) * a.N + col);
-          *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + col) = v * g;
+          emit(a.aux + ((size_t)img * HW + pix) * a.N + col, a.out + (size_t)row * a.N + col);
         } else {
           int h = (int)(((float)pix + 0.5f) * invw);
           int w = pix - h * a.W;
           if (w < 0) { --h; w += a.W; } else if (w >= a.W) { ++h; w -= a.W; }
           const int W2 = 2 * a.W, H2 = 2 * a.H;
-          f32x4 g[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            g[q] = *reinterpret_cast<const f32x4*>(
-                a.aux + (((size_t)img * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(a.out + (((size_t)n * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col) =
-                v * g[q];
+            emit(a.aux + (((size_t)img * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col,
+                 a.out + (((size_t)n * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col);
         }
       }
     }
@@ -348,9 +420,11 @@ inline ConvTile conv_pick_tile(int N) {
 inline int conv_npad(int N) { ConvTile t = conv_pick_tile(N); return (N + t.BN - 1) / t.BN * t.BN; }
 inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
 
-template <int EPI>
+template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
-  if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & 3)) return hipErrorInvalidValue;   // 16 B epilogue
+  constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
+  if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & need)) return hipErrorInvalidValue;
+  if (PREC == PREC_BF16X3 && (a.Cin & 7)) return hipErrorInvalidValue;
   if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
   const ConvTile t = conv_pick_tile(a.N);
   a.M = a.NB * a.H * a.W;
@@ -359,22 +433,31 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   const dim3 grid(a.m_tiles * a.n_tiles), block(256);
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (t.BN == 128)
-    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC>), grid, block, 0, st, a);
   else if (t.BN == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, EPI>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, EPI, PREC>), grid, block, 0, st, a);
   return hipGetLastError();
 }
 
-inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st) {
+// prec = PREC_BF16X3 exists for the reverse-walk epilogues only (MUL, MUL_UP2, STORE)
+inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int prec = PREC_FP32) {
+  if (prec == PREC_BF16X3) {
+    switch (epi) {
+      case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_BF16X3>(a, st);
+      case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_BF16X3>(a, st);
+      case EPI_STORE: return conv_launch_epi<EPI_STORE, PREC_BF16X3>(a, st);
+    }
+    return hipErrorInvalidValue;
+  }
   switch (epi) {
-    case EPI_BIAS_RELU: return conv_launch_epi<EPI_BIAS_RELU>(a, st);
-    case EPI_BIAS: return conv_launch_epi<EPI_BIAS>(a, st);
-    case EPI_MUL: return conv_launch_epi<EPI_MUL>(a, st);
-    case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2>(a, st);
-    case EPI_FWD_DUAL: return conv_launch_epi<EPI_FWD_DUAL>(a, st);
-    case EPI_STORE: return conv_launch_epi<EPI_STORE>(a, st);
+    case EPI_BIAS_RELU: return conv_launch_epi<EPI_BIAS_RELU, PREC_FP32>(a, st);
+    case EPI_BIAS: return conv_launch_epi<EPI_BIAS, PREC_FP32>(a, st);
+    case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_FP32>(a, st);
+    case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_FP32>(a, st);
+    case EPI_FWD_DUAL: return conv_launch_epi<EPI_FWD_DUAL, PREC_FP32>(a, st);
+    case EPI_STORE: return conv_launch_epi<EPI_STORE, PREC_FP32>(a, st);
   }
   return hipErrorInvalidValue;
 }
@@ -399,6 +482,30 @@ inline void pack_conv_bwd(const float* w_hwio, int taps, int Cin, int Cout, int 
       for (int co = 0; co < Cout; ++co)
         wpk[(size_t)(col0 + ci) * K + t * CoutP + co] = w_hwio[((size_t)tf * Cin + ci) * Cout + co];
   }
+}
+
+// fp32 packed matrix [rows][K] (K % 8 == 0) -> split8 in place-compatible layout: per 8 k, 32 B = [hi8 | lo8]
+inline unsigned short f32_to_bf16_rne(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+inline float bf16_to_f32(unsigned short h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline void pack_split8(const float* src, size_t n_floats, float* dst_as_float) {
+  unsigned short* d = reinterpret_cast<unsigned short*>(dst_as_float);
+  for (size_t g = 0; g < n_floats / 8; ++g)
+    for (int q = 0; q < 8; ++q) {
+      const float x = src[g * 8 + q];
+      const unsigned short hi = f32_to_bf16_rne(x);
+      d[g * 16 + q] = hi;
+      d[g * 16 + 8 + q] = f32_to_bf16_rne(x - bf16_to_f32(hi));
+    }
 }
 
 }  // namespace lrp

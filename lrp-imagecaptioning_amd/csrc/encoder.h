@@ -22,6 +22,7 @@ struct ConvLayer {
   bool have_w = false, have_b = false;
   DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
+  DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
   size_t act_elems() const { return (size_t)H * W * cout; }
@@ -45,6 +46,7 @@ struct Encoder {
   int encoded = 0;         // images currently cached
   bool features_only = false;
   bool profile = false;
+  int prec = PREC_BF16X3;  // arithmetic of the per-token reverse walk (lrp_set_precision); falls back to fp32 for widths % 8 != 0
   std::vector<ProfileRec> prof;
 
   int init(const lrp_config& c, int64_t* total) {
@@ -126,6 +128,12 @@ struct Encoder {
           }
       LRP_TRY(L.w_bwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_bwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      {
+        std::vector<float> sp(pk.size());
+        pack_split8(pk.data(), pk.size(), sp.data());
+        LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
     } else {
       const int Np = conv_npad(2 * L.cout), K = 9 * conv_cinp(L.cin);
       pk.assign((size_t)Np * K, 0.f);
@@ -138,6 +146,12 @@ struct Encoder {
       pack_conv_bwd(wp.data(), 9, L.cin, L.cout, 0, pk.data());
       LRP_TRY(L.w_bwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_bwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      {
+        std::vector<float> sp(pk.size());
+        pack_split8(pk.data(), pk.size(), sp.data());
+        LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
     }
     L.have_w = true;
     return LRP_OK;
@@ -213,7 +227,16 @@ struct Encoder {
     const ConvLayer& T = layers.back();
     float* S = s0.as<float>();
     float* Snext = s1.as<float>();
-    {
+    bool split = prec == PREC_BF16X3;
+    for (const ConvLayer& L : layers)
+      if (L.cout & 7) split = false;                    // split8 groups need widths % 8 == 0: exact fp32 otherwise
+    const int run_prec = split ? PREC_BF16X3 : PREC_FP32;
+    if (split) {
+      const size_t per8 = T.act_elems() / 8;
+      hipLaunchKernelGGL(top_divide_split_kernel, dim3(stream_grid((size_t)n * per8)), dim3(256), 0, st, R_feat_dev,
+                         ztop.as<float>(), row2img_dev, S, n, per8);
+      LRP_HIP_CHECK(hipGetLastError());
+    } else {
       const size_t per4 = T.act_elems() / 4;
       hipLaunchKernelGGL(top_divide_kernel, dim3(stream_grid((size_t)n * per4)), dim3(256), 0, st,
                          reinterpret_cast<const f32x4*>(R_feat_dev), ztop.as<f32x4>(), row2img_dev,
@@ -224,7 +247,7 @@ struct Encoder {
       const ConvLayer& L = layers[li];
       ConvArgs ca{};
       ca.in = S; ca.NB = n; ca.H = L.H; ca.W = L.W; ca.Cin = L.cout; ca.CinP = conv_cinp(L.cout); ca.taps = 9;
-      ca.wpk = L.w_bwd.as<float>();
+      ca.wpk = split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
       ca.row2img = row2img_dev;
       int epi;
       if (li == 0) {
@@ -240,7 +263,7 @@ struct Encoder {
         (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1);
         (void)hipEventRecord(pr.e0, st);
       }
-      LRP_HIP_CHECK(conv_launch(epi, ca, st));
+      LRP_HIP_CHECK(conv_launch(epi, ca, st, run_prec));
       if (profile) {
         (void)hipEventRecord(pr.e1, st);
         pr.flop = 2.0 * (double)n * L.H * L.W * 9.0 * L.cout * (li == 0 ? 6 : L.cin);

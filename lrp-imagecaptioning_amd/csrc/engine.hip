@@ -192,6 +192,13 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host, co
   return h->enc.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
 }
 
+int lrp_set_precision(lrp_handle* h, int32_t mode) {
+  if (!h) return fail(LRP_ERR_INVALID, "null handle");
+  if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3) return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);
+  h->enc.prec = mode;
+  return LRP_OK;
+}
+
 int lrp_profile_enable(lrp_handle* h, int32_t on) {
   if (!h) return fail(LRP_ERR_INVALID, "null handle");
   h->enc.profile = on != 0;

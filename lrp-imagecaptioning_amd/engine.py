@@ -52,6 +52,7 @@ class LRPEngine(object):
             _capi.check(self._lib.lrp_create(C.byref(cfg), C.byref(self._h)))
         self.captions = None
         self.n_images = 0
+        self.precision = "bf16x3"                       # library default for the reverse walk (set_precision)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -201,6 +202,14 @@ class LRPEngine(object):
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         _capi.check(self._lib.lrp_explain_tokens(self._h, n, pi, pt, v, p(out), p(R), p(att), p(rw), self._stream()))
         return out, R, att, rw
+
+    def set_precision(self, mode):
+        """'fp32' (exact fp32 MFMA) or 'bf16x3' (split-bf16 reverse walk, see include/lrp_hip.h)."""
+        m = {"fp32": _capi.LRP_PREC_FP32, "bf16x3": _capi.LRP_PREC_BF16X3}.get(mode)
+        if m is None:
+            raise ValueError("precision must be 'fp32' or 'bf16x3'")
+        _capi.check(self._lib.lrp_set_precision(self._h, m))
+        self.precision = mode
 
     # ------------------------------------------------------------------ profiling hooks (bench.py)
     def profile_enable(self, on=True):

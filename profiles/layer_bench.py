@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=10)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--vocab", type=int, default=10000)
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3"])
     a = ap.parse_args()
     import torch
     from bench import synth_weights
@@ -26,6 +27,7 @@ def main():
     B, T, V = a.batch, a.tokens, a.vocab
     eng = LRPEngine(decoder="adaptive", V=V, max_images=B, max_tokens=B * T, max_caption_len=T + 1)
     eng.set_weights(synth_weights(0, V))
+    eng.set_precision(a.precision)
     rs = np.random.RandomState(1)
     X = torch.as_tensor(images(rs, B)).cuda()
     caps = captions(rs, B, T, V)

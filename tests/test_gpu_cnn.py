@@ -28,13 +28,15 @@ def _engine(cfg, hw, B, ntok, w):
     return eng, side
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name,cfg,hw,B", [("tiny", TINY_CFG, 16, 3), ("mid", MID_CFG, 32, 2)])
-def test_small_nets_match_oracle(name, cfg, hw, B):
+def test_small_nets_match_oracle(name, cfg, hw, B, prec):
     rs = np.random.RandomState(7)
     w = vgg_weights(rs, cfg, bias_std=0.3)
     layers = C.vgg_layers(w, cfg)
     X = rs.uniform(-120, 130, size=(B, hw, hw, 3)).astype(np.float32)
     eng, side = _engine(cfg, hw, B, 2 * B, w)
+    eng.set_precision(prec)
     eng.encode_images(X)
     feat = eng.get_features().cpu().numpy().reshape(B, side, side, -1)
     feat_ref = C.forward(layers, X)
@@ -45,19 +47,22 @@ def test_small_nets_match_oracle(name, cfg, hw, B):
     out = eng.cnn_explain(idx, R).cpu().numpy()
     ref = C.analyze(layers, X[idx], R)
     errs = [rel_l1(out[i], ref[i]) for i in range(2 * B)]
-    report("cnn_" + name, max_rel_l1=max(errs))
+    report("cnn_" + name + "_" + prec, max_rel_l1=max(errs))
     assert np.isfinite(out).all()
     assert max(errs) < TOL, errs
 
 
-def test_vgg16_full_size_matches_oracle():
-    """BASELINE geometry: 224x224, VGG16 to block5_conv3, 2 images x 2 relevance maps."""
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_vgg16_full_size_matches_oracle(prec):
+    """BASELINE geometry: 224x224, VGG16 to block5_conv3, 2 images x 2 relevance maps, both arithmetic
+    modes of the reverse walk (exact fp32 MFMA / split-bf16 x3)."""
     rs = np.random.RandomState(0)
     w = vgg_weights(rs)
     layers = C.vgg_layers(w, VGG16_CFG)
     X = images(rs, 2)
     eng, side = _engine(VGG16_CFG, 224, 2, 4, w)
     assert side == 14
+    eng.set_precision(prec)
     eng.encode_images(X)
     feat = eng.get_features().cpu().numpy().reshape(2, 14, 14, 512)
     feat_ref = C.forward(layers, X)
@@ -67,12 +72,12 @@ def test_vgg16_full_size_matches_oracle():
     out = eng.cnn_explain(idx, R).cpu().numpy()
     ref = C.analyze(layers, X[idx], R)
     errs = [rel_l1(out[i], ref[i]) for i in range(4)]
-    report("cnn_vgg16", feat_rel_l1=e_feat, max_rel_l1=max(errs))
+    report("cnn_vgg16_" + prec, feat_rel_l1=e_feat, max_rel_l1=max(errs))
     assert e_feat < 1e-5
     assert max(errs) < TOL, errs
     # linearity in R (size-independent property): analyze(a*R1 + R2) = a*analyze(R1) + analyze(R2)
     out2 = eng.cnn_explain([0, 0], np.stack([2.5 * R[0] + R[3], R[3]])).cpu().numpy()
-    assert rel_l1(out2[0], 2.5 * out[0] + out[3]) < 1e-5
+    assert rel_l1(out2[0], 2.5 * out[0] + out[3]) < (1e-5 if prec == "fp32" else 5e-5)
 
 
 def test_state_errors():
