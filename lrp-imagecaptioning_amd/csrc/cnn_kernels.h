@@ -86,6 +86,16 @@ __global__ __launch_bounds__(256) void pool_gate_kernel(const float* __restrict_
   }
 }
 
+// fp32 NHWC -> split8 copy (operand format of the bf16x3 convs), 8 channels per thread
+__global__ __launch_bounds__(256) void split_copy_kernel(const float* __restrict__ x, float* __restrict__ xs, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    split8_store(v, xs + i * 8);
+  }
+}
+
 // Head of the reverse walk (KG:898-900): S_top = R_feat / safe(Z_top[img])
 __global__ __launch_bounds__(256) void top_divide_kernel(const f32x4* __restrict__ R, const f32x4* __restrict__ Ztop,
                                                          const int* __restrict__ row2img, f32x4* __restrict__ S,

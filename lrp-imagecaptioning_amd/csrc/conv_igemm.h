@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
   // ---- conv-LRP epilogues: stage the C tile through the (now idle) LDS so that the gate loads
   // and the relevance stores are 16 B per lane along the channel axis (a pixel's channels are
   // contiguous in NHWC) instead of one dword per lane.
-  if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_FWD_DUAL) {
+  if constexpr (EPI != EPI_STORE) {
     static_assert(BM * BN <= 2 * STAGE, "C tile must fit the staging LDS");
     float* Cs = smem;
 #pragma unroll
@@ -316,6 +316,23 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     const int col = n0 + c4 * CW;
     const int tn0 = m0 / HW, tp0 = m0 - tn0 * HW;
     const float invw = 1.0f / (float)a.W;
+    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+      if (col < a.N) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+#pragma unroll 4
+        for (int ps = 0; ps < BM / RPP; ++ps) {
+          const int lr = rin + ps * RPP, row = m0 + lr;
+          if (row >= a.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * 4) + bv;
+          if constexpr (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + col) = v;
+        }
+      }
+      return;
+    }
     if constexpr (EPI == EPI_FWD_DUAL) {
       // cols [0,split) -> out = relu(acc + bias)  (a_l);  cols [split,2 split) -> out2 = acc + bias  (Z+_l)
       if (col < 2 * a.split) {
@@ -378,7 +395,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     return;
   }
 
-  // ---- scalar epilogues.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- scalar epilogue (EPI_STORE, N = 54 is not a multiple of 4).  C/D map of the 32x32 MFMA:
+  // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int col_base = n0 + wn * TN * 32 + (lane & 31);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -386,17 +404,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const bool rv = row < a.M;
-      if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int col = col_base + j * 32;
-          if (rv && col < a.N) {
-            float v = acc[i][j][r] + a.bias[col];
-            if (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-            a.out[(size_t)row * a.N + col] = v;
-          }
-        }
-      } else if constexpr (EPI == EPI_STORE) {
+      if constexpr (EPI == EPI_STORE) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int col = col_base + j * 32;
@@ -424,6 +432,7 @@ template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
   if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & need)) return hipErrorInvalidValue;
+  if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.N & 3)) return hipErrorInvalidValue;
   if (PREC == PREC_BF16X3 && (a.Cin & 7)) return hipErrorInvalidValue;
   if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
   const ConvTile t = conv_pick_tile(a.N);
@@ -441,13 +450,14 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// prec = PREC_BF16X3 exists for the reverse-walk epilogues only (MUL, MUL_UP2, STORE)
+// prec = PREC_BF16X3 exists for the reverse-walk epilogues (MUL, MUL_UP2, STORE) and the forward Z+ conv (BIAS)
 inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int prec = PREC_FP32) {
   if (prec == PREC_BF16X3) {
     switch (epi) {
       case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_BF16X3>(a, st);
       case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_BF16X3>(a, st);
       case EPI_STORE: return conv_launch_epi<EPI_STORE, PREC_BF16X3>(a, st);
+      case EPI_BIAS: return conv_launch_epi<EPI_BIAS, PREC_BF16X3>(a, st);     // forward Z+ conv (fp32 out)
     }
     return hipErrorInvalidValue;
   }

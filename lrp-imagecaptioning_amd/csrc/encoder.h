@@ -20,7 +20,9 @@ struct ConvLayer {
   int cin = 0, cout = 0, H = 0, W = 0;   // H,W = resolution this conv runs at
   bool pool_after = false;
   bool have_w = false, have_b = false;
-  DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)
+  DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)          [fp32 mode, and the image layer]
+  DevBuf w_fwd_a;  // forward weights w, fp32                            [mixed mode: exact activation conv]
+  DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf bias;
@@ -40,6 +42,7 @@ struct Encoder {
   DevBuf images;           // [max_images][H][W][3]   (x of the image layer, needed by img_stencil_kernel)
   DevBuf a1;               // im2col of the image layer [max_images*H*W][64]
   DevBuf bufX, bufA, bufZ; // forward ping-pong (per call, all images)
+  DevBuf bufXs;            // split8 copy of the current conv input (mixed-precision forward)
   DevBuf feat;             // [max_images][top_h*top_w][top_c]  top activations (== CNN features)
   DevBuf ztop;             // [max_images][top...] Z+ of the top layer
   DevBuf s0, s1;           // reverse-walk ping-pong [max_tokens][biggest layer]
@@ -81,6 +84,7 @@ struct Encoder {
     LRP_TRY(bufX.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(bufA.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(bufZ.alloc(B * max_act * sizeof(float), total));
+    LRP_TRY(bufXs.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(feat.alloc(B * T.act_elems() * sizeof(float), total));
     LRP_TRY(ztop.alloc(B * T.act_elems() * sizeof(float), total));
     LRP_TRY(s0.alloc(NT * max_tok_act * sizeof(float), total));
@@ -141,6 +145,17 @@ struct Encoder {
       pack_conv_fwd(wp.data(), 9, L.cin, L.cout, L.cout, Np, pk.data());    // input >= 0: Z = x.w+ + b
       LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      {  // mixed-precision forward: w (fp32) and w+ (split8) as separate N = cout matrices
+        const int Npa = conv_npad(L.cout);
+        std::vector<float> pa((size_t)Npa * K, 0.f), pz((size_t)Npa * K, 0.f), pzs((size_t)Npa * K);
+        pack_conv_fwd(w, 9, L.cin, L.cout, 0, Npa, pa.data());
+        pack_conv_fwd(wp.data(), 9, L.cin, L.cout, 0, Npa, pz.data());
+        pack_split8(pz.data(), pz.size(), pzs.data());
+        LRP_TRY(L.w_fwd_a.alloc(pa.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_fwd_a.p, pa.data(), pa.size() * sizeof(float), hipMemcpyHostToDevice));
+        LRP_TRY(L.w_fwd_zs.alloc(pzs.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_fwd_zs.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
       const int Npb = conv_npad(L.cin), Kb = 9 * conv_cinp(L.cout);
       pk.assign((size_t)Npb * Kb, 0.f);
       pack_conv_bwd(wp.data(), 9, L.cin, L.cout, 0, pk.data());
@@ -186,6 +201,9 @@ struct Encoder {
     float* x = bufX.as<float>();
     float* a = bufA.as<float>();
     float* z = bufZ.as<float>();
+    bool mixed = prec == PREC_BF16X3;
+    for (const ConvLayer& L : layers)
+      if (L.cout & 7) mixed = false;
     for (size_t li = 0; li < layers.size(); ++li) {
       ConvLayer& L = layers[li];
       const bool top = li + 1 == layers.size();
@@ -195,11 +213,23 @@ struct Encoder {
       } else {
         ca.in = x; ca.NB = B; ca.H = L.H; ca.W = L.W; ca.Cin = L.cin; ca.CinP = conv_cinp(L.cin); ca.taps = 9;
       }
-      ca.wpk = L.w_fwd.as<float>();
-      ca.N = 2 * L.cout; ca.split = L.cout; ca.bias = L.bias.as<float>();
-      ca.out = top ? feat.as<float>() : a;
-      ca.out2 = top ? ztop.as<float>() : z;
-      LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st));
+      ca.bias = L.bias.as<float>();
+      float* a_out = top ? feat.as<float>() : a;
+      float* z_out = top ? ztop.as<float>() : z;
+      if (li > 0 && mixed) {
+        // a_l exact (it feeds the next layer), Z+_l in bf16x3 (its error stays inside gate G_l):
+        // measured on CPU emulation 4e-6 vs 3e-6 relative L1 for the all-fp32 forward.
+        ConvArgs cz = ca;
+        ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout; ca.out = a_out;
+        LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, ca, st));
+        cz.in = bufXs.as<float>(); cz.wpk = L.w_fwd_zs.as<float>(); cz.N = L.cout; cz.out = z_out;
+        LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, st, PREC_BF16X3));
+      } else {
+        ca.wpk = L.w_fwd.as<float>();
+        ca.N = 2 * L.cout; ca.split = L.cout;
+        ca.out = a_out; ca.out2 = z_out;
+        LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st));
+      }
       if (top) break;
       const size_t n = (size_t)B * L.act_elems();
       if (L.pool_after) {
@@ -212,6 +242,11 @@ struct Encoder {
                            reinterpret_cast<const f32x4*>(z), L.G.as<f32x4>(), n / 4);
         LRP_HIP_CHECK(hipGetLastError());
         float* t = x; x = a; a = t;                   // next input = a_l
+      }
+      if (mixed) {                                    // split8 copy of the next conv's input
+        const size_t n8 = (size_t)B * layers[li + 1].H * layers[li + 1].W * layers[li + 1].cin / 8;
+        hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, x, bufXs.as<float>(), n8);
+        LRP_HIP_CHECK(hipGetLastError());
       }
     }
     encoded = B;
