@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace lrp {
@@ -82,12 +83,17 @@ constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; sw
 // eight loads of a chunk issue back to back.
 __device__ __attribute__((aligned(16))) float lrp_zero_page[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the GLOBAL address space (a const page makes the select generic -> flat_load, which also counts on lgkmcnt)
 
+// waves per SIMD the register allocator must leave room for: LDS already limits a CU to
+// floor(160 KB / LDS per block) blocks of NW waves
+constexpr int conv_min_waves(int NW, int TM, int TN) { return NW == 8 ? 2 : (TM * TN >= 4 ? 2 : 3); }
+
 template <int WM, int WN, int TM, int TN, int EPI, int PREC>
-__global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int AP = BM / 32, BP = BN / 32;          // 32 rows per load pass (256 threads x 16 B)
+  constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;   // 1 KiB (8-row) DMA pieces per wave and chunk
   constexpr int STAGE = (BM + BN) * LDS_STRIDE;
-  static_assert(WM * WN == 4, "4 waves");
+  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   // ---- XCD-aware block remap: the n_tiles blocks that share an A tile get
@@ -182,14 +188,19 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
   // Two-level (blocked) summation: the MFMA is a strictly k-ordered fp32 fma chain, so a
   // K = 4608 reduction in ONE accumulator carries ~sqrt(K) ulp of round-off.  Every FLUSH
   // chunks (256 k) the running block is folded into `tot` and restarted: chains of 256 + K/256.
+  // (bf16x3: one MFMA already folds 16 k internally and the chain is K/16 long — no second level.)
   constexpr int FLUSH = 8;
-  f32x16 acc[TM][TN], tot[TM][TN];
+  constexpr bool BLOCKED = PREC == PREC_FP32;
+  f32x16 acc[TM][TN], tot[BLOCKED ? TM : 1][BLOCKED ? TN : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) {
+        acc[i][j][r] = 0.f;
+        if constexpr (BLOCKED) tot[i][j][r] = 0.f;
+      }
 
   issue_chunk(0);
   __syncthreads();                                     // (drains vmcnt: the DMA of chunk 0 has landed)
@@ -277,118 +288,129 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
     __syncthreads();
     if (more) read_frag(f0, smem + (buf ^ 1) * STAGE + a_off, smem + (buf ^ 1) * STAGE + b_off, 0);
     mfma_frag(f1);                                     // last step
-    if ((kc & (FLUSH - 1)) == FLUSH - 1) {
+    if constexpr (BLOCKED) {
+      if ((kc & (FLUSH - 1)) == FLUSH - 1) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          tot[i][j] += acc[i][j];
+          for (int j = 0; j < TN; ++j) {
+            tot[i][j] += acc[i][j];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+      }
     }
   }
   __syncthreads();                                     // LDS is reused by the epilogue
+  if constexpr (BLOCKED) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
+      for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
+  }
 
   // ---- conv-LRP epilogues: stage the C tile through the (now idle) LDS so that the gate loads
   // and the relevance stores are 16 B per lane along the channel axis (a pixel's channels are
   // contiguous in NHWC) instead of one dword per lane.
   if constexpr (EPI != EPI_STORE) {
-    static_assert(BM * BN <= 2 * STAGE, "C tile must fit the staging LDS");
+    // The C tile goes through the staging LDS in NH row slabs (a 256-row tile does not fit at once).
+    constexpr int NH = (BM * BN + 2 * STAGE - 1) / (2 * STAGE);
+    constexpr int RH = BM / NH;                         // rows per slab
+    static_assert(BM % NH == 0 && RH % (TM * 32) == 0 && RH * BN <= 2 * STAGE, "slab must hold whole wave tiles");
     float* Cs = smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) Cs[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
-      }
-    __syncthreads();
     constexpr bool SPLIT_OUT = PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2);
     constexpr int CW = SPLIT_OUT ? 8 : 4;               // channels per thread (split8 output is written per group)
-    constexpr int C4 = BN / CW, RPP = 256 / C4;
+    constexpr int C4 = BN / CW, RPP = NT / C4;
     const int c4 = tid % C4, rin = tid / C4;
     const int col = n0 + c4 * CW;
     const int tn0 = m0 / HW, tp0 = m0 - tn0 * HW;
     const float invw = 1.0f / (float)a.W;
-    if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
-      if (col < a.N) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
-#pragma unroll 4
-        for (int ps = 0; ps < BM / RPP; ++ps) {
-          const int lr = rin + ps * RPP, row = m0 + lr;
-          if (row >= a.M) break;
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * 4) + bv;
-          if constexpr (EPI == EPI_BIAS_RELU) {
+#pragma unroll 1
+    for (int hf = 0; hf < NH; ++hf) {
+      if (hf) __syncthreads();                          // previous slab fully consumed
+      if ((wm * TM * 32) / RH == hf) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int lr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) - hf * RH;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) Cs[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
           }
-          *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + col) = v;
-        }
       }
-      return;
-    }
-    if constexpr (EPI == EPI_FWD_DUAL) {
-      // cols [0,split) -> out = relu(acc + bias)  (a_l);  cols [split,2 split) -> out2 = acc + bias  (Z+_l)
-      if (col < 2 * a.split) {
-        const bool isz = col >= a.split;
-        const int c = isz ? col - a.split : col;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
-        float* dst = (isz ? a.out2 : a.out) + c;
+      __syncthreads();
+      if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
+        if (col < a.N) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
 #pragma unroll 4
-        for (int ps = 0; ps < BM / RPP; ++ps) {
-          const int lr = rin + ps * RPP, row = m0 + lr;
-          if (row >= a.M) break;
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * 4) + bv;
-          if (!isz) {
+          for (int ps = 0; ps < RH / RPP; ++ps) {
+            const int ll = rin + ps * RPP, row = m0 + hf * RH + ll;
+            if (row >= a.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
+            if constexpr (EPI == EPI_BIAS_RELU) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + col) = v;
           }
-          *reinterpret_cast<f32x4*>(dst + (size_t)row * a.split) = v;
         }
-      }
-      return;
-    }
-    if (col < a.N) {
+      } else if constexpr (EPI == EPI_FWD_DUAL) {
+        // cols [0,split) -> out = relu(acc + bias)  (a_l);  cols [split,2 split) -> out2 = acc + bias  (Z+_l)
+        if (col < 2 * a.split) {
+          const bool isz = col >= a.split;
+          const int c = isz ? col - a.split : col;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
+          float* dst = (isz ? a.out2 : a.out) + c;
 #pragma unroll 4
-      for (int ps = 0; ps < BM / RPP; ++ps) {
-        const int lr = rin + ps * RPP, row = m0 + lr;
-        if (row >= a.M) break;
-        float v[CW];
+          for (int ps = 0; ps < RH / RPP; ++ps) {
+            const int ll = rin + ps * RPP, row = m0 + hf * RH + ll;
+            if (row >= a.M) break;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
+            if (!isz) {
 #pragma unroll
-        for (int q4 = 0; q4 < CW / 4; ++q4)
-          *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + lr * BN + c4 * CW + 4 * q4);
-        int n = tn0, pix = tp0 + lr;
-        while (pix >= HW) { pix -= HW; ++n; }
-        const int img = a.row2img ? a.row2img[n] : n;
-        // out = acc * gate (fp32), stored as fp32 or re-split into [hi8 | lo8] for the next layer's MFMAs
-        auto emit = [&](const float* gsrc, float* dst) {
-          float r[CW];
-#pragma unroll
-          for (int q4 = 0; q4 < CW / 4; ++q4) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 4 * q4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) r[4 * q4 + q] = v[4 * q4 + q] * g[q];
+              for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(dst + (size_t)row * a.split) = v;
           }
-          if constexpr (SPLIT_OUT) split8_store(r, dst);
-          else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
-        };
-        if constexpr (EPI == EPI_MUL) {
-          emit(a.aux + ((size_t)img * HW + pix) * a.N + col, a.out + (size_t)row * a.N + col);
-        } else {
-          int h = (int)(((float)pix + 0.5f) * invw);
-          int w = pix - h * a.W;
-          if (w < 0) { --h; w += a.W; } else if (w >= a.W) { ++h; w -= a.W; }
-          const int W2 = 2 * a.W, H2 = 2 * a.H;
+        }
+      } else {
+        if (col < a.N) {
+#pragma unroll 4
+          for (int ps = 0; ps < RH / RPP; ++ps) {
+            const int ll = rin + ps * RPP, lr = hf * RH + ll, row = m0 + lr;
+            if (row >= a.M) break;
+            float v[CW];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            emit(a.aux + (((size_t)img * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col,
-                 a.out + (((size_t)n * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col);
+            for (int q4 = 0; q4 < CW / 4; ++q4)
+              *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * CW + 4 * q4);
+            int n = tn0, pix = tp0 + lr;
+            while (pix >= HW) { pix -= HW; ++n; }
+            const int img = a.row2img ? a.row2img[n] : n;
+            // out = acc * gate (fp32), stored as fp32 or re-split into [hi8 | lo8] for the next layer's MFMAs
+            auto emit = [&](const float* gsrc, float* dst) {
+              float r[CW];
+#pragma unroll
+              for (int q4 = 0; q4 < CW / 4; ++q4) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 4 * q4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[4 * q4 + q] = v[4 * q4 + q] * g[q];
+              }
+              if constexpr (SPLIT_OUT) split8_store(r, dst);
+              else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+            };
+            if constexpr (EPI == EPI_MUL) {
+              emit(a.aux + ((size_t)img * HW + pix) * a.N + col, a.out + (size_t)row * a.N + col);
+            } else {
+              int h = (int)(((float)pix + 0.5f) * invw);
+              int w = pix - h * a.W;
+              if (w < 0) { --h; w += a.W; } else if (w >= a.W) { ++h; w -= a.W; }
+              const int W2 = 2 * a.W, H2 = 2 * a.H;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                emit(a.aux + (((size_t)img * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col,
+                     a.out + (((size_t)n * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col);
+            }
+          }
         }
       }
     }
@@ -416,9 +438,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 4 ? 2 : 3)) void conv_igemm_kernel
 }
 
 // tile configurations: (WM,WN,TM,TN) -> BM x BN
-//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)            64 KB LDS, 2 blocks/CU
-//   n64   : 2,2,2,1 -> 128 x  64   (N == 64 layers)      48 KB LDS, 3 blocks/CU
+//   big   : 2,2,2,2 -> 128 x 128   (N >= 128)                 64 KB LDS, 2 blocks/CU   [fp32]
+//   n64   : 2,2,2,1 -> 128 x  64   (N == 64 layers)           48 KB LDS, 3 blocks/CU
 //   n32   : 4,1,1,1 -> 128 x  32   (N <= 32: tiny test nets)  40 KB LDS
+//   w256  : 2,4,4,2 -> 256 x 256   8 waves, 128 KB LDS, 1 block/CU   [bf16x3, N % 256 == 0]
+//   w128  : 4,2,2,2 -> 256 x 128   8 waves,  96 KB LDS, 1 block/CU   [bf16x3, N % 128 == 0]
+// bf16x3 spends 5.3x fewer matrix cycles per byte staged, so its limiter is the L2 -> LDS path
+// (~43 GB/s per CU at 128 x 128): the 8-wave tiles stage 25 % / 50 % fewer bytes per FLOP.
 struct ConvTile { int BM, BN; };
 inline ConvTile conv_pick_tile(int N) {
   if (N > 64) return {128, 128};
@@ -428,6 +454,12 @@ inline ConvTile conv_pick_tile(int N) {
 inline int conv_npad(int N) { ConvTile t = conv_pick_tile(N); return (N + t.BN - 1) / t.BN * t.BN; }
 inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
 
+// experiment knob (env LRP_CONV_TILE): 0 = auto, 1 = never use the 8-wave tiles, 128 = cap them at 256 x 128
+inline int conv_tile_override() {
+  static const int v = [] { const char* e = getenv("LRP_CONV_TILE"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
@@ -435,12 +467,34 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.N & 3)) return hipErrorInvalidValue;
   if (PREC == PREC_BF16X3 && (a.Cin & 7)) return hipErrorInvalidValue;
   if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
-  const ConvTile t = conv_pick_tile(a.N);
+  ConvTile t = conv_pick_tile(a.N);
+  int wide = 0;
+  if (PREC == PREC_BF16X3 && a.N >= 128 && (a.N % 128) == 0) {
+    wide = (a.N % 256) == 0 ? 256 : 128;
+    if (wide == 128) wide = 0;                           // measured: 256 x 128 loses to two 128 x 128 blocks per CU
+    if (conv_tile_override() == 128 && (a.N % 128) == 0) wide = 128;
+    if (conv_tile_override() == 1) wide = 0;
+    // one 8-wave block per CU: only worth it when the grid still fills the chip ~1.5 times over
+    const long mrows = (long)a.NB * a.H * a.W;
+    if (wide && ((mrows + 255) / 256) * (a.N / wide) < 400) wide = 0;
+    if (wide) t = {256, wide};
+  }
   a.M = a.NB * a.H * a.W;
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
-  const dim3 grid(a.m_tiles * a.n_tiles), block(256);
+  const dim3 grid(a.m_tiles * a.n_tiles);
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if constexpr (PREC == PREC_BF16X3) {
+    if (wide == 256) {
+      hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC>), grid, dim3(512), 0, st, a);
+      return hipGetLastError();
+    }
+    if (wide == 128) {
+      hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, EPI, PREC>), grid, dim3(512), 0, st, a);
+      return hipGetLastError();
+    }
+  }
+  const dim3 block(256);
   if (t.BN == 128)
     hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC>), grid, block, 0, st, a);
   else if (t.BN == 64)
