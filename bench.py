@@ -154,7 +154,7 @@ def main():
     eng.profile_enable(False)
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
-    traffic, traffic_src = pmc_traffic_per_launch()
+    traffic, traffic_src = pmc_traffic_per_launch(args.precision)
     if rank == 0:
         heatmaps = world * B * T * args.steps
         if args.precision == "bf16x3":
@@ -191,7 +191,7 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(precision="bf16x3"):
     """rocprofv3 cannot run inside this process: the per-launch fabric traffic of the reverse-walk
     conv launches comes from the newest committed PMC summary (profiles/run_profile.sh: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
@@ -203,8 +203,8 @@ def pmc_traffic_per_launch():
     tot = n = 0.0
     for k, v in d.items():
         # reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5)
-        m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+)>", k)
-        if m and m.group(1) in ("2", "3", "5"):
+        m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)>", k)
+        if m and m.group(1) in ("2", "3", "5") and m.group(2) == ("1" if precision == "bf16x3" else "0"):
             if "fetch_bytes_per_launch_x2corr" in v and "write_bytes_per_launch" in v:
                 tot += (v["fetch_bytes_per_launch_x2corr"] + v["write_bytes_per_launch"]) * v["launches"]
                 n += v["launches"]
