@@ -74,6 +74,7 @@ struct ConvArgs {
   const float* aux;
   const int* row2img;  // per input image-slot n -> cache slot (nullptr = identity)
   int split;
+  int out_plain;       // bf16x3 MUL epilogues: 1 = write fp32 instead of re-splitting (last GEMM of a chain)
 };
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -395,8 +396,16 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
 #pragma unroll
                 for (int q = 0; q < 4; ++q) r[4 * q4 + q] = v[4 * q4 + q] * g[q];
               }
-              if constexpr (SPLIT_OUT) split8_store(r, dst);
-              else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+              if constexpr (SPLIT_OUT) {
+                if (a.out_plain) {
+                  *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+                  *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(r + 4);
+                } else {
+                  split8_store(r, dst);
+                }
+              } else {
+                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+              }
             };
             if constexpr (EPI == EPI_MUL) {
               emit(a.aux + ((size_t)img * HW + pix) * a.N + col, a.out + (size_t)row * a.N + col);

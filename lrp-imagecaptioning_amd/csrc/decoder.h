@@ -38,7 +38,8 @@ struct Decoder {
   int B_cur = 0;
   bool have_forward = false;
   // explain scratch
-  DevBuf rctx, ravg;
+  DevBuf rctx, ravg, tailA, w_ifT_pk, w_ifT_pks;
+  int prec = PREC_BF16X3;   // arithmetic of the tail GEMM (follows lrp_set_precision)
   // grid-TD only
   DevBuf Wcat2, bcat2, Wg2T, xh1d, xh2d, zg1d, zg2d, hprojd, sprojd, h2u, rho;
 
@@ -96,6 +97,7 @@ struct Decoder {
     LRP_TRY(u.alloc(B * Tm * H * 8, total));
     LRP_TRY(cap_dev.alloc(B * Tm * sizeof(int), total));
     LRP_TRY(rctx.alloc((size_t)NT_max * H * 8, total));
+    if (kind == LRP_DEC_ADAPTIVE && (H & 7) == 0) LRP_TRY(tailA.alloc((size_t)NT_max * L * H * 4, total));
     LRP_TRY(ravg.alloc((size_t)NT_max * D * 8, total));
     cap_host.assign(B * Tm, eos);
     len_host.assign(B, 0);
@@ -183,6 +185,14 @@ struct Decoder {
     for (int d = 0; d < D; ++d)
       for (int j = 0; j < H; ++j) pk[(size_t)j * D + d] = Wif[(size_t)d * H + j];
     LRP_TRY(upload(WifT, pk, total));
+    {  // the same matrix as the B operand of the MFMA tail GEMM: out[m][d] = sum_j A[m][j] * W_if[d][j]
+      const int Np = conv_npad(D), K = conv_cinp(H);
+      std::vector<float> g((size_t)Np * K, 0.f), gs((size_t)Np * K);
+      pack_conv_fwd(pk.data(), 1, H, D, 0, Np, g.data());          // pk = WifT [j][d] == "w[ci=j][co=d]"
+      pack_split8(g.data(), g.size(), gs.data());
+      LRP_TRY(upload(w_ifT_pk, g, total));
+      LRP_TRY(upload(w_ifT_pks, gs, total));
+    }
     return LRP_OK;
   }
 
@@ -433,6 +443,24 @@ struct Decoder {
     const size_t lds = (size_t)(2 * H + std::max(H, E) + E + 8) * sizeof(double);
     hipLaunchKernelGGL(dec_explain_adaptive_kernel, dim3(n), dim3(256), lds, st, a);
     LRP_HIP_CHECK(hipGetLastError());
+    if (tailA.p && (D & 7) == 0) {
+      // tail on the matrix cores: A operand -> 1-tap conv_igemm with the F-multiply as its gate -> mean-pool share
+      const bool split = prec == PREC_BF16X3;
+      TailAArgs aa{};
+      aa.img_idx = img_dev; aa.tpos = t_dev; aa.vfeat = vfeat.as<float>(); aa.ipre = ipre.as<double>(); aa.att = a.att;
+      aa.rho = a.rctx; aa.A = tailA.as<float>(); aa.Tm = Tm; aa.L = L; aa.H = H; aa.split = split;
+      hipLaunchKernelGGL(tail_a_kernel, dim3((L * (H / 8) + 255) / 256, n), dim3(256), 0, st, aa);
+      LRP_HIP_CHECK(hipGetLastError());
+      ConvArgs cg{};
+      cg.in = tailA.as<float>(); cg.NB = n; cg.H = L; cg.W = 1; cg.Cin = H; cg.CinP = conv_cinp(H); cg.taps = 1;
+      cg.wpk = split ? w_ifT_pks.as<float>() : w_ifT_pk.as<float>(); cg.N = D; cg.aux = feat_dev; cg.row2img = img_dev;
+      cg.out = R_feat_dev; cg.out_plain = 1;
+      LRP_HIP_CHECK(conv_launch(EPI_MUL, cg, st, split ? PREC_BF16X3 : PREC_FP32));
+      hipLaunchKernelGGL(tail_finish_kernel, dim3((L * D + 255) / 256 > 64 ? 64 : (L * D + 255) / 256, n), dim3(256), 0, st,
+                         img_dev, feat_dev, a.avg, a.ravg, R_feat_dev, L, D);
+      LRP_HIP_CHECK(hipGetLastError());
+      return LRP_OK;
+    }
     TailArgs ta{};
     ta.img_idx = img_dev; ta.tpos = t_dev; ta.F = feat_dev; ta.vfeat = vfeat.as<float>(); ta.ipre = ipre.as<double>();
     ta.att = a.att;

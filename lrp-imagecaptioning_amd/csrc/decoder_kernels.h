@@ -493,4 +493,59 @@ __global__ __launch_bounds__(256) void dec_tail_kernel(TailArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Tail on the matrix cores (replaces dec_tail_kernel's float64 VALU GEMM): the (L x H).(H x D) product per
+// token runs on conv_igemm (1-tap mode) with the A operand materialised once by tail_a_kernel and the
+// F-multiply fused as the EPI_MUL gate; tail_finish_kernel adds the mean-pool share.  The reference rounds
+// r_V and R_feat to float32 anyway (E:554-555); the GEMM itself now rounds at fp32 / split-bf16 level
+// (~1e-6 relative on R_feat, bar 1e-4).
+//   A[n][l][j] = float32( float32( relu(if_pre[l][j]) * alpha_l * rho_j ) / stab(if_pre[l][j]) )
+// ------------------------------------------------------------------------------------------
+struct TailAArgs {
+  const int* img_idx; const int* tpos;
+  const float* vfeat; const double* ipre; const float* att; const double* rho;
+  float* A;                 // [n][L][H] fp32, or split8 when `split`
+  int Tm, L, H, split;
+};
+
+__global__ __launch_bounds__(256) void tail_a_kernel(TailAArgs a) {
+  const int n = blockIdx.y;
+  const int b = a.img_idx[n], t = a.tpos[n], S = a.Tm + 1;
+  const int H8 = a.H >> 3;
+  const size_t rowt = (size_t)b * S + t;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.L * H8; i += gridDim.x * 256) {
+    const int l = i / H8, j0 = (i - l * H8) << 3;
+    const size_t o = ((size_t)b * a.L + l) * a.H + j0;
+    const double al = (double)a.att[rowt * a.L + l];
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float rV = (float)((double)a.vfeat[o + q] * al * a.rho[(size_t)n * a.H + j0 + q]);
+      v[q] = (float)((double)rV * a.ipre[o + q]);
+    }
+    float* dst = a.A + ((size_t)n * a.L + l) * a.H + j0;
+    if (a.split) {
+      split8_store(v, dst);
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(v);
+      *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(v + 4);
+    }
+  }
+}
+
+// R_feat[n][l][d] = float32( float32( F/L / stab(avg) * r_avg ) + R_feat[n][l][d] )      (E:642-647 + E:654-659)
+__global__ __launch_bounds__(256) void tail_finish_kernel(const int* __restrict__ img_idx, const float* __restrict__ F,
+                                                          const float* __restrict__ avg, const double* __restrict__ ravg,
+                                                          float* __restrict__ R, int L, int D) {
+  const int n = blockIdx.y, b = img_idx[n];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L * D; i += gridDim.x * 256) {
+    const int d = i % D;
+    const float f = F[(size_t)b * L * D + i];
+    const float fl = f / (float)L;
+    const float first = (float)((double)fl / stab((double)avg[(size_t)b * D + d]) * ravg[(size_t)n * D + d]);
+    float* r = R + (size_t)n * L * D + i;
+    *r = (float)((double)first + (double)*r);
+  }
+}
+
 }  // namespace lrp
