@@ -111,3 +111,38 @@ def images(rs, B, H=224, W=224):
 
 def captions(rs, B, T, V):
     return [[int(c) for c in rs.randint(3, V + 1, size=T)] + [1] for _ in range(B)]
+
+
+# --------------------------------------------------------------------------- ResNet (config 4)
+RESNET101_STACKS = ((64, 3), (128, 4), (256, 23), (512, 3))
+
+
+def resnet_conv_list(stacks=RESNET101_STACKS, stem=64):
+    """(name, k, cin, cout, stride) of every conv in forward order — ResNet-v1 bottleneck
+    (keras_applications.resnet_common: ResNet101 -> stack1 -> block1)."""
+    out = [("conv1", 7, 3, stem, 2)]
+    cin = stem
+    for i, (f, n) in enumerate(stacks):
+        for b in range(1, n + 1):
+            p = "conv%d_block%d" % (i + 2, b)
+            stride = (1 if i == 0 else 2) if b == 1 else 1
+            if b == 1:
+                out.append((p + "_0", 1, cin, 4 * f, stride))
+            out.append((p + "_1", 1, cin, f, stride))
+            out.append((p + "_2", 3, f, f, 1))
+            out.append((p + "_3", 1, f, 4 * f, 1))
+            cin = 4 * f
+    return out
+
+
+def resnet_weights(rs, stacks=RESNET101_STACKS, stem=64, bias_std=0.05):
+    """He-normal kernels, mixed-sign conv biases, non-trivial BN statistics (ImageNet weights cannot be fetched)."""
+    w = {}
+    for name, k, cin, cout, _ in resnet_conv_list(stacks, stem):
+        w[name + "_conv_W"] = (rs.standard_normal((k, k, cin, cout)) * np.sqrt(2.0 / (k * k * cin))).astype(np.float32)
+        w[name + "_conv_b"] = (rs.standard_normal((cout,)) * bias_std).astype(np.float32)
+        w[name + "_bn_gamma"] = rs.uniform(0.6, 1.4, size=cout).astype(np.float32)
+        w[name + "_bn_beta"] = (rs.standard_normal(cout) * 0.2).astype(np.float32)
+        w[name + "_bn_mean"] = (rs.standard_normal(cout) * 0.3).astype(np.float32)
+        w[name + "_bn_var"] = rs.uniform(0.5, 1.5, size=cout).astype(np.float32)
+    return w
