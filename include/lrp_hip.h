@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 1
+#define LRP_ABI_VERSION 2
 
 enum {
   LRP_OK = 0,
@@ -50,6 +50,8 @@ enum { LRP_DEC_ADAPTIVE = 0,   /* ExplainImgCaptioningAdaptiveAttention  E:260-6
 
 enum { LRP_EXPLAIN_SEQUENCE = 0,   /* _explain_lstm_single_word_sequence  E:537-666 / E:1180-1321 */
        LRP_EXPLAIN_SINGLE_STEP = 1 /* _explain_lstm_single_word           E:438-535 (adaptive)    */ };
+
+enum { LRP_ENC_VGG = 0, LRP_ENC_RESNET = 1 };
 
 #define LRP_MAX_CONV 32
 
@@ -73,6 +75,16 @@ typedef struct lrp_config {
   int32_t max_tokens;           /* capacity of one explain call (heat-maps)             */
   int32_t max_caption_len;      /* longest caption incl. EOS (config.py:34 -> 20+1)     */
   int32_t sos_id, eos_id;       /* tokenizer ids (1-based); model column = id-1 (E:443) */
+  /* ABI v2: encoder selection.  LRP_ENC_VGG uses the conv_* table above.  LRP_ENC_RESNET builds the Keras
+   * ResNet-v1 bottleneck encoder (keras_applications.resnet_common; ResNet-101 = stem 64, filters 64/128/256/512,
+   * blocks 3/4/23/3) cut after the last block's ReLU (conv5_block3_out, config.py:41-45); weights are named
+   * "<unit>_conv_W" HWIO, "<unit>_conv_b", "<unit>_bn_gamma|beta|mean|var" with <unit> = "conv1" or
+   * "conv<s>_block<b>_<0|1|2|3>" (0 = projection shortcut).  The conv_* table is ignored. */
+  int32_t encoder;              /* LRP_ENC_VGG / LRP_ENC_RESNET                         */
+  int32_t resnet_stem;          /* 64                                                   */
+  int32_t resnet_n_stacks;      /* 4                                                    */
+  int32_t resnet_filters[8];    /* 64,128,256,512                                       */
+  int32_t resnet_blocks[8];     /* 3,4,23,3                                             */
 } lrp_config;
 
 typedef struct lrp_handle lrp_handle;

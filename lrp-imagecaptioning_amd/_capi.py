@@ -7,9 +7,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrp_hip.so")
 
-LRP_ABI_VERSION = 1
+LRP_ABI_VERSION = 2
 LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANGE, LRP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
+LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
 LRP_EXPLAIN_SEQUENCE, LRP_EXPLAIN_SINGLE_STEP = 0, 1
 LRP_PREC_FP32, LRP_PREC_BF16X3 = 0, 1
 LRP_MAX_CONV = 32
@@ -24,6 +25,8 @@ class LrpConfig(C.Structure):
         ("L", C.c_int32), ("D", C.c_int32), ("H", C.c_int32), ("E", C.c_int32), ("V", C.c_int32),
         ("max_images", C.c_int32), ("max_tokens", C.c_int32), ("max_caption_len", C.c_int32),
         ("sos_id", C.c_int32), ("eos_id", C.c_int32),
+        ("encoder", C.c_int32), ("resnet_stem", C.c_int32), ("resnet_n_stacks", C.c_int32),
+        ("resnet_filters", C.c_int32 * 8), ("resnet_blocks", C.c_int32 * 8),
     ]
 
 

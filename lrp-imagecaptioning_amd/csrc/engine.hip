@@ -12,6 +12,7 @@
 #include "conv_igemm.h"
 #include "decoder.h"
 #include "encoder.h"
+#include "resnet_encoder.h"
 #include "rules_kernels.h"
 #include "score_kernels.h"
 
@@ -27,8 +28,13 @@ using namespace lrp;
 struct lrp_handle {
   lrp_config cfg;
   int64_t ws_bytes = 0;
-  Encoder enc;
+  Encoder enc;             // VGG-style encoder (LRP_ENC_VGG)
+  ResNetEncoder rn;        // ResNet bottleneck encoder (LRP_ENC_RESNET)
+  bool resnet = false;
   Decoder dec;
+  float* feat() { return resnet ? rn.feat.as<float>() : enc.feat.as<float>(); }
+  int& encoded() { return resnet ? rn.encoded : enc.encoded; }
+  bool& features_only() { return resnet ? rn.features_only : enc.features_only; }
   DevBuf idx_dev;          // staged (img_idx | t) for the current explain call
   DevBuf rfeat_tmp;        // R_feat when the caller does not want it back
   int* idx_pinned = nullptr;
@@ -55,7 +61,12 @@ int lrp_create(const lrp_config* cfg, lrp_handle** out) {
   LRP_HIP_CHECK(hipSetDevice(cfg->device));
   lrp_handle* h = new lrp_handle();
   h->cfg = *cfg;
-  int rc = h->enc.init(*cfg, &h->ws_bytes);
+  if (cfg->encoder != LRP_ENC_VGG && cfg->encoder != LRP_ENC_RESNET) {
+    delete h;
+    return fail(LRP_ERR_UNSUPPORTED, "unknown encoder kind %d", cfg->encoder);
+  }
+  h->resnet = cfg->encoder == LRP_ENC_RESNET;
+  int rc = h->resnet ? h->rn.init(*cfg, &h->ws_bytes) : h->enc.init(*cfg, &h->ws_bytes);
   if (rc == LRP_OK) rc = h->dec.init(*cfg, &h->ws_bytes);
   if (rc == LRP_OK) rc = h->idx_dev.alloc((size_t)cfg->max_tokens * 2 * sizeof(int), &h->ws_bytes);
   if (rc == LRP_OK) rc = h->rfeat_tmp.alloc((size_t)cfg->max_tokens * cfg->L * cfg->D * sizeof(float), &h->ws_bytes);
@@ -83,6 +94,11 @@ static int set_weight_host(lrp_handle* h, const char* name, const float* data, i
   if (!h || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(LRP_ERR_INVALID, "bad lrp_set_weight arguments");
   LRP_HIP_CHECK(hipSetDevice(h->cfg.device));
   const std::string nm(name);
+  if (h->resnet) {
+    const int rc = h->rn.set_weight(nm, data, ndim, shape, &h->ws_bytes);
+    if (rc != 1) return rc;                       // 1 = not an encoder weight
+    return h->dec.set_weight(nm, data, ndim, shape, &h->ws_bytes);
+  }
   if (nm.size() > 2 && (nm.compare(nm.size() - 2, 2, "_W") == 0 || nm.compare(nm.size() - 2, 2, "_b") == 0)) {
     const int li = h->enc.find_layer(nm.substr(0, nm.size() - 2));
     if (li >= 0) {
@@ -116,32 +132,32 @@ int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev, i
 
 int lrp_encode_images(lrp_handle* h, const float* images_dev, int32_t B, void* stream) {
   if (!h || !images_dev) return fail(LRP_ERR_INVALID, "null argument");
-  LRP_TRY(h->enc.encode(images_dev, B, S(stream)));
+  LRP_TRY(h->resnet ? h->rn.encode(images_dev, B, S(stream)) : h->enc.encode(images_dev, B, S(stream)));
   return h->dec.on_new_features(B);
 }
 
 int lrp_set_features(lrp_handle* h, const float* features_dev, int32_t B, void* stream) {
   if (!h || !features_dev) return fail(LRP_ERR_INVALID, "null argument");
   if (B < 1 || B > h->cfg.max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, h->cfg.max_images);
-  LRP_HIP_CHECK(hipMemcpyAsync(h->enc.feat.p, features_dev, (size_t)B * h->cfg.L * h->cfg.D * sizeof(float),
+  LRP_HIP_CHECK(hipMemcpyAsync(h->feat(), features_dev, (size_t)B * h->cfg.L * h->cfg.D * sizeof(float),
                                hipMemcpyDeviceToDevice, S(stream)));
-  h->enc.encoded = B;
-  h->enc.features_only = true;
+  h->encoded() = B;
+  h->features_only() = true;
   return h->dec.on_new_features(B);
 }
 
 int lrp_get_features(lrp_handle* h, float* features_dev, int32_t B, void* stream) {
   if (!h || !features_dev) return fail(LRP_ERR_INVALID, "null argument");
-  if (B < 1 || B > h->enc.encoded) return fail(LRP_ERR_STATE, "only %d images are cached", h->enc.encoded);
-  LRP_HIP_CHECK(hipMemcpyAsync(features_dev, h->enc.feat.p, (size_t)B * h->cfg.L * h->cfg.D * sizeof(float),
+  if (B < 1 || B > h->encoded()) return fail(LRP_ERR_STATE, "only %d images are cached", h->encoded());
+  LRP_HIP_CHECK(hipMemcpyAsync(features_dev, h->feat(), (size_t)B * h->cfg.L * h->cfg.D * sizeof(float),
                                hipMemcpyDeviceToDevice, S(stream)));
   return LRP_OK;
 }
 
 int lrp_decoder_forward(lrp_handle* h, const int32_t* captions_host, const int32_t* lengths_host, int32_t B, void* stream) {
   if (!h || !captions_host || !lengths_host) return fail(LRP_ERR_INVALID, "null argument");
-  if (B < 1 || B > h->enc.encoded) return fail(LRP_ERR_STATE, "B=%d but %d images have features cached", B, h->enc.encoded);
-  return h->dec.forward(h->enc.feat.as<float>(), captions_host, lengths_host, B, S(stream));
+  if (B < 1 || B > h->encoded()) return fail(LRP_ERR_STATE, "B=%d but %d images have features cached", B, h->encoded());
+  return h->dec.forward(h->feat(), captions_host, lengths_host, B, S(stream));
 }
 
 int lrp_read_state(lrp_handle* h, const char* name, void* out_dev, size_t out_bytes, void* stream) {
@@ -154,8 +170,8 @@ static int stage_indices(lrp_handle* h, int n, const int32_t* img_idx, const int
   if (n < 1 || n > h->cfg.max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, h->cfg.max_tokens);
   LRP_HIP_CHECK(hipStreamSynchronize(st));      // the pinned staging buffer may still be in flight
   for (int i = 0; i < n; ++i) {
-    if (img_idx[i] < 0 || img_idx[i] >= h->enc.encoded)
-      return fail(LRP_ERR_INVALID, "img_idx[%d]=%d outside the %d cached images", i, img_idx[i], h->enc.encoded);
+    if (img_idx[i] < 0 || img_idx[i] >= h->encoded())
+      return fail(LRP_ERR_INVALID, "img_idx[%d]=%d outside the %d cached images", i, img_idx[i], h->encoded());
     h->idx_pinned[i] = img_idx[i];
     if (need_t) {
       LRP_TRY(h->dec.check_token(img_idx[i], t[i]));
@@ -171,14 +187,15 @@ int lrp_decoder_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, c
   if (!h || !img_idx_host || !t_host || !R_feat_dev) return fail(LRP_ERR_INVALID, "null argument");
   LRP_TRY(stage_indices(h, n, img_idx_host, t_host, true, S(stream)));
   return h->dec.explain(n, h->idx_dev.as<int>(), h->idx_dev.as<int>() + n, img_idx_host, t_host, variant,
-                        h->enc.feat.as<float>(), R_feat_dev, att_dev, r_words_dev, S(stream));
+                        h->feat(), R_feat_dev, att_dev, r_words_dev, S(stream));
 }
 
 int lrp_cnn_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const float* R_feat_dev, float* R_img_dev,
                     void* stream) {
   if (!h || !img_idx_host || !R_feat_dev || !R_img_dev) return fail(LRP_ERR_INVALID, "null argument");
-  if (h->enc.encoded < 1 || h->enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before lrp_cnn_explain");
+  if (h->encoded() < 1 || h->features_only()) return fail(LRP_ERR_STATE, "lrp_encode_images must run before lrp_cnn_explain");
   LRP_TRY(stage_indices(h, n, img_idx_host, nullptr, false, S(stream)));
+  if (h->resnet) return h->rn.explain(n, h->idx_dev.as<int>(), R_feat_dev, R_img_dev, S(stream));
   return h->enc.explain(n, h->idx_dev.as<int>(), R_feat_dev, R_img_dev, S(stream));
 }
 
@@ -188,7 +205,8 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host, co
   LRP_TRY(stage_indices(h, n, img_idx_host, t_host, true, S(stream)));
   float* rf = R_feat_dev ? R_feat_dev : h->rfeat_tmp.as<float>();
   LRP_TRY(h->dec.explain(n, h->idx_dev.as<int>(), h->idx_dev.as<int>() + n, img_idx_host, t_host, variant,
-                         h->enc.feat.as<float>(), rf, att_dev, r_words_dev, S(stream)));
+                         h->feat(), rf, att_dev, r_words_dev, S(stream)));
+  if (h->resnet) return h->rn.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
   return h->enc.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
 }
 
@@ -203,6 +221,7 @@ int lrp_set_precision(lrp_handle* h, int32_t mode) {
 int lrp_profile_enable(lrp_handle* h, int32_t on) {
   if (!h) return fail(LRP_ERR_INVALID, "null handle");
   h->enc.profile = on != 0;
+  h->rn.profile = on != 0;
   return LRP_OK;
 }
 
@@ -213,7 +232,7 @@ int lrp_profile_query(lrp_handle* h, int64_t* n_launches, double* total_ms, doub
 
 int lrp_profile_records(lrp_handle* h, int32_t cap, double* ms_out, double* flop_out, int32_t* n_out) {
   if (!h || !ms_out || !flop_out || !n_out || cap < 0) return fail(LRP_ERR_INVALID, "bad lrp_profile_records arguments");
-  return h->enc.profile_records(cap, ms_out, flop_out, n_out);
+  return h->resnet ? h->rn.profile_records(cap, ms_out, flop_out, n_out) : h->enc.profile_records(cap, ms_out, flop_out, n_out);
 }
 
 int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias_host, const float* aux_dev, float* out_dev,

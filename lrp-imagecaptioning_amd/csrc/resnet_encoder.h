@@ -1,0 +1,372 @@
+// resnet_encoder.h — host-side orchestration of the CNN half for the ResNet-101 encoder (BASELINE config 4:
+// grid-TD decoder + ResNet-101 cut at conv5_block3_out, LRP-alpha1beta0).  Same contract as Encoder (encoder.h):
+//   encode():  one forward per IMAGE, caching per conv unit the gate that combines the BatchNorm reverse rule
+//              (RA:197-257) with the alpha1beta0 denominator (RR:274-322) and per block the Add-rule factors (RA:260-286)
+//   explain(): one reverse walk per TOKEN: three (four) convs per bottleneck block on conv_igemm + streaming kernels
+// The algorithm is oracle/resnet_lrp_ref.analyze_cached, which equals the literal iNNvestigate walk to 1e-10.
+// This path runs in exact fp32 (PREC_FP32) throughout.
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "conv_igemm.h"
+#include "resnet_kernels.h"
+
+namespace lrp {
+
+constexpr float RN_BN_EPS = 1.001e-5f;
+
+struct RnUnit {            // conv + BN
+  std::string name;
+  int k = 1, cin = 0, cout = 0, stride = 1;
+  int Hin = 0, Win = 0, Hout = 0, Wout = 0;
+  bool relu = false;
+  bool have[6] = {false, false, false, false, false, false};   // W b gamma beta mean var
+  DevBuf w_a, w_z, w_b, bias, gamma, beta, mean, var;
+  DevBuf gate;             // [B][Hout][Wout][cout]: act*Q (relu units) or Q (pre-Add units)
+  size_t out_elems() const { return (size_t)Hout * Wout * cout; }
+  size_t in_elems() const { return (size_t)Hin * Win * cin; }
+};
+
+struct RnBlock {
+  int u0 = -1, u1 = -1, u2 = -1, u3 = -1;     // unit indices (u0 = projection shortcut or -1)
+  int stride = 1, cin = 0, f = 0, Hin = 0, Win = 0, H = 0, W = 0;
+  DevBuf t_in;             // [B][Hin][Win][cin] block input (what relevance is multiplied with at the fork)
+  DevBuf t_sub;            // [B][H][W][cin] stride-2 gather of t_in (first block of stacks 3..5)
+  DevBuf GA, GS;           // [B][H][W][4f]: fA*Q3 and fS (identity) / fS*Q0 (projection)
+};
+
+struct ResNetEncoder {
+  int img_h = 0, img_w = 0, max_images = 0, max_tokens = 0, stem_c = 0;
+  int top_h = 0, top_w = 0, top_c = 0;
+  std::vector<RnUnit> units;       // units[0] = stem
+  std::vector<RnBlock> blocks;
+  DevBuf images, stemA, a0;        // image copy, stem im2col, stem activation [B][H/2][W/2][stem]
+  DevBuf fa, fb, fc, fz, fsc;      // forward scratch
+  DevBuf feat;                     // [B][top...]
+  DevBuf r0, r1, r2, r3, r4;       // reverse scratch (per token)
+  int encoded = 0;
+  bool features_only = false;
+  bool profile = false;
+  std::vector<ProfileRec> prof;
+
+  int add_unit(const std::string& nm, int k, int cin, int cout, int stride, int Hin, int Win, bool relu) {
+    RnUnit u;
+    u.name = nm; u.k = k; u.cin = cin; u.cout = cout; u.stride = stride; u.Hin = Hin; u.Win = Win; u.relu = relu;
+    u.Hout = (Hin + stride - 1) / stride; u.Wout = (Win + stride - 1) / stride;
+    units.push_back(std::move(u));
+    return (int)units.size() - 1;
+  }
+
+  int init(const lrp_config& c, int64_t* total) {
+    img_h = c.img_h; img_w = c.img_w; max_images = c.max_images; max_tokens = c.max_tokens; stem_c = c.resnet_stem;
+    if (c.resnet_n_stacks < 1 || c.resnet_n_stacks > 8) return fail(LRP_ERR_INVALID, "resnet_n_stacks out of range");
+    if ((img_h % 4) || (img_w % 4) || stem_c % 4) return fail(LRP_ERR_UNSUPPORTED, "image size and stem width must be multiples of 4");
+    add_unit("conv1", 7, 3, stem_c, 2, img_h, img_w, true);
+    int H = img_h / 4, W = img_w / 4, cin = stem_c;
+    for (int s = 0; s < c.resnet_n_stacks; ++s) {
+      const int f = c.resnet_filters[s], nb = c.resnet_blocks[s];
+      if (f % 4 || nb < 1) return fail(LRP_ERR_INVALID, "bad resnet stack %d", s);
+      for (int b = 1; b <= nb; ++b) {
+        char nm[64];
+        snprintf(nm, sizeof(nm), "conv%d_block%d", s + 2, b);
+        const int stride = (b == 1 && s > 0) ? 2 : 1;
+        if (stride == 2 && ((H & 1) || (W & 1))) return fail(LRP_ERR_UNSUPPORTED, "odd resolution before a stride-2 block");
+        RnBlock B;
+        B.stride = stride; B.cin = cin; B.f = f; B.Hin = H; B.Win = W; B.H = H / stride; B.W = W / stride;
+        if (b == 1) B.u0 = add_unit(std::string(nm) + "_0", 1, cin, 4 * f, stride, H, W, false);
+        B.u1 = add_unit(std::string(nm) + "_1", 1, cin, f, stride, H, W, true);
+        B.u2 = add_unit(std::string(nm) + "_2", 3, f, f, 1, B.H, B.W, true);
+        B.u3 = add_unit(std::string(nm) + "_3", 1, f, 4 * f, 1, B.H, B.W, false);
+        blocks.push_back(std::move(B));
+        H /= stride; W /= stride; cin = 4 * f;
+      }
+    }
+    top_h = H; top_w = W; top_c = cin;
+    if (top_h * top_w != c.L || top_c != c.D)
+      return fail(LRP_ERR_INVALID, "ResNet output (%d x %d x %d) does not match L=%d, D=%d", top_h, top_w, top_c, c.L, c.D);
+    const size_t B = max_images, NT = max_tokens;
+    size_t max_act = (size_t)(img_h / 2) * (img_w / 2) * stem_c;
+    for (const RnUnit& u : units) { max_act = std::max(max_act, u.out_elems()); max_act = std::max(max_act, u.in_elems()); }
+    const size_t stem_hw = (size_t)(img_h / 2) * (img_w / 2);
+    LRP_TRY(images.alloc(B * img_h * img_w * 3 * 4, total));
+    LRP_TRY(stemA.alloc(B * stem_hw * 2 * RN_STEM_K * 4, total));
+    LRP_TRY(a0.alloc(B * stem_hw * stem_c * 4, total));
+    LRP_TRY(q_stem.alloc(B * stem_hw * stem_c * 4, total));
+    for (DevBuf* d : {&fa, &fb, &fc, &fz, &fsc}) LRP_TRY(d->alloc(B * max_act * 4, total));
+    LRP_TRY(feat.alloc(B * (size_t)top_h * top_w * top_c * 4, total));
+    const size_t max_tok = std::max(max_act, stem_hw * (size_t)std::max(RN_STEM_TCOLS, stem_c));
+    for (DevBuf* d : {&r0, &r1, &r2, &r3, &r4}) LRP_TRY(d->alloc(NT * max_tok * 4, total));
+    for (RnUnit& u : units) LRP_TRY(u.gate.alloc(B * u.out_elems() * 4, total));
+    for (RnBlock& b : blocks) {
+      LRP_TRY(b.t_in.alloc(B * (size_t)b.Hin * b.Win * b.cin * 4, total));
+      if (b.stride == 2) LRP_TRY(b.t_sub.alloc(B * (size_t)b.H * b.W * b.cin * 4, total));
+      LRP_TRY(b.GA.alloc(B * (size_t)b.H * b.W * 4 * b.f * 4, total));
+      LRP_TRY(b.GS.alloc(B * (size_t)b.H * b.W * 4 * b.f * 4, total));
+    }
+    return LRP_OK;
+  }
+
+  int find_unit(const std::string& nm) const {
+    for (size_t i = 0; i < units.size(); ++i)
+      if (units[i].name == nm) return (int)i;
+    return -1;
+  }
+
+  static int up(DevBuf& d, const std::vector<float>& v, int64_t* total) {
+    LRP_TRY(d.alloc(v.size() * 4, total));
+    LRP_HIP_CHECK(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return LRP_OK;
+  }
+
+  // name = "<unit>_conv_W" | "_conv_b" | "_bn_gamma" | "_bn_beta" | "_bn_mean" | "_bn_var"; returns 1 if not ours
+  int set_weight(const std::string& nm, const float* data, int ndim, const int64_t* shape, int64_t* total) {
+    static const char* suf[6] = {"_conv_W", "_conv_b", "_bn_gamma", "_bn_beta", "_bn_mean", "_bn_var"};
+    for (int s = 0; s < 6; ++s) {
+      const std::string sf(suf[s]);
+      if (nm.size() <= sf.size() || nm.compare(nm.size() - sf.size(), sf.size(), sf) != 0) continue;
+      const int ui = find_unit(nm.substr(0, nm.size() - sf.size()));
+      if (ui < 0) return 1;
+      RnUnit& u = units[ui];
+      if (s == 0) {
+        if (ndim != 4 || shape[0] != u.k || shape[1] != u.k || shape[2] != u.cin || shape[3] != u.cout)
+          return fail(LRP_ERR_INVALID, "%s: expected HWIO (%d,%d,%d,%d)", nm.c_str(), u.k, u.k, u.cin, u.cout);
+        LRP_TRY(pack_unit(u, data, total));
+      } else {
+        if (ndim != 1 || shape[0] != u.cout) return fail(LRP_ERR_INVALID, "%s: expected (%d,)", nm.c_str(), u.cout);
+        DevBuf* dst[6] = {nullptr, &u.bias, &u.gamma, &u.beta, &u.mean, &u.var};
+        LRP_TRY(up(*dst[s], std::vector<float>(data, data + u.cout), total));
+      }
+      u.have[s] = true;
+      return LRP_OK;
+    }
+    return 1;
+  }
+
+  int pack_unit(RnUnit& u, const float* w, int64_t* total) {
+    const size_t nW = (size_t)u.k * u.k * u.cin * u.cout;
+    std::vector<float> wp(nW), wn(nW), pk;
+    for (size_t i = 0; i < nW; ++i) { wp[i] = w[i] >= 0.f ? w[i] : 0.f; wn[i] = w[i] < 0.f ? w[i] : 0.f; }
+    if (u.k == 7) {
+      // stem forward: 1-tap GEMM over the im2col matrix [x+ patch | x- patch] (K = 2 * 160)
+      const int Np = conv_npad(u.cout), K = 2 * RN_STEM_K;
+      std::vector<float> a((size_t)Np * K, 0.f), z((size_t)Np * K, 0.f);
+      for (int kk = 0; kk < 147; ++kk)
+        for (int co = 0; co < u.cout; ++co) {
+          const size_t s = (size_t)kk * u.cout + co;
+          a[(size_t)co * K + kk] = w[s]; a[(size_t)co * K + RN_STEM_K + kk] = w[s];
+          z[(size_t)co * K + kk] = wp[s]; z[(size_t)co * K + RN_STEM_K + kk] = wn[s];
+        }
+      LRP_TRY(up(u.w_a, a, total));
+      LRP_TRY(up(u.w_z, z, total));
+      // reverse at the image: T[q][tap*6 + c] (c<3: w+, c>=3: w-), K = cout
+      const int Npb = conv_npad(RN_STEM_TCOLS), Kb = conv_cinp(u.cout);
+      pk.assign((size_t)Npb * Kb, 0.f);
+      for (int t = 0; t < 49; ++t)
+        for (int c = 0; c < 3; ++c)
+          for (int co = 0; co < u.cout; ++co) {
+            pk[(size_t)(t * 6 + c) * Kb + co] = wp[((size_t)t * 3 + c) * u.cout + co];
+            pk[(size_t)(t * 6 + 3 + c) * Kb + co] = wn[((size_t)t * 3 + c) * u.cout + co];
+          }
+      return up(u.w_b, pk, total);
+    }
+    const int taps = u.k * u.k;
+    const int Np = conv_npad(u.cout), K = taps * conv_cinp(u.cin);
+    pk.assign((size_t)Np * K, 0.f);
+    pack_conv_fwd(w, taps, u.cin, u.cout, 0, Np, pk.data());
+    LRP_TRY(up(u.w_a, pk, total));
+    pk.assign((size_t)Np * K, 0.f);
+    pack_conv_fwd(wp.data(), taps, u.cin, u.cout, 0, Np, pk.data());           // inputs are post-ReLU: Z = conv(x, w+) + b
+    LRP_TRY(up(u.w_z, pk, total));
+    const int Npb = conv_npad(u.cin), Kb = taps * conv_cinp(u.cout);
+    pk.assign((size_t)Npb * Kb, 0.f);
+    pack_conv_bwd(wp.data(), taps, u.cin, u.cout, 0, pk.data());
+    return up(u.w_b, pk, total);
+  }
+
+  int check_ready() const {
+    for (const RnUnit& u : units)
+      for (int s = 0; s < 6; ++s)
+        if (!u.have[s]) return fail(LRP_ERR_STATE, "ResNet weights of '%s' incomplete", u.name.c_str());
+    return LRP_OK;
+  }
+
+  // conv + BN unit forward: x [B][Hin][Win][cin] -> act (relu(BN) or BN) and the unit's gate
+  int unit_forward(RnUnit& u, const float* x, int B, float* act, hipStream_t st) {
+    const float* xin = x;
+    if (u.k == 1 && u.stride == 2) {
+      const size_t n = (size_t)B * u.Hout * u.Wout * u.cin;
+      hipLaunchKernelGGL(rn_subsample2_kernel, dim3(stream_grid(n)), dim3(256), 0, st, x, fsc.as<float>(), B, u.Hin, u.Win, u.cin);
+      LRP_HIP_CHECK(hipGetLastError());
+      xin = fsc.as<float>();
+    }
+    ConvArgs ca{};
+    ca.in = xin; ca.bias = u.bias.as<float>(); ca.N = u.cout;
+    if (u.k == 3) { ca.NB = B; ca.H = u.Hout; ca.W = u.Wout; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 9; }
+    else { ca.NB = B * u.Hout * u.Wout; ca.H = 1; ca.W = 1; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 1; }
+    ConvArgs cz = ca;
+    ca.wpk = u.w_a.as<float>(); ca.out = fc.as<float>();
+    LRP_HIP_CHECK(conv_launch(EPI_BIAS, ca, st));
+    cz.wpk = u.w_z.as<float>(); cz.out = fz.as<float>();
+    LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, st));
+    const size_t n = (size_t)B * u.out_elems();
+    hipLaunchKernelGGL(rn_bn_unit_kernel, dim3(stream_grid(n)), dim3(256), 0, st, fc.as<float>(), fz.as<float>(),
+                       u.gamma.as<float>(), u.beta.as<float>(), u.mean.as<float>(), u.var.as<float>(), RN_BN_EPS, act,
+                       u.gate.as<float>(), (float*)nullptr, n, u.cout, u.relu ? 1 : 0);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+
+  int encode(const float* images_dev, int B, hipStream_t st) {
+    if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
+    LRP_TRY(check_ready());
+    LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, (size_t)B * img_h * img_w * 3 * 4, hipMemcpyDeviceToDevice, st));
+    RnUnit& s = units[0];
+    {  // stem: im2col -> two 1-tap GEMMs (c exact / Z with both sign branches) -> BN + relu + gate
+      const size_t tot = (size_t)B * s.Hout * s.Wout * 2 * RN_STEM_K;
+      hipLaunchKernelGGL(rn_stem_im2col_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, images.as<float>(),
+                         stemA.as<float>(), B, img_h, img_w);
+      LRP_HIP_CHECK(hipGetLastError());
+      ConvArgs ca{};
+      ca.in = stemA.as<float>(); ca.NB = B * s.Hout * s.Wout; ca.H = 1; ca.W = 1; ca.Cin = 2 * RN_STEM_K; ca.CinP = 2 * RN_STEM_K;
+      ca.taps = 1; ca.N = s.cout; ca.bias = s.bias.as<float>();
+      ConvArgs cz = ca;
+      ca.wpk = s.w_a.as<float>(); ca.out = fc.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_BIAS, ca, st));
+      cz.wpk = s.w_z.as<float>(); cz.out = fz.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, st));
+      const size_t n = (size_t)B * s.out_elems();
+      hipLaunchKernelGGL(rn_bn_unit_kernel, dim3(stream_grid(n)), dim3(256), 0, st, fc.as<float>(), fz.as<float>(),
+                         s.gamma.as<float>(), s.beta.as<float>(), s.mean.as<float>(), s.var.as<float>(), RN_BN_EPS,
+                         a0.as<float>(), s.gate.as<float>(), q_stem.as<float>(), n, s.cout, 1);
+      LRP_HIP_CHECK(hipGetLastError());
+      const size_t np = (size_t)B * (s.Hout / 2) * (s.Wout / 2) * s.cout;
+      hipLaunchKernelGGL(rn_pool3_kernel, dim3(stream_grid(np)), dim3(256), 0, st, a0.as<float>(), blocks[0].t_in.as<float>(),
+                         B, s.Hout, s.Wout, s.cout);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+      RnBlock& b = blocks[bi];
+      const float* t = b.t_in.as<float>();
+      if (b.stride == 2) {
+        const size_t n = (size_t)B * b.H * b.W * b.cin;
+        hipLaunchKernelGGL(rn_subsample2_kernel, dim3(stream_grid(n)), dim3(256), 0, st, t, b.t_sub.as<float>(), B, b.Hin,
+                           b.Win, b.cin);
+        LRP_HIP_CHECK(hipGetLastError());
+      }
+      // main path: fa <- a1, fb <- a2, fa <- y3 ; shortcut: fsc2 (= r0 scratch is per-token; use GS buffer as temp) ...
+      LRP_TRY(unit_forward(units[b.u1], t, B, fa.as<float>(), st));
+      LRP_TRY(unit_forward(units[b.u2], fa.as<float>(), B, fb.as<float>(), st));
+      LRP_TRY(unit_forward(units[b.u3], fb.as<float>(), B, fa.as<float>(), st));        // fa = y3
+      const float* sc = t;
+      if (b.u0 >= 0) {
+        LRP_TRY(unit_forward(units[b.u0], t, B, fb.as<float>(), st));                   // fb = y0
+        sc = fb.as<float>();
+      }
+      const bool last = bi + 1 == blocks.size();
+      float* o = last ? feat.as<float>() : blocks[bi + 1].t_in.as<float>();
+      const size_t n = (size_t)B * b.H * b.W * 4 * b.f;
+      hipLaunchKernelGGL(rn_block_out_kernel, dim3(stream_grid(n)), dim3(256), 0, st, sc, fa.as<float>(),
+                         units[b.u3].gate.as<float>(), b.u0 >= 0 ? units[b.u0].gate.as<float>() : (const float*)nullptr, o,
+                         b.GA.as<float>(), b.GS.as<float>(), n);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    encoded = B;
+    features_only = false;
+    return LRP_OK;
+  }
+
+  // conv-LRP step through one unit: S [n][Hout][Wout][cout] -> out [n][Hout'][..][cin] = convT(S, w+) * aux[img]
+  int unit_backward(const RnUnit& u, int n, const int* row2img, const float* S, const float* aux, float* out, hipStream_t st) {
+    ConvArgs ca{};
+    ca.in = S; ca.wpk = u.w_b.as<float>(); ca.row2img = row2img; ca.aux = aux; ca.out = out; ca.N = u.cin;
+    ca.Cin = u.cout; ca.CinP = conv_cinp(u.cout); ca.NB = n; ca.H = u.Hout; ca.W = u.Wout; ca.taps = u.k == 3 ? 9 : 1;
+    ProfileRec pr{};
+    if (profile) { (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1); (void)hipEventRecord(pr.e0, st); }
+    LRP_HIP_CHECK(conv_launch(EPI_MUL, ca, st));
+    if (profile) {
+      (void)hipEventRecord(pr.e1, st);
+      pr.flop = 2.0 * n * u.Hout * u.Wout * (double)(u.k == 3 ? 9 : 1) * u.cout * u.cin;
+      prof.push_back(pr);
+    }
+    return LRP_OK;
+  }
+
+  int explain(int n, const int* row2img, const float* R_feat_dev, float* R_img_dev, hipStream_t st) {
+    if (n < 1 || n > max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, max_tokens);
+    if (encoded < 1 || features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before the CNN explain");
+    const float* Ro = R_feat_dev;          // relevance at the current block's output
+    float* cur = r0.as<float>();           // where the next R_t is written (ping-pong r0 / r4)
+    float* other = r4.as<float>();
+    for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
+      const RnBlock& b = blocks[bi];
+      const size_t per_o = (size_t)b.H * b.W * 4 * b.f;
+      // S3 = R_o * (fA Q3)
+      hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GA.as<float>(),
+                         row2img, (const float*)nullptr, r1.as<float>(), n, per_o);
+      LRP_HIP_CHECK(hipGetLastError());
+      LRP_TRY(unit_backward(units[b.u3], n, row2img, r1.as<float>(), units[b.u2].gate.as<float>(), r2.as<float>(), st));  // S2
+      LRP_TRY(unit_backward(units[b.u2], n, row2img, r2.as<float>(), units[b.u1].gate.as<float>(), r1.as<float>(), st));  // S1
+      const float* taux = b.stride == 2 ? b.t_sub.as<float>() : b.t_in.as<float>();
+      LRP_TRY(unit_backward(units[b.u1], n, row2img, r1.as<float>(), taux, r2.as<float>(), st));                          // t*C1 (coarse)
+      const size_t per_c = (size_t)b.H * b.W * b.cin;          // coarse (= fine when stride 1)
+      if (b.u0 >= 0) {
+        hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GS.as<float>(),
+                           row2img, (const float*)nullptr, r1.as<float>(), n, per_o);                                     // S0
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(unit_backward(units[b.u0], n, row2img, r1.as<float>(), taux, r3.as<float>(), st));                        // t*C0
+        if (b.stride == 2) {
+          const size_t tot = (size_t)n * b.Hin * b.Win * b.cin;
+          hipLaunchKernelGGL(rn_scatter2_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur, n,
+                             b.Hin, b.Win, b.cin);
+        } else {
+          hipLaunchKernelGGL(rn_add_kernel, dim3(stream_grid((size_t)n * per_c)), dim3(256), 0, st, r2.as<float>(),
+                             r3.as<float>(), cur, (size_t)n * per_c);
+        }
+        LRP_HIP_CHECK(hipGetLastError());
+      } else {
+        // identity shortcut (stride 1, cin == 4f): R_t = t*C1 + R_o * fS
+        hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GS.as<float>(),
+                           row2img, r2.as<float>(), cur, n, per_o);
+        LRP_HIP_CHECK(hipGetLastError());
+      }
+      Ro = cur;
+      std::swap(cur, other);
+    }
+    // stem: pool routing * Q_stem -> T = S . W (K = stem_c, N = 294) -> 7x7/2 stencil with the x+/x- selection
+    const RnUnit& s = units[0];
+    const size_t tot = (size_t)n * s.Hout * s.Wout * s.cout;
+    hipLaunchKernelGGL(rn_pool3_route_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, Ro, a0.as<float>(),
+                       q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
+    LRP_HIP_CHECK(hipGetLastError());
+    ConvArgs ca{};
+    ca.in = r1.as<float>(); ca.NB = n * s.Hout * s.Wout; ca.H = 1; ca.W = 1; ca.Cin = s.cout; ca.CinP = conv_cinp(s.cout);
+    ca.taps = 1; ca.wpk = s.w_b.as<float>(); ca.N = RN_STEM_TCOLS; ca.out = r2.as<float>();
+    LRP_HIP_CHECK(conv_launch(EPI_STORE, ca, st));
+    hipLaunchKernelGGL(rn_stem_stencil_kernel, dim3(stream_grid((size_t)n * img_h * img_w)), dim3(256), 0, st, r2.as<float>(),
+                       images.as<float>(), row2img, R_img_dev, n, img_h, img_w);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+
+  // the stem's routing needs Q alone: what arrives at a0 = relu(y) through the pool is already a relevance
+  // (t * C1 of the first block), so multiplying by the relu-unit gate a0*Q would count a0 twice
+  DevBuf q_stem;
+
+  int profile_records(int cap, double* ms_out, double* flop_out, int* n_out) {
+    int k = 0;
+    for (ProfileRec& p : prof) {
+      float t = 0.f;
+      const bool ok = hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&t, p.e0, p.e1) == hipSuccess;
+      if (ok && k < cap) { ms_out[k] = t; flop_out[k] = p.flop; ++k; }
+      (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1);
+    }
+    prof.clear();
+    *n_out = k;
+    return LRP_OK;
+  }
+};
+
+}  // namespace lrp

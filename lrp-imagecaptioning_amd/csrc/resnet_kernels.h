@@ -1,0 +1,225 @@
+// resnet_kernels.h — streaming (HBM-bound) helpers of the ResNet-101 encoder path (config 4):
+// BN + gate construction, block outputs / Add-rule factors, stride-2 gather / scatter, the
+// overlapping 3x3/2 max-pool and its relevance routing, the 7x7/2 stem im2col and stencil.
+// Rules: BatchNormalizationReverseLayer RA:197-257, AddReverseLayer RA:260-286, Alpha1Beta0 RR:274-322,
+// gradient routing RA:470-480; architecture: keras_applications.resnet_common (ResNet v1 bottleneck).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "cnn_kernels.h"
+
+namespace lrp {
+
+__device__ __forceinline__ float stab_sign(float d) { return d + (d >= 0.f ? 1e-7f : -1e-7f); }
+
+// After a conv unit: c = conv(x,w)+b (exact), Z = alpha1beta0 denominator.
+//   y = BN(c);  Q = c (y - beta) / stab((c - mu) y) / safe(Z)     [BN reverse o conv denominator]
+//   relu != 0: act = relu(y), gate = act * Q  (what the NEXT conv's relevance is multiplied with)
+//   relu == 0: act = y (pre-Add tensor), gate = Q
+__global__ __launch_bounds__(256) void rn_bn_unit_kernel(const float* __restrict__ c, const float* __restrict__ Z,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float bn_eps, float* __restrict__ act, float* __restrict__ gate,
+                                                         float* __restrict__ qonly, size_t n, int C, int relu) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % C);
+    const float cv = c[i], mu = mean[ch], bt = beta[ch];
+    const float y = gamma[ch] * (cv - mu) / sqrtf(var[ch] + bn_eps) + bt;
+    const float q = (cv * (y - bt)) / safe_den(stab_sign((cv - mu) * y)) / safe_den(Z[i]);
+    const float av = relu ? fmaxf(y, 0.f) : y;
+    act[i] = av;
+    gate[i] = relu ? av * q : q;
+    if (qonly) qonly[i] = q;
+  }
+}
+
+// Block end: o = relu(sc + y3);  GA = y3 / safe(sc + y3) * Q3;  GS = sc / safe(sc + y3) [* Q0 for a projection shortcut]
+__global__ __launch_bounds__(256) void rn_block_out_kernel(const float* __restrict__ sc, const float* __restrict__ y3,
+                                                           const float* __restrict__ Q3, const float* __restrict__ Q0,
+                                                           float* __restrict__ o, float* __restrict__ GA,
+                                                           float* __restrict__ GS, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float s = sc[i], y = y3[i];
+    const float den = safe_den(s + y);
+    o[i] = fmaxf(s + y, 0.f);
+    GA[i] = y / den * Q3[i];
+    GS[i] = Q0 ? s / den * Q0[i] : s / den;
+  }
+}
+
+// out[t][e] = R[t][e] * G[img(t)][e]  (+ add[t][e])
+__global__ __launch_bounds__(256) void rn_mul_gate_kernel(const float* __restrict__ R, const float* __restrict__ G,
+                                                          const int* __restrict__ row2img, const float* __restrict__ add,
+                                                          float* __restrict__ out, int ntok, size_t per_img) {
+  const size_t total = (size_t)ntok * per_img;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / per_img);
+    const size_t e = i - (size_t)t * per_img;
+    const int img = row2img ? row2img[t] : t;
+    float v = R[i] * G[(size_t)img * per_img + e];
+    if (add) v += add[i];
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void rn_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+
+// stride-2 gather: xs[n][ho][wo][c] = x[n][2ho][2wo][c]   (input of a strided 1x1 conv)
+__global__ __launch_bounds__(256) void rn_subsample2_kernel(const float* __restrict__ x, float* __restrict__ xs, int NB,
+                                                            int H, int W, int C) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)NB * Ho * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    xs[i] = x[(((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c];
+  }
+}
+
+// stride-2 scatter of relevance: fine[n][h][w][c] = (h,w both even) ? (a[..] (+ b[..])) : 0
+__global__ __launch_bounds__(256) void rn_scatter2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ fine, int NB, int H, int W, int C) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const size_t total = (size_t)NB * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float v = 0.f;
+    if (!(h & 1) && !(w & 1)) {
+      const size_t j = (((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c;
+      v = a[j] + (b ? b[j] : 0.f);
+    }
+    fine[i] = v;
+  }
+}
+
+// 3x3/2 max-pool on the 1-padded map (ZeroPadding2D(1) + MaxPooling2D(3, 2, 'valid')):  a (H,W) -> (H/2, W/2)
+__device__ __forceinline__ float rn_padded_at(const float* __restrict__ a, int n, int i, int j, int c, int H, int W, int C) {
+  return (i >= 0 && i < H && j >= 0 && j < W) ? a[(((size_t)n * H + i) * W + j) * C + c] : 0.f;   // zero padding is a candidate
+}
+__global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__ a, float* __restrict__ out, int NB, int H,
+                                                       int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)NB * Ho * Wo * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int ow = (int)(r % Wo);
+    r /= Wo;
+    const int oh = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float m = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) m = fmaxf(m, rn_padded_at(a, n, 2 * oh + kh - 1, 2 * ow + kw - 1, c, H, W, C));
+    out[i] = m;
+  }
+}
+
+// Relevance routing through that pool (gradient of max-pool = first arg-max of each window, windows overlap),
+// fused with the stem gate:  S[n][i][j][c] = Q[img][i][j][c] * sum_{windows (oh,ow) whose arg-max is (i,j)} R[n][oh][ow][c]
+__global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __restrict__ R, const float* __restrict__ a,
+                                                             const float* __restrict__ Q, const int* __restrict__ row2img,
+                                                             float* __restrict__ S, int ntok, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)ntok * H * W * C;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int c = (int)(idx % C);
+    size_t r = idx / C;
+    const int j = (int)(r % W);
+    r /= W;
+    const int i = (int)(r % H);
+    const int t = (int)(r / H);
+    const int img = row2img ? row2img[t] : t;
+    float acc = 0.f;
+    // windows containing padded position (i+1, j+1): oh in [ceil((i-1)/2), floor((i+1)/2)]
+    for (int oh = (i) / 2; oh <= (i + 1) / 2; ++oh) {
+      if (oh < 0 || oh >= Ho || 2 * oh - 1 > i || 2 * oh + 1 < i) continue;
+      for (int ow = (j) / 2; ow <= (j + 1) / 2; ++ow) {
+        if (ow < 0 || ow >= Wo || 2 * ow - 1 > j || 2 * ow + 1 < j) continue;
+        // first maximum in window scan order
+        float m = -INFINITY;
+        int ai = 0, aj = 0;
+        for (int kh = 0; kh < 3; ++kh)
+          for (int kw = 0; kw < 3; ++kw) {
+            const int ii = 2 * oh + kh - 1, jj = 2 * ow + kw - 1;
+            const float v = rn_padded_at(a, img, ii, jj, c, H, W, C);
+            if (v > m) { m = v; ai = ii; aj = jj; }
+          }
+        if (ai == i && aj == j) acc += R[(((size_t)t * Ho + oh) * Wo + ow) * C + c];
+      }
+    }
+    S[idx] = acc * Q[(((size_t)img * H + i) * W + j) * C + c];
+  }
+}
+
+// Stem forward as a 1-tap GEMM: A[m][320] = [ x+ patch (7*7*3 = 147) | 0*13 | x- patch (147) | 0*13 ] for output pixel
+// m = (n, oh, ow); patch element (kh,kw,c) = x[2oh+kh-3][2ow+kw-3][c] (ZeroPadding2D(3) + 7x7/2 'valid')
+constexpr int RN_STEM_K = 160;
+__global__ __launch_bounds__(256) void rn_stem_im2col_kernel(const float* __restrict__ img, float* __restrict__ A, int NB,
+                                                             int H, int W) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)NB * Ho * Wo * (2 * RN_STEM_K);
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int k = (int)(idx % (2 * RN_STEM_K));
+    size_t m = idx / (2 * RN_STEM_K);
+    const int ow = (int)(m % Wo);
+    m /= Wo;
+    const int oh = (int)(m % Ho);
+    const int n = (int)(m / Ho);
+    const int kk = k % RN_STEM_K;
+    float v = 0.f;
+    if (kk < 147) {
+      const int tap = kk / 3, c = kk - 3 * tap;
+      const int i = 2 * oh + tap / 7 - 3, j = 2 * ow + tap % 7 - 3;
+      if (i >= 0 && i < H && j >= 0 && j < W) {
+        const float x = img[(((size_t)n * H + i) * W + j) * 3 + c];
+        v = (k < RN_STEM_K) ? (x >= 0.f ? x : 0.f) : (x < 0.f ? x : 0.f);
+      }
+    }
+    A[idx] = v;
+  }
+}
+
+// Stem reverse: T[q][tap*6 + c] = sum_co S[q][co] w+[tap][c][co] (c<3) / w-[..] (c>=3) came from one K = C_stem GEMM;
+// R_img[p][c] = x+[p][c] * sum_{tap} T+[q(p,tap)][tap][c] + x-[p][c] * sum T-[...],  q = ((i+3-kh)/2, (j+3-kw)/2) when integral
+constexpr int RN_STEM_TCOLS = 294;
+__global__ __launch_bounds__(256) void rn_stem_stencil_kernel(const float* __restrict__ T, const float* __restrict__ ximg,
+                                                              const int* __restrict__ row2img, float* __restrict__ out,
+                                                              int ntok, int H, int W) {
+  const int Ho = H / 2, Wo = W / 2;
+  const size_t total = (size_t)ntok * H * W;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int HW = H * W;
+    const int t = (int)(idx / HW), pix = (int)(idx - (size_t)t * HW);
+    const int i = pix / W, j = pix - i * W;
+    float pos[3] = {0.f, 0.f, 0.f}, neg[3] = {0.f, 0.f, 0.f};
+    for (int kh = (i + 3) & 1; kh < 7; kh += 2) {
+      const int oh = (i + 3 - kh) >> 1;
+      if (oh < 0 || oh >= Ho) continue;
+      for (int kw = (j + 3) & 1; kw < 7; kw += 2) {
+        const int ow = (j + 3 - kw) >> 1;
+        if (ow < 0 || ow >= Wo) continue;
+        const float* r = T + (((size_t)t * Ho + oh) * Wo + ow) * RN_STEM_TCOLS + (kh * 7 + kw) * 6;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pos[c] += r[c]; neg[c] += r[3 + c]; }
+      }
+    }
+    const int img = row2img ? row2img[t] : t;
+    const float* x = ximg + ((size_t)img * HW + pix) * 3;
+    float* o = out + idx * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = x[c] >= 0.f ? x[c] * pos[c] : x[c] * neg[c];
+  }
+}
+
+}  // namespace lrp

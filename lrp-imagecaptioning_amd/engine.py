@@ -22,7 +22,10 @@ class LRPEngine(object):
     """Geometry + weights + caches for one captioning model on one GPU."""
 
     def __init__(self, decoder="adaptive", cnn_cfg=VGG16_CFG, img_hw=(224, 224), L=196, D=512, H=512, E=512,
-                 V=10000, max_images=32, max_tokens=320, max_caption_len=21, sos_id=2, eos_id=1, device=None):
+                 V=10000, max_images=32, max_tokens=320, max_caption_len=21, sos_id=2, eos_id=1, device=None,
+                 resnet=None):
+        """resnet: None (VGG-style `cnn_cfg`) or dict(stem=64, stacks=((64,3),(128,4),(256,23),(512,3))) for the
+        ResNet-v1 bottleneck encoder of BASELINE config 4 (then cnn_cfg is ignored)."""
         if decoder not in ("adaptive", "gridtd"):
             raise NotImplementedError("decoder must be 'adaptive' or 'gridtd'")
         self._lib = _capi.load()                      # raises if the HIP library is missing
@@ -34,10 +37,19 @@ class LRPEngine(object):
         cfg.device = self.device.index
         cfg.decoder = _capi.LRP_DEC_ADAPTIVE if decoder == "adaptive" else _capi.LRP_DEC_GRIDTD
         cfg.img_h, cfg.img_w = img_hw
-        cfg.n_conv = len(cnn_cfg)
-        for i, (name, cin, cout, pool) in enumerate(cnn_cfg):
-            cfg.conv_cin[i], cfg.conv_cout[i], cfg.conv_pool_after[i] = cin, cout, int(bool(pool))
-            cfg.conv_name[i].value = name.encode()
+        if resnet is None:
+            cfg.encoder = _capi.LRP_ENC_VGG
+            cfg.n_conv = len(cnn_cfg)
+            for i, (name, cin, cout, pool) in enumerate(cnn_cfg):
+                cfg.conv_cin[i], cfg.conv_cout[i], cfg.conv_pool_after[i] = cin, cout, int(bool(pool))
+                cfg.conv_name[i].value = name.encode()
+        else:
+            cfg.encoder = _capi.LRP_ENC_RESNET
+            cfg.resnet_stem = int(resnet.get("stem", 64))
+            stacks = list(resnet["stacks"])
+            cfg.resnet_n_stacks = len(stacks)
+            for i, (f, nb) in enumerate(stacks):
+                cfg.resnet_filters[i], cfg.resnet_blocks[i] = int(f), int(nb)
         cfg.L, cfg.D, cfg.H, cfg.E, cfg.V = L, D, H, E, V
         cfg.max_images, cfg.max_tokens, cfg.max_caption_len = max_images, max_tokens, max_caption_len
         cfg.sos_id, cfg.eos_id = sos_id, eos_id

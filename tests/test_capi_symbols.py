@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_matches_header():
     from lrp_imagecaptioning_amd import _capi
-    # 6 scalars + 3*32 ints + 32*32 chars + 5 + 3 + 2 ints
-    assert ctypes.sizeof(_capi.LrpConfig) == 4 * (6 + 3 * 32 + 5 + 3 + 2) + 32 * 32
+    # 6 scalars + 3*32 ints + 32*32 chars + 5 + 3 + 2 ints + (ABI v2) 3 ints + 2*8 ints
+    assert ctypes.sizeof(_capi.LrpConfig) == 4 * (6 + 3 * 32 + 5 + 3 + 2 + 3 + 16) + 32 * 32
 
 
 def test_error_path_without_gpu():

@@ -1,0 +1,88 @@
+"""-m gpu: ResNet (v1 bottleneck) encoder LRP through the C ABI against the float64 literal oracle
+(oracle/resnet_lrp_ref.py) — BASELINE config 4's CNN half (rows c3, c5, c6 of SURVEY §8a)."""
+import numpy as np
+import pytest
+
+from conftest import rel_l1
+from gpu_util import report
+from lrp_imagecaptioning_amd.synthetic import RESNET101_STACKS, gridtd_weights, resnet_weights
+from oracle import resnet_lrp_ref as RN
+from oracle.decoder_ref import GridTDOracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _engine(stacks, stem, hw, B, ntok, w, decoder="gridtd", H=32, V=50):
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    side = hw // 4 // (2 ** (len(stacks) - 1))
+    D = 4 * stacks[-1][0]
+    eng = LRPEngine(decoder=decoder, img_hw=(hw, hw), L=side * side, D=D, H=H, E=H, V=V, max_images=B, max_tokens=ntok,
+                    max_caption_len=6, resnet={"stem": stem, "stacks": stacks})
+    eng.set_weights(w)
+    return eng, side, D
+
+
+@pytest.mark.parametrize("name,stacks,stem,hw,B", [("tiny", ((4, 2), (8, 2)), 8, 32, 2),
+                                                   ("mid", ((8, 2), (16, 3), (32, 2)), 16, 64, 2)])
+def test_small_resnets_match_oracle(name, stacks, stem, hw, B):
+    rs = np.random.RandomState(3)
+    w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
+    spec = RN.resnet_spec(stacks, stem=stem)
+    X = rs.uniform(-120, 130, size=(B, hw, hw, 3)).astype(np.float32)
+    eng, side, D = _engine(stacks, stem, hw, B, 2 * B, w)
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(B, side, side, D)
+    feat_ref = RN.forward(w, spec, X)
+    assert rel_l1(feat, feat_ref) < 1e-5
+    idx = list(range(B)) + list(range(B))[::-1]
+    R = (rs.standard_normal((2 * B,) + feat_ref.shape[1:]) * feat_ref[idx]).astype(np.float32)
+    out = eng.cnn_explain(idx, R).cpu().numpy()
+    ref = RN.analyze(w, spec, X[idx], R)
+    errs = [rel_l1(out[i], ref[i]) for i in range(2 * B)]
+    report("resnet_" + name, feat_rel_l1=rel_l1(feat, feat_ref), max_rel_l1=max(errs))
+    assert np.isfinite(out).all()
+    assert max(errs) < TOL, errs
+
+
+def test_resnet101_full_size_matches_oracle():
+    """ResNet-101, 224x224 -> (7,7,2048) (config.py:41-45), one image, two relevance maps."""
+    rs = np.random.RandomState(0)
+    w = resnet_weights(rs)
+    spec = RN.resnet_spec()
+    X = rs.uniform(-120, 130, size=(1, 224, 224, 3)).astype(np.float32)
+    eng, side, D = _engine(RESNET101_STACKS, 64, 224, 1, 2, w)
+    assert (side, D) == (7, 2048)
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(1, 7, 7, 2048)
+    feat_ref = RN.forward(w, spec, X)
+    e_feat = rel_l1(feat, feat_ref)
+    R = (rs.standard_normal((2, 7, 7, 2048)) * feat_ref).astype(np.float32)
+    out = eng.cnn_explain([0, 0], R).cpu().numpy()
+    ref = RN.analyze(w, spec, np.repeat(X, 2, axis=0), R)
+    errs = [rel_l1(out[i], ref[i]) for i in range(2)]
+    report("resnet101", feat_rel_l1=e_feat, max_rel_l1=max(errs))
+    assert e_feat < 1e-5
+    assert max(errs) < TOL, errs
+
+
+def test_config4_gridtd_plus_resnet_end_to_end():
+    """grid-TD decoder on a ResNet encoder (BASELINE config 4 at reduced size): decoder LRP -> CNN LRP fused call."""
+    stacks, stem, hw, H, V = ((4, 2), (8, 2)), 8, 32, 32, 50
+    rs = np.random.RandomState(9)
+    w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
+    L, D = 16, 32
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    X = rs.uniform(-120, 130, size=(1, hw, hw, 3)).astype(np.float32)
+    cap = [7, 19, 33, 1]
+    eng, side, _ = _engine(stacks, stem, hw, 1, 4, w, decoder="gridtd", H=H, V=V)
+    eng.encode_images(X)
+    eng.decoder_forward([cap])
+    out, _, _, _ = eng.explain_tokens([0, 0, 0], [1, 2, 3])
+    out = out.cpu().numpy()
+    spec = RN.resnet_spec(stacks, stem=stem)
+    o = GridTDOracle(w, L, D, H, H)
+    o.forward(RN.forward(w, spec, X).astype(np.float32), cap)
+    worst = max(rel_l1(out[t - 1], RN.analyze(w, spec, X, o.explain(t)[0])[0]) for t in (1, 2, 3))
+    report("config4_small", max_rel_l1=worst)
+    assert worst < TOL
