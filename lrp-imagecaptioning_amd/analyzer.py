@@ -20,16 +20,33 @@ class NotAnalyzeableModelException(Exception):
 
 
 class ImageModelSpec(object):
-    def __init__(self, weights, cnn_cfg=VGG16_CFG, img_hw=(224, 224)):
-        self.weights = {k: v for k, v in weights.items() if k.endswith(("_W", "_b")) and k[:-2] in {c[0] for c in cnn_cfg}}
-        self.cnn_cfg = list(cnn_cfg)
+    """The truncated encoder `Model(input_1 -> block5_conv3)` (explainers.py:29-30) as data: a VGG-style conv list,
+    or (resnet=dict(stem, stacks)) the ResNet-v1 bottleneck stack cut at conv5_block3_out.  The analyzer's head
+    shape follows from it — (14,14,512) / (7,7,2048) in the reference's hard-coded table (base.py:370-373)."""
+
+    def __init__(self, weights, cnn_cfg=VGG16_CFG, img_hw=(224, 224), resnet=None):
         self.img_hw = tuple(img_hw)
-        missing = [c[0] for c in cnn_cfg if c[0] + "_W" not in self.weights or c[0] + "_b" not in self.weights]
+        self.resnet = resnet
+        if resnet is None:
+            self.cnn_cfg = list(cnn_cfg)
+            self.weights = {k: v for k, v in weights.items() if k.endswith(("_W", "_b")) and k[:-2] in {c[0] for c in cnn_cfg}}
+            missing = [c[0] for c in cnn_cfg if c[0] + "_W" not in self.weights or c[0] + "_b" not in self.weights]
+        else:
+            from .synthetic import resnet_conv_list
+            self.cnn_cfg = VGG16_CFG
+            names = [c[0] for c in resnet_conv_list(resnet["stacks"], resnet.get("stem", 64))]
+            sufs = ("_conv_W", "_conv_b", "_bn_gamma", "_bn_beta", "_bn_mean", "_bn_var")
+            self.weights = {n + s: weights[n + s] for n in names for s in sufs if n + s in weights}
+            missing = [n + s for n in names for s in sufs if n + s not in weights]
         if missing:
-            raise NotAnalyzeableModelException("weights missing for layers %s" % missing)
+            raise NotAnalyzeableModelException("weights missing for layers %s" % missing[:8])
 
     def output_shape(self):
         h, w = self.img_hw
+        if self.resnet is not None:
+            stacks = self.resnet["stacks"]
+            d = 4 * 2 ** (len(stacks) - 1)
+            return h // d, w // d, 4 * stacks[-1][0]
         for _, _, _, pool in self.cnn_cfg:
             if pool:
                 h, w = h // 2, w // 2
@@ -50,7 +67,8 @@ class LRPSequentialPresetA(object):
         h, w, c = model.output_shape()
         # the decoder half of the handle is idle here: minimal dims
         self._engine = LRPEngine(decoder="adaptive", cnn_cfg=model.cnn_cfg, img_hw=model.img_hw, L=h * w, D=c, H=4, E=4,
-                                 V=4, max_images=max_batch, max_tokens=max_batch, max_caption_len=2, device=device)
+                                 V=4, max_images=max_batch, max_tokens=max_batch, max_caption_len=2, device=device,
+                                 resnet=model.resnet)
         self._engine.set_weights(model.weights)
         self._impl = _EngineAnalyzer(self._engine)
 

@@ -44,9 +44,15 @@ class CaptionModelSpec(object):
     """What the reference reads off `model` (E:26-39): encoder kind, dims, and the weights."""
 
     def __init__(self, weights, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512,
-                 vocab_size=None, cnn_cfg=VGG16_CFG, img_hw=(224, 224)):
-        if img_encoder not in ("vgg16",):
-            raise NotImplementedError("the img_encode is not valid, [vgg16]")     # explain_image.py:25-26
+                 vocab_size=None, cnn_cfg=VGG16_CFG, img_hw=(224, 224), resnet=None):
+        """img_encoder 'vgg16' (config.py:36-40: block5_conv3, 196 x 512) or 'resnet101' (config.py:41-45:
+        conv5_block3_out, 49 x 2048; `resnet` = dict(stem, stacks), default ResNet-101)."""
+        if img_encoder not in ("vgg16", "resnet101"):
+            raise NotImplementedError("the img_encode is not valid, [vgg16, resnet101]")     # explain_image.py:25-26
+        if img_encoder == "resnet101" and resnet is None:
+            from .synthetic import RESNET101_STACKS
+            resnet = {"stem": 64, "stacks": RESNET101_STACKS}
+        self.resnet = resnet if img_encoder == "resnet101" else None
         self.weights = dict(weights)
         self.img_encoder = img_encoder
         self._hidden_dim, self._embedding_dim = hidden_dim, embedding_dim
@@ -77,7 +83,8 @@ class ExplainImgCaptioningAttentionModel(object):
                                  D=model.D, H=model._hidden_dim, E=model._embedding_dim, V=model.vocab_size,
                                  max_images=max_images, max_tokens=max_images * Tm, max_caption_len=Tm,
                                  sos_id=self._preprocessor.SOS_TOKEN_LABEL_ENCODED,
-                                 eos_id=self._preprocessor.EOS_TOKEN_LABEL_ENCODED, device=device)
+                                 eos_id=self._preprocessor.EOS_TOKEN_LABEL_ENCODED, device=device,
+                                 resnet=getattr(model, "resnet", None))
         self._engine.set_weights(model.weights)
         self._CNN_explainer = _EngineAnalyzer(self._engine)      # LRPSequentialPresetA(image_model, EPS, 'replace'), E:32
         self._state_cache = {}

@@ -86,3 +86,31 @@ def test_config4_gridtd_plus_resnet_end_to_end():
     worst = max(rel_l1(out[t - 1], RN.analyze(w, spec, X, o.explain(t)[0])[0]) for t in (1, 2, 3))
     report("config4_small", max_rel_l1=worst)
     assert worst < TOL
+
+
+def test_reference_surface_with_resnet():
+    """ExplainImgCaptioningGridTDModel on a ResNet spec, and LRPSequentialPresetA.analyze([X, R]) with the
+    (h, w, 4f) head the reference hard-codes as (7,7,2048) (base.py:370-373)."""
+    from lrp_imagecaptioning_amd.analyzer import ImageModelSpec, LRPSequentialPresetA
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningGridTDModel
+    stacks, stem, hw, H, V, L, D = ((4, 2), (8, 2)), 8, 32, 32, 50, 16, 32
+    rs = np.random.RandomState(2)
+    w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    rn = {"stem": stem, "stacks": stacks}
+    X = rs.uniform(-120, 130, size=(1, hw, hw, 3)).astype(np.float32)
+    spec = RN.resnet_spec(stacks, stem=stem)
+    an = LRPSequentialPresetA(ImageModelSpec(w, img_hw=(hw, hw), resnet=rn), epsilon=0.01, neuron_selection_mode="replace")
+    feat = RN.forward(w, spec, X)
+    R = (rs.standard_normal(feat.shape) * feat).astype(np.float32)
+    assert rel_l1(an.analyze([X, R]), RN.analyze(w, spec, X, R)) < TOL
+    ex = ExplainImgCaptioningGridTDModel(
+        CaptionModelSpec(w, img_encoder="resnet101", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V, img_hw=(hw, hw),
+                         resnet=rn), None, None, max_caption_length=5)
+    cap = [9, 21, 1]
+    ex._forward_beam_search((None, X), cap)
+    rel, att = ex._explain_sentence()
+    o = GridTDOracle(w, L, D, H, H)
+    o.forward(feat.astype(np.float32), cap)
+    for i, Rf in enumerate(rel):
+        assert rel_l1(ex._explain_CNN(X, Rf), RN.analyze(w, spec, X, o.explain(i + 1)[0])) < TOL
