@@ -70,3 +70,14 @@ class LRPInferenceLayerAdaptive(object):
         """model.py:1675-1686 for the device tensor R (n,H,W,3), in liblrp_hip.so (lrp_heatmap_scores)."""
         from .engine import heatmap_scores
         return heatmap_scores(R, self._lrp_inference_mode).cpu().numpy()
+
+
+class LRPInferenceLayergridTD(LRPInferenceLayerAdaptive):
+    """models/model.py:1693-2062 (call() at :2013-2062): the same batch driver over the grid-TD engine — the
+    reference duplicates the whole class; here only the explainer handed in differs
+    (an `ExplainImgCaptioningGridTDModel`)."""
+
+    def __init__(self, explainer, lrp_inference_mode="mean", stop_words=(), color_conversion="BGRtoRGB"):
+        if getattr(explainer, "_decoder_kind", None) != "gridtd":
+            raise ValueError("LRPInferenceLayergridTD needs a grid-TD explainer")
+        super(LRPInferenceLayergridTD, self).__init__(explainer, lrp_inference_mode, stop_words, color_conversion)

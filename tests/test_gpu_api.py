@@ -192,3 +192,40 @@ def test_gridtd_explainer_class():
     np.testing.assert_allclose(ex.r_words, o.r_words, rtol=1e-4, atol=1e-9)
     with pytest.raises(NotImplementedError):
         ex._explain_lstm_single_word(1)
+
+
+def test_lrp_inference_layer_gridtd():
+    """model.py:2013-2062 over the grid-TD engine; and the class refuses an adaptive explainer."""
+    from lrp_imagecaptioning_amd.explainers import (CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention,
+                                                    ExplainImgCaptioningGridTDModel)
+    from lrp_imagecaptioning_amd.lrp_inference import LRPInferenceLayergridTD
+    from lrp_imagecaptioning_amd.postprocess import lrp_inference_score
+    from lrp_imagecaptioning_amd.synthetic import gridtd_weights
+    from oracle.decoder_ref import GridTDOracle
+    rs = np.random.RandomState(12)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V, cnn_cfg=CFG,
+                            img_hw=(HW, HW))
+    B, T = 2, 4
+    X = rs.uniform(-120, 130, size=(B, HW, HW, 3)).astype(np.float32)
+    y = rs.standard_normal((B, T, V))
+    y[1, 2, 0] = 50.0
+    ex = ExplainImgCaptioningGridTDModel(spec, None, None, max_caption_length=T, max_images=B)
+    got = LRPInferenceLayergridTD(ex, "pos_mean").call([None, X, y])
+    layers = C.vgg_layers(w, CFG)
+    want = np.zeros(y.shape)
+    for b in range(B):
+        cap = list(np.argmax(y[b], axis=-1) + 1)
+        full = [int(c) for c in (cap[:cap.index(1) + 1] if 1 in cap else cap + [1])]
+        o = GridTDOracle(w, L, D, H, H)
+        o.forward(C.forward(layers, X[b:b + 1]).astype(np.float32), full)
+        for i in range(T):
+            if cap[i] == 1:
+                break
+            if cap[i] < V:
+                want[b, i, cap[i]] = lrp_inference_score(C.analyze(layers, X[b:b + 1], o.explain(i + 1)[0]), "pos_mean")
+    np.testing.assert_allclose(got, 1 + want, rtol=2e-3, atol=2e-5)
+    w2, _ = _weights(8)
+    with pytest.raises(ValueError):
+        LRPInferenceLayergridTD(ExplainImgCaptioningAdaptiveAttention(_spec(w2), None, None, max_caption_length=T), "mean")
