@@ -190,7 +190,10 @@ int64_t lrp_workspace_bytes(const lrp_handle* h);
  * fp32 MFMA path.  w_hwio_host: (3,3,Cin,Cout) or (1,1,Cin,Cout).
  * mode 0: out = relu(conv + bias); mode 1: out = conv + bias;
  * mode 2: out = convT(in, w) * aux   (LRP backward with gate `aux`, shape of out)
- * mode 3: like 2 with 2x nearest up-sampling of the conv result (pool routing). */
+ * mode 3: like 2 with 2x nearest up-sampling of the conv result (pool routing).
+ * mode | LRP_CONV_SPLIT_BF16 (modes 1..3, channels % 8 == 0): the same operator on the split-bf16
+ * MFMA path the engine uses by default (three bf16 MFMAs per fp32 product); in/out stay float32. */
+enum { LRP_CONV_SPLIT_BF16 = 0x100 };
 int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias_host,
                 const float* aux_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
                 int32_t Cin, int32_t Cout, int32_t taps, int32_t mode, void* stream);

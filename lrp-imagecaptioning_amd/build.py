@@ -7,8 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblrp_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["common.h", "conv_igemm.h", "cnn_kernels.h", "encoder.h", "decoder_kernels.h", "decoder.h",
-           os.path.join("..", "..", "include", "lrp_hip.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "lrp_hip.h")]
 
 
 def needs_build():
@@ -24,7 +23,7 @@ def build_library(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", LIB] + os.environ.get("LRP_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[build]", " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

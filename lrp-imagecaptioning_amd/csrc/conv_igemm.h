@@ -75,6 +75,10 @@ struct ConvArgs {
   const int* row2img;  // per input image-slot n -> cache slot (nullptr = identity)
   int split;
   int out_plain;       // bf16x3 MUL epilogues: 1 = write fp32 instead of re-splitting (last GEMM of a chain)
+  // halo-resident 3x3 variant (template HALO): a tile is th rows x tw (<= 14) columns of the image stack
+  // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
+  // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
+  int tw, th, hrows, cols_t, nyh;
 };
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -86,15 +90,29 @@ __device__ __attribute__((aligned(16))) float lrp_zero_page[4] = {0.f, 0.f, 0.f,
 
 // waves per SIMD the register allocator must leave room for: LDS already limits a CU to
 // floor(160 KB / LDS per block) blocks of NW waves
-constexpr int conv_min_waves(int NW, int TM, int TN) { return NW == 8 ? 2 : (TM * TN >= 4 ? 2 : 3); }
+constexpr int conv_min_waves(int NW, int TM, int TN, bool halo = false) { return NW == 8 || halo ? 2 : (TM * TN >= 4 ? 2 : 3); }
 
-template <int WM, int WN, int TM, int TN, int EPI, int PREC>
-__global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void conv_igemm_kernel(ConvArgs a) {
+// HALO (3x3 only): instead of re-staging the A tile for each of the 9 taps (9 x BM rows per 32-channel
+// chunk, 8 of them L2 hits but still L2->LDS traffic, the limiter of the bf16x3 mode), the tile's pixels
+// PLUS their one-pixel halo are staged once per channel chunk and the taps read shifted rows of that
+// resident image.  A traffic per chunk: 9 x 256 rows -> 352 rows.
+// The resident image is a window of the EXTENDED stack: every image contributes its H rows plus one all-zero
+// separator row (extended row E = n*(H+1) + h, h == H is the separator), and columns x0-1 .. x0+tw with zeros
+// outside [0, W).  A pixel's 3x3 neighbourhood is then always at fixed offsets (dy*HALO_PITCH + dx) from it,
+// borders included: no per-lane tap masks in the main loop.  See DESIGN.md 4.1.
+constexpr int HALO_PITCH = 16, HALO_PL = 4;
+constexpr int conv_halo_rows(int BM) { return BM == 256 ? 352 : 192; }   // x 128 B; 22 / 12 image rows
+
+template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false>
+__global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
   constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;   // 1 KiB (8-row) DMA pieces per wave and chunk
-  constexpr int STAGE = (BM + BN) * LDS_STRIDE;
+  constexpr int HR = conv_halo_rows(BM);              // HALO: LDS rows (pixels) of the resident image
+  constexpr int ABUF = (HALO ? HR : BM) * LDS_STRIDE;
+  constexpr int STAGE = ABUF + BN * LDS_STRIDE;
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
+  static_assert(!HALO || EPI != EPI_STORE, "the image layer is a 1-tap GEMM");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
   // ---- XCD-aware block remap: the n_tiles blocks that share an A tile get
@@ -107,6 +125,21 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
   }
   const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
+  int Y0 = 0, x0 = 0, img0 = 0;                          // HALO: first stack row / column of the tile, its image
+  if constexpr (HALO) {
+    const int tyt = mt / a.cols_t;
+    Y0 = tyt * a.th;
+    x0 = (mt - tyt * a.cols_t) * a.tw;
+    img0 = Y0 / a.H;
+  }
+  // exact small-integer division (operands < 2^22): float estimate + one fix-up step
+  auto divmod = [](int x, int d, float inv, int& q, int& r) {
+    q = (int)(((float)x + 0.5f) * inv);
+    r = x - q * d;
+    if (r < 0) { --q; r += d; } else if (r >= d) { ++q; r -= d; }
+  };
+  const float inv_tw = HALO ? 1.0f / (float)a.tw : 0.f, inv_H = HALO ? 1.0f / (float)a.H : 0.f;
+  const float inv_H1 = HALO ? 1.0f / (float)(a.H + 1) : 0.f;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -122,10 +155,10 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
   // Wave w issues pieces w*AP .. w*AP+AP-1 of the A tile and w*BP .. of the B tile.
   const int prow = lane >> 3, pchk = lane & 7;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const float* aptr[AP];
-  unsigned amask[AP];
-  int alc[AP];                                         // logical chunk (x4 floats) this lane fetches for piece p
-  {
+  const float* aptr[HALO ? 1 : AP];
+  unsigned amask[HALO ? 1 : AP];
+  int alc[HALO ? 1 : AP];                              // logical chunk (x4 floats) this lane fetches for piece p
+  if constexpr (!HALO) {
     const int rfirst = wave_s * AP * 8 + prow;         // tile row of piece p = 0
     const int mfirst = m0 + rfirst;
     int rem = mfirst % HW;
@@ -163,23 +196,43 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   int tap = 0, cc = 0;                                 // position of the chunk being LOADED
-  auto issue_chunk = [&](int buf) {
+  // HALO: 8-row piece p of the resident image of channel chunk `chunk` -> A buffer `abuf`
+  const int halo_np = HALO ? a.hrows * (HALO_PITCH / 8) : 0;
+  auto issue_halo_piece = [&](int p, int chunk, int abuf) {
+    // piece p = half of resident row hy (wave-uniform): extended stack row E -> image n, row h (h == H: separator)
+    const int hy = p >> 1, hx = (p & 1) * 8 + prow;
+    const int E = Y0 + img0 - 1 + hy;
+    int n, h;
+    divmod(E < 0 ? 0 : E, a.H + 1, inv_H1, n, h);
+    const int x = x0 - 1 + hx;
+    const int lc = (pchk ^ (((hy * a.tw + hx - 1) >> 1) & 7)) << 2;   // halo swizzle, see set_tap
+    const int cfirst = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;
+    const bool ok = E >= 0 && h < a.H && n < a.NB && hx < a.tw + 2 && x >= 0 && x < a.W && (chunk << 5) + cfirst < a.Cin;
+    const float* src = ok ? a.in + ((size_t)(E - n) * a.W + x) * a.Cin + (chunk << 5) + lc : lrp_zero_page;
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + abuf * STAGE + p * 8 * LDS_STRIDE), 16, 0, 0);
+  };
+  // live = false: past the end of K — the same instructions run on the zero page (keeps the loop body branch-free)
+  auto issue_chunk = [&](int buf, bool live) {
     const int c0 = cc << 5;
     const int off = (a.taps == 1 ? 0 : ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * a.Cin) + c0;
     float* As = smem + buf * STAGE;
-    float* Bs = As + BM * LDS_STRIDE;
+    float* Bs = As + ABUF;
+    if constexpr (!HALO) {
 #pragma unroll
-    for (int p = 0; p < AP; ++p) {
-      // first channel covered by this lane's 16 B chunk: 4*chunk (fp32) or 8*(chunk/2) (split8 group)
-      const int cfirst = PREC == PREC_BF16X3 ? ((alc[p] >> 3) << 3) : alc[p];
-      const bool ok = ((amask[p] >> tap) & 1u) && (c0 + cfirst < a.Cin);
-      const float* src = ok ? aptr[p] + off : lrp_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave_s * AP + p) * 8 * LDS_STRIDE), 16, 0, 0);
+      for (int p = 0; p < AP; ++p) {
+        // first channel covered by this lane's 16 B chunk: 4*chunk (fp32) or 8*(chunk/2) (split8 group)
+        const int cfirst = PREC == PREC_BF16X3 ? ((alc[p] >> 3) << 3) : alc[p];
+        const bool ok = live && ((amask[p] >> tap) & 1u) && (c0 + cfirst < a.Cin);
+        const float* src = ok ? aptr[p] + off : lrp_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave_s * AP + p) * 8 * LDS_STRIDE), 16, 0, 0);
+      }
     }
     const int kofs = tap * a.CinP + c0;
 #pragma unroll
-    for (int p = 0; p < BP; ++p)
-      __builtin_amdgcn_global_load_lds((gptr_t)(bptr[p] + kofs), (lptr_t)(Bs + (wave_s * BP + p) * 8 * LDS_STRIDE), 16, 0, 0);
+    for (int p = 0; p < BP; ++p) {
+      const float* src = live ? bptr[p] + kofs : lrp_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (wave_s * BP + p) * 8 * LDS_STRIDE), 16, 0, 0);
+    }
     // taps innermost: the 9 taps of one 32-channel chunk touch the same ~(BM + halo) pixel rows
     // (24 KB), so 8 of 9 re-reads hit L1/L2; tap-major order streamed BM x Cin x 4 B per tap
     // through a 64 KB-per-block share of the XCD's L2 and missed on every tap (FETCH_SIZE 7x).
@@ -203,11 +256,58 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
         if constexpr (BLOCKED) tot[i][j][r] = 0.f;
       }
 
-  issue_chunk(0);
-  __syncthreads();                                     // (drains vmcnt: the DMA of chunk 0 has landed)
+  // DMA schedule: chunk kc+2 is launched right AFTER the barrier of iteration kc (the barrier proves every wave
+  // has finished reading buffer kc&1) and is waited for at the barrier of iteration kc+1, so a load has a whole
+  // iteration (48 MFMAs per wave on the 8-wave tile) to land — launching it at the top of iteration kc+1 instead
+  // left it half of that, which the HBM / MALL latency of the A rows did not fit into in the bf16x3 mode.
+  if constexpr (HALO) {
+    for (int p = wave_s; p < halo_np; p += NW) issue_halo_piece(p, 0, 0);
+    if (cpt > 1 && wave_s < halo_np) issue_halo_piece(wave_s, 1, 1);      // slot 0 of chunk 1 (see the loop)
+  }
+  issue_chunk(0, true);
+  issue_chunk(1, nk > 1);
+  // hipcc gives __syncthreads() an lgkmcnt(0) only; the LDS-DMA completes on vmcnt, so the wait is explicit
+  auto dma_landed_barrier = [] {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  dma_landed_barrier();
 
-  const int a_off = (wm * TM * 32 + (lane & 31)) * LDS_STRIDE;
-  const int b_off = BM * LDS_STRIDE + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE;
+  const int a_off = HALO ? 0 : (wm * TM * 32 + (lane & 31)) * LDS_STRIDE;
+  const int b_off = ABUF + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE;
+  // HALO: per A fragment row, the LDS row of its pixel in the resident image (padding rows of the tile read
+  // pixel (1,1): their C rows are never stored), and per tap the float offset of its first 16 B chunk
+  int fbase[HALO ? TM : 1], fu[HALO ? TM : 1], faddr[HALO ? TM : 1];
+  const int hh_ = lane >> 5;
+  if constexpr (HALO) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = (wm * TM + i) * 32 + (lane & 31);
+      int ty, tx, n_, h_;
+      divmod(r, a.tw, inv_tw, ty, tx);
+      const int Y = Y0 + ty;
+      divmod(Y, a.H, inv_H, n_, h_);
+      const bool ok = r < a.th * a.tw && Y < a.nyh && x0 + tx < a.W;
+      const int hy = ok ? ty + 1 + n_ - img0 : 1, hx = ok ? tx + 1 : 1;
+      fbase[i] = hy * HALO_PITCH + hx;
+      fu[i] = hy * a.tw + hx - 1;
+    }
+  }
+  auto tap_shift = [&](int t) { return (t / 3 - 1) * HALO_PITCH + (t % 3 - 1); };
+  // first chunk of lane-half hh at step 0 is 2hh (bf16x3: hi of split8 group hh) / hh (fp32); the others are XORs of it
+  // Halo swizzle: the 16 B chunk index is XORed with (u >> 1) & 7, u = hy*tw + hx - 1 = the pixel's index in the
+  // DENSE tile (the LDS rows have pitch 16 but only tw = 14 of them per image row are tile pixels).  The 32 lanes
+  // of a fragment read 32 consecutive tile pixels, i.e. consecutive u (shifted as a whole by the tap), and 16
+  // consecutive u give 16 distinct (row parity, chunk ^ swizzle) bank slots; the LDS-row based swizzle of the
+  // non-halo layout would collide on the two rows behind every wrap of tx.
+  auto set_tap = [&](int t) {
+    const int tsh = tap_shift(t), ush = (t / 3 - 1) * a.tw + (t % 3 - 1);
+#pragma unroll
+    for (int i = 0; i < (HALO ? TM : 0); ++i) {
+      const int row = fbase[i] + tsh, u = fu[i] + ush;
+      faddr[i] = row * LDS_STRIDE + ((((PREC == PREC_BF16X3 ? 2 : 1) * hh_) ^ ((u >> 1) & 7)) << 2);
+    }
+  };
   // Fragment registers are double-buffered one step ahead, and the first fragments of the NEXT
   // chunk are fetched right after the barrier: the last MFMA group of the current chunk runs on
   // registers while those reads are in flight.  (All reads of `buf` are issued AND completed
@@ -222,21 +322,35 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
     koff[q] = PREC == PREC_BF16X3 ? (((4 * (q >> 1) + 2 * hh + (q & 1)) ^ swz) << 2)     // q = 2*step + {hi,lo}
                                   : (((2 * q + hh) ^ swz) << 2);
   struct Frag { u32x4 a[PREC == PREC_BF16X3 ? 2 * TM : TM], b[PREC == PREC_BF16X3 ? 2 * TN : TN]; };
+  // HALO: A addresses come from faddr[] (set_tap); chunk c ^ swizzle = (c0 ^ swizzle) ^ (c - c0) for disjoint bits
   auto read_frag = [&](Frag& f, const float* Ab, const float* Bb, int st) {
-    if constexpr (PREC == PREC_BF16X3) {
+    if constexpr (HALO) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (PREC == PREC_BF16X3) {
+          f.a[2 * i] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ ((4 * st) << 2)));
+          f.a[2 * i + 1] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ ((4 * st + 1) << 2)));
+        } else {
+          f.a[i] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ ((2 * st) << 2)));
+        }
+      }
+    } else if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         f.a[2 * i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[2 * st]);
         f.a[2 * i + 1] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[2 * st + 1]);
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[st]);
+    }
+    if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         f.b[2 * j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st]);
         f.b[2 * j + 1] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st + 1]);
       }
     } else {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[st]);
 #pragma unroll
       for (int j = 0; j < TN; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[st]);
     }
@@ -266,14 +380,14 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
   };
 
   Frag f0, f1;
+  int ctap = 0, ccc = 0;                               // HALO: (tap, channel chunk) being COMPUTED; kc = ccc*9 + ctap
+  set_tap(0);
   read_frag(f0, smem + a_off, smem + b_off, 0);
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
-    // The other LDS buffer is free for the whole iteration, so the DMA of chunk kc+1 is launched
-    // first and has the whole chunk to land; the barrier below waits for it (vmcnt(0)).
-    if (more) issue_chunk(buf ^ 1);
-    const float* Ab = smem + buf * STAGE + a_off;
+    const int abuf = HALO ? (ccc & 1) : buf;
+    const float* Ab = smem + abuf * STAGE + a_off;
     const float* Bb = smem + buf * STAGE + b_off;
     if constexpr (NSTEP == 4) {
       read_frag(f1, Ab, Bb, 1);
@@ -286,8 +400,28 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
       read_frag(f1, Ab, Bb, 1);
       mfma_frag(f0);                                   // step 0
     }
-    __syncthreads();
-    if (more) read_frag(f0, smem + (buf ^ 1) * STAGE + a_off, smem + (buf ^ 1) * STAGE + b_off, 0);
+    dma_landed_barrier();                              // reads of `buf` done everywhere; DMA of chunk kc+1 landed
+    issue_chunk(buf, kc + 2 < nk);
+    if constexpr (HALO) {
+      if (++ctap == 9) { ctap = 0; ++ccc; }
+      // the resident image of the NEXT channel chunk trickles in over this chunk's taps: slot ctap = one piece
+      // per wave; its buffer was last read in the chunk before this one
+      const int p = ctap * NW + wave_s;
+      if (more && ccc + 1 < cpt && p < halo_np) issue_halo_piece(p, ccc + 1, (ccc & 1) ^ 1);
+    }
+    // keep the MFMAs below the DMA launch: without this the compiler hoists all of them above it (they do not
+    // depend on it) and the loads start ~24 MFMA issue slots later
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));
+    // (on the last iteration this reads a stale buffer into registers nobody uses)
+    if constexpr (HALO) {
+      set_tap(ctap);
+      read_frag(f0, smem + (ccc & 1) * STAGE, smem + (buf ^ 1) * STAGE + b_off, 0);
+    } else {
+      read_frag(f0, smem + (buf ^ 1) * STAGE + a_off, smem + (buf ^ 1) * STAGE + b_off, 0);
+    }
     mfma_frag(f1);                                     // last step
     if constexpr (BLOCKED) {
       if ((kc & (FLUSH - 1)) == FLUSH - 1) {
@@ -302,7 +436,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
       }
     }
   }
-  __syncthreads();                                     // LDS is reused by the epilogue
+  dma_landed_barrier();                                // LDS is reused by the epilogue (and the tail DMAs of zeros are in)
   if constexpr (BLOCKED) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -326,6 +460,31 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
     const int col = n0 + c4 * CW;
     const int tn0 = m0 / HW, tp0 = m0 - tn0 * HW;
     const float invw = 1.0f / (float)a.W;
+    // tile row lr -> linear NHWC row / image slot n / pixel (h, w); false = padding row
+    auto locate = [&](int lr, int& row, int& n, int& h, int& w) -> bool {
+      if constexpr (HALO) {
+        int ty, tx;
+        divmod(lr, a.tw, inv_tw, ty, tx);
+        const int Y = Y0 + ty;
+        w = x0 + tx;
+        if (lr >= a.th * a.tw || Y >= a.nyh || w >= a.W) return false;
+        divmod(Y, a.H, inv_H, n, h);
+        row = Y * a.W + w;
+        return true;
+      } else {
+        row = m0 + lr;
+        if (row >= a.M) return false;
+        if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
+          n = tn0;
+          int pix = tp0 + lr;
+          while (pix >= HW) { pix -= HW; ++n; }
+          h = (int)(((float)pix + 0.5f) * invw);
+          w = pix - h * a.W;
+          if (w < 0) { --h; w += a.W; } else if (w >= a.W) { ++h; w -= a.W; }
+        }
+        return true;
+      }
+    };
 #pragma unroll 1
     for (int hf = 0; hf < NH; ++hf) {
       if (hf) __syncthreads();                          // previous slab fully consumed
@@ -345,8 +504,9 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
           const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
 #pragma unroll 4
           for (int ps = 0; ps < RH / RPP; ++ps) {
-            const int ll = rin + ps * RPP, row = m0 + hf * RH + ll;
-            if (row >= a.M) break;
+            const int ll = rin + ps * RPP;
+            int row, n_, h_, w_;
+            if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
             if constexpr (EPI == EPI_BIAS_RELU) {
 #pragma unroll
@@ -364,8 +524,9 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
           float* dst = (isz ? a.out2 : a.out) + c;
 #pragma unroll 4
           for (int ps = 0; ps < RH / RPP; ++ps) {
-            const int ll = rin + ps * RPP, row = m0 + hf * RH + ll;
-            if (row >= a.M) break;
+            const int ll = rin + ps * RPP;
+            int row, n_, h_, w_;
+            if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
             if (!isz) {
 #pragma unroll
@@ -378,14 +539,14 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
         if (col < a.N) {
 #pragma unroll 4
           for (int ps = 0; ps < RH / RPP; ++ps) {
-            const int ll = rin + ps * RPP, lr = hf * RH + ll, row = m0 + lr;
-            if (row >= a.M) break;
+            const int ll = rin + ps * RPP;
+            int row, n, h, w;
+            if (!locate(hf * RH + ll, row, n, h, w)) continue;
             float v[CW];
 #pragma unroll
             for (int q4 = 0; q4 < CW / 4; ++q4)
               *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * CW + 4 * q4);
-            int n = tn0, pix = tp0 + lr;
-            while (pix >= HW) { pix -= HW; ++n; }
+            const int pix = h * a.W + w;
             const int img = a.row2img ? a.row2img[n] : n;
             // out = acc * gate (fp32), stored as fp32 or re-split into [hi8 | lo8] for the next layer's MFMAs
             auto emit = [&](const float* gsrc, float* dst) {
@@ -410,9 +571,6 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN)) void
             if constexpr (EPI == EPI_MUL) {
               emit(a.aux + ((size_t)img * HW + pix) * a.N + col, a.out + (size_t)row * a.N + col);
             } else {
-              int h = (int)(((float)pix + 0.5f) * invw);
-              int w = pix - h * a.W;
-              if (w < 0) { --h; w += a.W; } else if (w >= a.W) { ++h; w -= a.W; }
               const int W2 = 2 * a.W, H2 = 2 * a.H;
 #pragma unroll
               for (int q = 0; q < 4; ++q)
@@ -469,6 +627,28 @@ inline int conv_tile_override() {
   return v;
 }
 
+// halo-resident variant: env LRP_CONV_HALO = 0 never, 1 (default) when a tile shape fills >= 90 % of the M tile,
+// 2 always (tests: ragged tile shapes).  Read per launch so a test can flip it.
+inline int conv_halo_mode() {
+  const char* e = getenv("LRP_CONV_HALO");
+  return e ? atoi(e) : 1;
+}
+// best (tw, th, pitch) for a BM-row tile on an H x W image stack; returns the fraction of MFMA rows doing real work
+inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) {
+  const int avail = conv_halo_rows(BM) / HALO_PITCH;   // resident image rows that fit
+  float best = 0.f;
+  for (int c = 1; c <= HALO_PITCH - 2 && c <= W; ++c) {
+    // th stack rows cross at most ceil((th-1)/H) image boundaries, each costing one separator row
+    int t = BM / c;
+    while (t > 0 && t + 2 + (t - 1 + H - 1) / H > avail) --t;
+    if (t < 1) continue;
+    const int cols = (W + c - 1) / c;
+    const float u = (float)(t * c) / (float)BM * (float)W / (float)(cols * c);
+    if (u > best + 1e-6f) { best = u; tw = c; th = t; hrows = t + 2 + (t - 1 + H - 1) / H; }
+  }
+  return best;
+}
+
 template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
@@ -491,8 +671,29 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.M = a.NB * a.H * a.W;
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
-  const dim3 grid(a.m_tiles * a.n_tiles);
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if constexpr (PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS)) {
+    const int mode = conv_halo_mode();
+    // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
+    // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
+    if (a.taps == 9 && mode > 0 && (t.BN >= 128 || (mode == 2 && t.BN >= 64)) && wide != 128) {
+      const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
+      if (u >= 0.9f || (mode == 2 && u > 0.f)) {
+        a.nyh = a.NB * a.H;
+        a.cols_t = (a.W + a.tw - 1) / a.tw;
+        a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+        const dim3 hgrid(a.m_tiles * a.n_tiles);
+        if (wide == 256)
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true>), hgrid, dim3(512), 0, st, a);
+        else if (t.BN == 128)
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true>), hgrid, dim3(256), 0, st, a);
+        else
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true>), hgrid, dim3(256), 0, st, a);
+        return hipGetLastError();
+      }
+    }
+  }
+  const dim3 grid(a.m_tiles * a.n_tiles);
   if constexpr (PREC == PREC_BF16X3) {
     if (wide == 256) {
       hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC>), grid, dim3(512), 0, st, a);

@@ -240,7 +240,10 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
   if (!in_dev || !w_hwio_host || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
   if (taps != 1 && taps != 9) return fail(LRP_ERR_INVALID, "taps must be 1 or 9");
   if (Cin % 4 != 0) return fail(LRP_ERR_UNSUPPORTED, "Cin must be a multiple of 4");
+  const bool split = (mode & LRP_CONV_SPLIT_BF16) != 0;   // same op on the split-bf16 MFMA path (fp32 in, fp32 out)
+  mode &= ~LRP_CONV_SPLIT_BF16;
   if (mode < 0 || mode > 3) return fail(LRP_ERR_INVALID, "mode must be 0..3");
+  if (split && mode == 0) return fail(LRP_ERR_UNSUPPORTED, "the split-bf16 path has no relu epilogue (modes 1..3)");
   const bool bwd = mode >= 2;
   // forward: in has Cin channels, out Cout.  backward: in has Cout channels (S), out Cin (relevance of the input)
   const int inC = bwd ? Cout : Cin, outC = bwd ? Cin : Cout;
@@ -249,10 +252,22 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
   std::vector<float> pk((size_t)Np * K, 0.f);
   if (bwd) pack_conv_bwd(w_hwio_host, taps, Cin, Cout, 0, pk.data());
   else pack_conv_fwd(w_hwio_host, taps, Cin, Cout, 0, Np, pk.data());
-  DevBuf wdev, bdev;
+  DevBuf wdev, bdev, insplit;
+  if (split) {
+    if ((inC & 7) || (bwd && (outC & 7))) return fail(LRP_ERR_UNSUPPORTED, "split-bf16 path: channels must be multiples of 8");
+    std::vector<float> sp(pk.size());
+    pack_split8(pk.data(), pk.size(), sp.data());
+    pk.swap(sp);
+    const size_t n8 = (size_t)NB * H * W * inC / 8;
+    LRP_TRY(insplit.alloc(n8 * 32, nullptr));
+    hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, S(stream), in_dev, insplit.as<float>(), n8);
+    LRP_HIP_CHECK(hipGetLastError());
+    in_dev = insplit.as<float>();
+  }
   LRP_TRY(wdev.alloc(pk.size() * sizeof(float), nullptr));
   LRP_HIP_CHECK(hipMemcpy(wdev.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
   ConvArgs ca{};
+  ca.out_plain = 1;
   ca.in = in_dev; ca.wpk = wdev.as<float>(); ca.NB = NB; ca.H = H; ca.W = W; ca.Cin = inC; ca.CinP = conv_cinp(inC);
   ca.N = outC; ca.taps = taps; ca.out = out_dev; ca.aux = aux_dev;
   if (!bwd) {
@@ -264,7 +279,7 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
     return fail(LRP_ERR_INVALID, "aux (gate) required for backward modes");
   }
   static const int epi_of_mode[4] = {EPI_BIAS_RELU, EPI_BIAS, EPI_MUL, EPI_MUL_UP2};
-  LRP_HIP_CHECK(conv_launch(epi_of_mode[mode], ca, S(stream)));
+  LRP_HIP_CHECK(conv_launch(epi_of_mode[mode], ca, S(stream), split ? PREC_BF16X3 : PREC_FP32));
   LRP_HIP_CHECK(hipStreamSynchronize(S(stream)));      // weights are freed on return
   return LRP_OK;
 }

@@ -244,8 +244,12 @@ def _profile_records(self, cap=256):
 LRPEngine.profile_records = _profile_records
 
 
-def op_conv(x, w_hwio, bias, aux, mode, taps=9):
-    """Operator-level entry for unit tests of the MFMA conv kernel (see lrp_op_conv)."""
+CONV_SPLIT_BF16 = 0x100
+
+
+def op_conv(x, w_hwio, bias, aux, mode, taps=9, split_bf16=False):
+    """Operator-level entry for unit tests of the MFMA conv kernel (see lrp_op_conv); split_bf16 runs the
+    same operator on the split-bf16 path (LRP_CONV_SPLIT_BF16)."""
     lib = _capi.load()
     dev = x.device
     w = np.ascontiguousarray(w_hwio, dtype=np.float32)
@@ -262,7 +266,8 @@ def op_conv(x, w_hwio, bias, aux, mode, taps=9):
     _capi.check(lib.lrp_op_conv(C.c_void_p(x.data_ptr()), w.ctypes.data_as(C.c_void_p),
                                 b.ctypes.data_as(C.c_void_p) if b is not None else None,
                                 C.c_void_p(aux.data_ptr()) if aux is not None else None,
-                                C.c_void_p(out.data_ptr()), NB, H, W, Cin, Cout, taps, mode,
+                                C.c_void_p(out.data_ptr()), NB, H, W, Cin, Cout, taps,
+                                mode | (CONV_SPLIT_BF16 if split_bf16 else 0),
                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     return out
 

@@ -101,3 +101,57 @@ def test_identity_weight_asymmetric():
     ref = x.copy()
     ref[..., 5] += 2.0 * x[..., 3]
     np.testing.assert_allclose(out, ref, rtol=1e-6, atol=1e-6)
+
+
+# ---- split-bf16 path, incl. the halo-resident 3x3 variant (LRP_CONV_HALO: 0 never, 1 auto, 2 always)
+SPLIT_CASES = [  # NB, H, W, Cin, Cout   (forward: Cin -> Cout; backward: S has Cout channels, out has Cin)
+    (3, 14, 14, 64, 128),     # tw = 14: tiles span image boundaries in the stack
+    (2, 28, 28, 40, 64),      # tw = 14 on W = 28 (BM = 128), Cin not a multiple of 32
+    (1, 56, 56, 8, 128),      # two column tiles per row
+    (2, 7, 5, 72, 64),        # W < every candidate: ragged columns, tiny image
+    (1, 9, 33, 16, 128),      # W = 33 = 3 x 11
+    (2, 16, 16, 64, 64),      # power-of-two width (the halo pitch equals tw + 2 only for 14 / 30)
+    (33, 56, 56, 8, 256),     # 8-wave 256 x 256 tile (>= 400 blocks), tw = 28
+    (140, 14, 14, 16, 256),   # 8-wave tile on 14 x 14 images: 18 stack rows per tile, ~1.3 images
+]
+
+
+@pytest.fixture(params=["0", "1", "2"])
+def halo_mode(request, monkeypatch):
+    monkeypatch.setenv("LRP_CONV_HALO", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_split_bf16_forward(case, halo_mode):
+    from lrp_imagecaptioning_amd.engine import op_conv
+    NB, H, W, Cin, Cout = case
+    rs = np.random.RandomState(sum(case))
+    x = rs.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rs.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32)
+    out = op_conv(torch.as_tensor(x).cuda(), w, b, None, 1, 9, split_bf16=True).cpu().numpy()
+    err = rel_l1(out, _ref_conv(x, w, b, 9, relu=False))
+    report("conv_split_fwd", case=list(case), halo=halo_mode, rel_l1=err)
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+@pytest.mark.parametrize("mode", [2, 3])
+def test_split_bf16_lrp_backward(case, mode, halo_mode):
+    from lrp_imagecaptioning_amd.engine import op_conv
+    NB, H, W, Cin, Cout = case
+    if mode == 3 and NB * H * W > 50000:
+        NB = max(1, NB // 4)          # the 2x-resolution gate of the pool mode is 4x the pixels
+    rs = np.random.RandomState(sum(case) + mode)
+    s = rs.standard_normal((NB, H, W, Cout)).astype(np.float32)
+    w = np.abs(rs.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    up = 2 if mode == 3 else 1
+    gate = rs.uniform(0, 1, size=(NB, up * H, up * W, Cin)).astype(np.float32)
+    out = op_conv(torch.as_tensor(s).cuda(), w, None, torch.as_tensor(gate).cuda(), mode, 9, split_bf16=True).cpu().numpy()
+    c = _ref_convT(s, w, 9)
+    if mode == 3:
+        c = c.repeat(2, axis=1).repeat(2, axis=2)
+    err = rel_l1(out, c * gate)
+    report("conv_split_bwd", case=list(case), mode=mode, halo=halo_mode, rel_l1=err)
+    assert err < 2e-5, err
