@@ -105,6 +105,7 @@ constexpr int conv_halo_rows(int BM) { return BM == 256 ? 352 : 192; }   // x 12
 
 template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false>
 __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;   // 1 KiB (8-row) DMA pieces per wave and chunk
@@ -148,16 +149,35 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   const int cpt = a.CinP >> 5;                         // 32-wide k chunks per tap
   const int nk = a.taps * cpt;
 
-  // ---- staging: global -> LDS directly (global_load_lds_dwordx4), no VGPR round trip.
+  // ---- staging: global -> LDS directly (buffer_load_dwordx4 ... lds), no VGPR round trip.
   // One wave instruction moves 64 x 16 B = 1 KiB = 8 staged rows; the LDS side is linear
-  // (M0 base + lane*16), so the XOR swizzle is applied on the per-lane SOURCE address: lane i of
+  // (M0 base + lane*16), so the XOR swizzle is applied on the per-lane SOURCE offset: lane i of
   // piece q fills row 8q + (i>>3), physical chunk i&7, with logical chunk (i&7) ^ ((row>>1)&7).
   // Wave w issues pieces w*AP .. w*AP+AP-1 of the A tile and w*BP .. of the B tile.
+  // Buffer addressing = SGPR base (the descriptor) + SGPR offset (tap / channel chunk: wave-uniform) + one
+  // 32-bit VGPR offset per lane that never changes; out-of-image taps, ragged tails and padded channels set the
+  // VGPR offset to a value beyond num_records and the hardware writes zeros — no pointer selects, no 64-bit
+  // VALU adds, no branches in the loop.  Descriptors are rebased per block, so tensors > 4 GiB are fine.
   const int prow = lane >> 3, pchk = lane & 7;
   const int wave_s = __builtin_amdgcn_readfirstlane(wave);
-  const float* aptr[HALO ? 1 : AP];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int OOB = (int)0x80000000;                 // >= any num_records used here
+  constexpr int RSRC_FLAGS = 0x00020000;               // raw buffer, DATA_FORMAT_32 (gfx9 V# dword 3)
+  const __amdgpu_buffer_rsrc_t rsB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)n0 * K), 0, BN * K * 4, RSRC_FLAGS);
+  int bvo[BP];
+#pragma unroll
+  for (int p = 0; p < BP; ++p) {
+    const int r = (wave_s * BP + p) * 8 + prow;
+    bvo[p] = (r * K + ((pchk ^ ((r >> 1) & 7)) << 2)) * 4;
+  }
+  // A, non-HALO: descriptor base = pixel (m0 - W - 1), so that every tap offset is >= 0
+  const float* abase = HALO ? a.in + (size_t)(Y0 > 0 ? Y0 - 1 : 0) * a.W * a.Cin
+                            : a.in + ((long)m0 - (a.taps == 1 ? 0 : a.W + 1)) * (long)a.Cin;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7FFFFFFF, RSRC_FLAGS);
+  int avo[HALO ? 1 : AP];
   unsigned amask[HALO ? 1 : AP];
-  int alc[HALO ? 1 : AP];                              // logical chunk (x4 floats) this lane fetches for piece p
+  int acf[HALO ? 1 : AP];                              // first channel (within a 32-chunk) of this lane's 16 B
   if constexpr (!HALO) {
     const int rfirst = wave_s * AP * 8 + prow;         // tile row of piece p = 0
     const int mfirst = m0 + rfirst;
@@ -177,8 +197,9 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
         }
       }
       amask[p] = mask;
-      alc[p] = (pchk ^ ((r >> 1) & 7)) << 2;
-      aptr[p] = a.in + (size_t)m * a.Cin + alc[p];
+      const int lc = (pchk ^ ((r >> 1) & 7)) << 2;
+      acf[p] = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;   // 4*chunk (fp32) or 8*(chunk/2) (split8 group)
+      avo[p] = (r * a.Cin + lc) * 4;
       if (a.taps != 1) {                                  // next piece: 8 pixels further
         w += 8;
         while (w >= a.W) { w -= a.W; ++h; }
@@ -186,20 +207,13 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
       }
     }
   }
-  const float* bptr[BP];
-#pragma unroll
-  for (int p = 0; p < BP; ++p) {
-    const int r = (wave_s * BP + p) * 8 + prow;
-    bptr[p] = a.wpk + (size_t)(n0 + r) * K + ((pchk ^ ((r >> 1) & 7)) << 2);
-  }
 
-  typedef __attribute__((address_space(1))) const void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
   int tap = 0, cc = 0;                                 // position of the chunk being LOADED
-  // HALO: 8-row piece p of the resident image of channel chunk `chunk` -> A buffer `abuf`
+  // HALO: 8-row piece p of the resident image of channel chunk `chunk` -> A buffer `abuf`.
+  // piece p = half of resident row hy (wave-uniform): extended stack row E -> image n, row h (h == H: separator)
   const int halo_np = HALO ? a.hrows * (HALO_PITCH / 8) : 0;
-  auto issue_halo_piece = [&](int p, int chunk, int abuf) {
-    // piece p = half of resident row hy (wave-uniform): extended stack row E -> image n, row h (h == H: separator)
+  struct HaloPiece { int vo, so; };
+  auto prep_halo_piece = [&](int p, int chunk, bool live) {
     const int hy = p >> 1, hx = (p & 1) * 8 + prow;
     const int E = Y0 + img0 - 1 + hy;
     int n, h;
@@ -207,36 +221,49 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
     const int x = x0 - 1 + hx;
     const int lc = (pchk ^ (((hy * a.tw + hx - 1) >> 1) & 7)) << 2;   // halo swizzle, see set_tap
     const int cfirst = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;
-    const bool ok = E >= 0 && h < a.H && n < a.NB && hx < a.tw + 2 && x >= 0 && x < a.W && (chunk << 5) + cfirst < a.Cin;
-    const float* src = ok ? a.in + ((size_t)(E - n) * a.W + x) * a.Cin + (chunk << 5) + lc : lrp_zero_page;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + abuf * STAGE + p * 8 * LDS_STRIDE), 16, 0, 0);
+    const bool ok = live && E >= 0 && h < a.H && n < a.NB && hx < a.tw + 2 && x >= 0 && x < a.W && (chunk << 5) + cfirst < a.Cin;
+    HaloPiece r;
+    r.vo = ok ? (x * a.Cin + lc) * 4 : OOB;
+    // (n comes out of float math = VALU; the offset is wave-uniform and must reach the instruction in an SGPR)
+    const int so = (((E - n) - (Y0 > 0 ? Y0 - 1 : 0)) * a.W * a.Cin + (chunk << 5)) * 4;
+    r.so = __builtin_amdgcn_readfirstlane(so < 0 ? 0 : so);
+    return r;
   };
-  // live = false: past the end of K — the same instructions run on the zero page (keeps the loop body branch-free)
-  auto issue_chunk = [&](int buf, bool live) {
+  auto fire_halo_piece = [&](const HaloPiece& hp, int p, int abuf) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(smem + abuf * STAGE + p * 8 * LDS_STRIDE), 16, hp.vo, hp.so, 0, 0);
+  };
+  // prep: per-lane offsets of the chunk at (tap, cc) (cheap VALU, placed BEFORE the barrier where it overlaps the
+  // MFMAs still in flight); fire: the DMA instructions themselves, right after the barrier.
+  struct ChunkPrep { int avo[HALO ? 1 : AP]; int aso, bso; };
+  auto prep_chunk = [&](bool live) {
+    ChunkPrep c;
     const int c0 = cc << 5;
-    const int off = (a.taps == 1 ? 0 : ((tap / 3 - 1) * a.W + (tap % 3 - 1)) * a.Cin) + c0;
-    float* As = smem + buf * STAGE;
-    float* Bs = As + ABUF;
     if constexpr (!HALO) {
 #pragma unroll
       for (int p = 0; p < AP; ++p) {
-        // first channel covered by this lane's 16 B chunk: 4*chunk (fp32) or 8*(chunk/2) (split8 group)
-        const int cfirst = PREC == PREC_BF16X3 ? ((alc[p] >> 3) << 3) : alc[p];
-        const bool ok = live && ((amask[p] >> tap) & 1u) && (c0 + cfirst < a.Cin);
-        const float* src = ok ? aptr[p] + off : lrp_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave_s * AP + p) * 8 * LDS_STRIDE), 16, 0, 0);
+        const bool ok = live && ((amask[p] >> tap) & 1u) && (c0 + acf[p] < a.Cin);
+        c.avo[p] = ok ? avo[p] : OOB;
       }
     }
-    const int kofs = tap * a.CinP + c0;
-#pragma unroll
-    for (int p = 0; p < BP; ++p) {
-      const float* src = live ? bptr[p] + kofs : lrp_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (wave_s * BP + p) * 8 * LDS_STRIDE), 16, 0, 0);
-    }
+    c.aso = ((a.taps == 1 ? 0 : (tap / 3) * a.W + (tap % 3)) * a.Cin + c0) * 4;
+    c.bso = live ? (tap * a.CinP + c0) * 4 : 0;
     // taps innermost: the 9 taps of one 32-channel chunk touch the same ~(BM + halo) pixel rows
     // (24 KB), so 8 of 9 re-reads hit L1/L2; tap-major order streamed BM x Cin x 4 B per tap
     // through a 64 KB-per-block share of the XCD's L2 and missed on every tap (FETCH_SIZE 7x).
     if (++tap == a.taps) { tap = 0; ++cc; }
+    return c;
+  };
+  auto fire_chunk = [&](const ChunkPrep& c, int buf) {
+    float* As = smem + buf * STAGE;
+    float* Bs = As + ABUF;
+    if constexpr (!HALO) {
+#pragma unroll
+      for (int p = 0; p < AP; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + (wave_s * AP + p) * 8 * LDS_STRIDE), 16, c.avo[p], c.aso, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < BP; ++p)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lptr_t)(Bs + (wave_s * BP + p) * 8 * LDS_STRIDE), 16, bvo[p], c.bso, 0, 0);
   };
 
   // Two-level (blocked) summation: the MFMA is a strictly k-ordered fp32 fma chain, so a
@@ -261,11 +288,11 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   // iteration (48 MFMAs per wave on the 8-wave tile) to land — launching it at the top of iteration kc+1 instead
   // left it half of that, which the HBM / MALL latency of the A rows did not fit into in the bf16x3 mode.
   if constexpr (HALO) {
-    for (int p = wave_s; p < halo_np; p += NW) issue_halo_piece(p, 0, 0);
-    if (cpt > 1 && wave_s < halo_np) issue_halo_piece(wave_s, 1, 1);      // slot 0 of chunk 1 (see the loop)
+    for (int p = wave_s; p < halo_np; p += NW) fire_halo_piece(prep_halo_piece(p, 0, true), p, 0);
+    if (wave_s < halo_np) fire_halo_piece(prep_halo_piece(wave_s, 1, cpt > 1), wave_s, 1);   // slot 0 of chunk 1 (see the loop)
   }
-  issue_chunk(0, true);
-  issue_chunk(1, nk > 1);
+  fire_chunk(prep_chunk(true), 0);
+  fire_chunk(prep_chunk(nk > 1), 1);
   // hipcc gives __syncthreads() an lgkmcnt(0) only; the LDS-DMA completes on vmcnt, so the wait is explicit
   auto dma_landed_barrier = [] {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -400,14 +427,21 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
       read_frag(f1, Ab, Bb, 1);
       mfma_frag(f0);                                   // step 0
     }
-    dma_landed_barrier();                              // reads of `buf` done everywhere; DMA of chunk kc+1 landed
-    issue_chunk(buf, kc + 2 < nk);
+    // offsets of chunk kc+2 (-> `buf`) and, HALO, of this tap slot's piece of the next channel chunk's resident
+    // image (slot = one piece per wave; that A buffer was last read in the chunk before this one)
+    const ChunkPrep cp = prep_chunk(kc + 2 < nk);
+    HaloPiece hp{};
+    int hpp = 0;
     if constexpr (HALO) {
       if (++ctap == 9) { ctap = 0; ++ccc; }
-      // the resident image of the NEXT channel chunk trickles in over this chunk's taps: slot ctap = one piece
-      // per wave; its buffer was last read in the chunk before this one
-      const int p = ctap * NW + wave_s;
-      if (more && ccc + 1 < cpt && p < halo_np) issue_halo_piece(p, ccc + 1, (ccc & 1) ^ 1);
+      hpp = ctap * NW + wave_s;
+      if (hpp >= halo_np) hpp = -1;
+      hp = prep_halo_piece(hpp < 0 ? 0 : hpp, ccc + 1, more && ccc + 1 < cpt);
+    }
+    dma_landed_barrier();                              // reads of `buf` done everywhere; DMA of chunk kc+1 landed
+    fire_chunk(cp, buf);
+    if constexpr (HALO) {
+      if (hpp >= 0 && more && ccc + 1 < cpt) fire_halo_piece(hp, hpp, (ccc & 1) ^ 1);
     }
     // keep the MFMAs below the DMA launch: without this the compiler hoists all of them above it (they do not
     // depend on it) and the loads start ~24 MFMA issue slots later
@@ -602,6 +636,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
       }
     }
   }
+#endif
 }
 
 // tile configurations: (WM,WN,TM,TN) -> BM x BN

@@ -10,7 +10,7 @@ import shutil
 import sys
 
 
-def agg(path, key_len=80):
+def agg(path, key_len=120):
     out = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
