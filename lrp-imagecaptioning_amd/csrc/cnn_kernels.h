@@ -35,8 +35,8 @@ __global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restri
 }
 
 // No pool after layer l:  G_l = a_l / safe(Z_l)     (x_{l+1} = a_l)
-__global__ __launch_bounds__(256) void gate_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ z,
-                                                   f32x4* __restrict__ g, size_t n4) {
+// (a and g may be the same buffer: the overlapped encode keeps a_l in the gate's storage until the gate is due)
+__global__ __launch_bounds__(256) void gate_kernel(const f32x4* a, const f32x4* __restrict__ z, f32x4* g, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const f32x4 av = a[i], zv = z[i];
     f32x4 o;
@@ -48,8 +48,10 @@ __global__ __launch_bounds__(256) void gate_kernel(const f32x4* __restrict__ a, 
 
 // 2x2/2 max-pool after layer l:  x_{l+1} = pool(a_l);  G_l = [first arg-max of the window] * a_l / safe(Z_l)
 // (MaxPooling2D relevance = gradient routing, RA:470-480 -> layers.py:138-157)
-__global__ __launch_bounds__(256) void pool_gate_kernel(const float* __restrict__ a, const float* __restrict__ z,
-                                                        float* __restrict__ xnext, float* __restrict__ g,
+// xnext == nullptr: gate only (the pooled activations were produced earlier by maxpool2_kernel); a may alias g
+// (a thread reads its whole 2x2 window before it writes any of it).
+__global__ __launch_bounds__(256) void pool_gate_kernel(const float* a, const float* __restrict__ z,
+                                                        float* __restrict__ xnext, float* g,
                                                         int NB, int H, int W, int C) {
   const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)NB * Ho * Wo * C4;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void pool_gate_kernel(const float* __restrict_
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (av[p][c] > mx[c]) { mx[c] = av[p][c]; arg[c] = p; }
-    *reinterpret_cast<f32x4*>(xnext + (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4) = mx;
+    if (xnext) *reinterpret_cast<f32x4*>(xnext + (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4) = mx;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       f32x4 o;
@@ -83,6 +85,28 @@ __global__ __launch_bounds__(256) void pool_gate_kernel(const float* __restrict_
       for (int c = 0; c < 4; ++c) o[c] = (arg[c] == p) ? av[p][c] / safe_den(zv[p][c]) : 0.f;
       *reinterpret_cast<f32x4*>(g + off[p]) = o;
     }
+  }
+}
+
+// plain 2x2/2 max-pool (the forward chain of the overlapped encode; the arg-max mask is recomputed by pool_gate_kernel)
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ a, float* __restrict__ xnext,
+                                                       int NB, int H, int W, int C) {
+  const int C4 = C >> 2, Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)NB * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float* p0 = a + ((((size_t)n * H + 2 * ho) * W + 2 * wo) * C) + 4 * c4;
+    f32x4 mx = *reinterpret_cast<const f32x4*>(p0);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(p0 + C), v2 = *reinterpret_cast<const f32x4*>(p0 + (size_t)W * C),
+                v3 = *reinterpret_cast<const f32x4*>(p0 + (size_t)W * C + C);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mx[c] = fmaxf(fmaxf(mx[c], v1[c]), fmaxf(v2[c], v3[c]));
+    *reinterpret_cast<f32x4*>(xnext + (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4) = mx;
   }
 }
 

@@ -27,6 +27,7 @@ struct ConvLayer {
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
+  DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
   size_t act_elems() const { return (size_t)H * W * cout; }
 };
 
@@ -51,6 +52,22 @@ struct Encoder {
   bool profile = false;
   int prec = PREC_BF16X3;  // arithmetic of the per-token reverse walk (lrp_set_precision); falls back to fp32 for widths % 8 != 0
   std::vector<ProfileRec> prof;
+  // Overlapped encode (mixed-precision mode): the caller's stream runs only the activation chain a_1..a_top (what
+  // the decoder needs); the denominators Z+_l and the gates G_l — needed by explain() only — run on `side` behind
+  // it, i.e. concurrently with the latency-bound decoder replay the caller enqueues next.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fwd = nullptr, ev_gates = nullptr;
+  bool gates_pending = false;
+
+  ~Encoder() {
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
+    if (ev_fwd) (void)hipEventDestroy(ev_fwd);
+    if (ev_gates) (void)hipEventDestroy(ev_gates);
+  }
+  static bool overlap_enabled() {
+    const char* e = getenv("LRP_ENCODE_OVERLAP");
+    return !e || atoi(e) != 0;
+  }
 
   int init(const lrp_config& c, int64_t* total) {
     img_h = c.img_h; img_w = c.img_w; max_images = c.max_images; max_tokens = c.max_tokens;
@@ -90,6 +107,16 @@ struct Encoder {
     LRP_TRY(s0.alloc(NT * max_tok_act * sizeof(float), total));
     LRP_TRY(s1.alloc(NT * max_tok_act * sizeof(float), total));
     for (size_t i = 0; i + 1 < layers.size(); ++i) LRP_TRY(layers[i].G.alloc(B * layers[i].act_elems() * sizeof(float), total));
+    for (size_t i = 0; i + 1 < layers.size(); ++i)
+      if (layers[i].pool_after) LRP_TRY(layers[i].P.alloc(B * layers[i].act_elems() / 4 * sizeof(float), total));
+    {
+      // lowest priority: the side work is throughput work that should only fill what the caller's stream leaves idle
+      int lo = 0, hi = 0;
+      LRP_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      LRP_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));
+    }
+    LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
+    LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_gates, hipEventDisableTiming));
     return LRP_OK;
   }
 
@@ -191,6 +218,10 @@ struct Encoder {
     if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
     LRP_TRY(check_ready());
     const size_t img_elems = (size_t)img_h * img_w * 3;
+    if (gates_pending) {                               // the previous encode's side work still owns G / bufZ / bufXs
+      LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));
+      gates_pending = false;
+    }
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, B * img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
     {
       const size_t total = (size_t)B * img_h * img_w * 64;
@@ -204,10 +235,30 @@ struct Encoder {
     bool mixed = prec == PREC_BF16X3;
     for (const ConvLayer& L : layers)
       if (L.cout & 7) mixed = false;
+    const bool overlap = mixed && side && overlap_enabled() && layers.size() > 1;
+    std::vector<const float*> xin(layers.size() + 1, nullptr);   // overlapped path: input of every conv
     for (size_t li = 0; li < layers.size(); ++li) {
       ConvLayer& L = layers[li];
       const bool top = li + 1 == layers.size();
       ConvArgs ca{};
+      if (overlap && li > 0) {
+        // activation chain only: a_l = relu(conv(x_l) + b) exact fp32, parked in the storage of its future gate
+        ca.in = xin[li]; ca.NB = B; ca.H = L.H; ca.W = L.W; ca.Cin = L.cin; ca.CinP = conv_cinp(L.cin); ca.taps = 9;
+        ca.bias = L.bias.as<float>(); ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout;
+        float* a_out = top ? feat.as<float>() : L.G.as<float>();
+        ca.out = a_out;
+        LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, ca, st));
+        if (top) break;
+        if (L.pool_after) {
+          const size_t n = (size_t)B * L.act_elems();
+          hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);
+          LRP_HIP_CHECK(hipGetLastError());
+          xin[li + 1] = L.P.as<float>();
+        } else {
+          xin[li + 1] = a_out;
+        }
+        continue;
+      }
       if (li == 0) {
         ca.in = a1.as<float>(); ca.NB = B * L.H * L.W; ca.H = 1; ca.W = 1; ca.Cin = 64; ca.CinP = 64; ca.taps = 1;
       } else {
@@ -243,11 +294,41 @@ struct Encoder {
         LRP_HIP_CHECK(hipGetLastError());
         float* t = x; x = a; a = t;                   // next input = a_l
       }
-      if (mixed) {                                    // split8 copy of the next conv's input
+      xin[li + 1] = x;
+      if (mixed && !overlap) {                        // split8 copy of the next conv's input
         const size_t n8 = (size_t)B * layers[li + 1].H * layers[li + 1].W * layers[li + 1].cin / 8;
         hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, x, bufXs.as<float>(), n8);
         LRP_HIP_CHECK(hipGetLastError());
       }
+    }
+    if (overlap) {
+      // side stream, top layer first: layer l's input x_l = a_{l-1} lives in the gate storage of layer l-1, which
+      // is turned into G_{l-1} only after layer l is done with it
+      LRP_HIP_CHECK(hipEventRecord(ev_fwd, st));
+      LRP_HIP_CHECK(hipStreamWaitEvent(side, ev_fwd, 0));
+      for (size_t li = layers.size() - 1; li >= 1; --li) {
+        ConvLayer& L = layers[li];
+        const bool top = li + 1 == layers.size();
+        const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
+        hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, side, xin[li], bufXs.as<float>(), n8);
+        LRP_HIP_CHECK(hipGetLastError());
+        ConvArgs cz{};
+        cz.in = bufXs.as<float>(); cz.NB = B; cz.H = L.H; cz.W = L.W; cz.Cin = L.cin; cz.CinP = conv_cinp(L.cin); cz.taps = 9;
+        cz.bias = L.bias.as<float>(); cz.wpk = L.w_fwd_zs.as<float>(); cz.N = L.cout;
+        cz.out = top ? ztop.as<float>() : bufZ.as<float>();
+        LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, side, PREC_BF16X3));
+        if (top) continue;
+        const size_t n = (size_t)B * L.act_elems();
+        if (L.pool_after)
+          hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, side, L.G.as<float>(), bufZ.as<float>(),
+                             (float*)nullptr, L.G.as<float>(), B, L.H, L.W, L.cout);
+        else
+          hipLaunchKernelGGL(gate_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, side, reinterpret_cast<const f32x4*>(L.G.as<float>()),
+                             reinterpret_cast<const f32x4*>(bufZ.as<float>()), L.G.as<f32x4>(), n / 4);
+        LRP_HIP_CHECK(hipGetLastError());
+      }
+      LRP_HIP_CHECK(hipEventRecord(ev_gates, side));
+      gates_pending = true;
     }
     encoded = B;
     features_only = false;
@@ -259,6 +340,7 @@ struct Encoder {
   int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st) {
     if (n < 1 || n > max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, max_tokens);
     if (encoded < 1 || features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before the CNN explain");
+    if (gates_pending) LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));   // gates / Z_top come from the side stream
     const ConvLayer& T = layers.back();
     float* S = s0.as<float>();
     float* Snext = s1.as<float>();
