@@ -213,6 +213,12 @@ int lrp_op_batchnorm_lrp(const float* x_dev, const float* gamma_dev, const float
 int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, float* Ra_dev, float* Rb_dev,
                    int64_t n, void* stream);
 
+/* AveragePoolingReverseLayer (RA:289-316) for k x k / stride k 'valid' average pooling, channels-last:
+ * x (NB,H,W,C), R (NB,H/k,W/k,C) -> out (NB,H,W,C) = x * SafeDivide(R, avgpool(x))[window] / k^2.
+ * (Not reachable from either encoder cut — VGG16 block5_conv3, ResNet conv5_block3_out — provided as an operator.) */
+int lrp_op_avgpool_lrp(const float* x_dev, const float* R_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
+                       int32_t C, int32_t k, void* stream);
+
 /* Score reduction of the LRP-inference layer (models/model.py:1675-1686) for n heat-maps:
  * hp = mean over channels, hp /= max|hp|, then mode 0 = mean, 1 = mean(max(hp,0)), 2 = np.quantile(hp, 0.9).
  * R_img_dev (n, npix, C) float32, scores_dev (n) float64. */

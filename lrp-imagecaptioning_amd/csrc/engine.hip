@@ -336,6 +336,17 @@ int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, f
   return LRP_OK;
 }
 
+int lrp_op_avgpool_lrp(const float* x_dev, const float* R_dev, float* out_dev, int32_t NB, int32_t H, int32_t W, int32_t C,
+                       int32_t k, void* stream) {
+  if (!x_dev || !R_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (NB < 1 || k < 1 || H < k || W < k || (H % k) || (W % k)) return fail(LRP_ERR_UNSUPPORTED, "need H, W multiples of the pool size");
+  if (C < 4 || (C & 3)) return fail(LRP_ERR_UNSUPPORTED, "C must be a multiple of 4");
+  const size_t total = (size_t)NB * (H / k) * (W / k) * (C / 4);
+  hipLaunchKernelGGL(avgpool_lrp_kernel, dim3(stream_grid(total)), dim3(256), 0, S(stream), x_dev, R_dev, out_dev, NB, H, W, C, k);
+  LRP_HIP_CHECK(hipGetLastError());
+  return LRP_OK;
+}
+
 int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, int32_t npix, int32_t C, int32_t mode,
                        void* stream) {
   if (!R_img_dev || !scores_dev) return fail(LRP_ERR_INVALID, "null argument");

@@ -48,4 +48,36 @@ __global__ __launch_bounds__(256) void add_lrp_kernel(const float* __restrict__ 
   }
 }
 
+// AveragePoolingReverseLayer (RA:289-316), k x k / stride k 'valid' average pooling on NHWC:
+//   Z = avgpool(x);  S = SafeDivide(R, Z);  R_in = x * dZ/dx^T S = x * S[window(x)] / k^2
+// one thread per 4 channels of one OUTPUT window: Z is a k*k-term sum it then fans back out (x read twice, from L2).
+__global__ __launch_bounds__(256) void avgpool_lrp_kernel(const float* __restrict__ x, const float* __restrict__ R,
+                                                          float* __restrict__ out, int NB, int H, int W, int C, int k) {
+  const int C4 = C >> 2, Ho = H / k, Wo = W / k;
+  const size_t total = (size_t)NB * Ho * Wo * C4;
+  const float inv = 1.0f / (float)(k * k);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    size_t r = i / C4;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const float* xb = x + ((((size_t)n * H + (size_t)ho * k) * W + (size_t)wo * k) * C) + 4 * c4;
+    float* ob = out + (xb - x);
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) z += *reinterpret_cast<const f32x4*>(xb + ((size_t)dy * W + dx) * C);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (((size_t)n * Ho + ho) * Wo + wo) * C + 4 * c4);
+    f32x4 s;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[c] = rv[c] / safe_den(z[c] * inv) * inv;
+    for (int dy = 0; dy < k; ++dy)
+      for (int dx = 0; dx < k; ++dx) {
+        const size_t o = ((size_t)dy * W + dx) * C;
+        *reinterpret_cast<f32x4*>(ob + o) = *reinterpret_cast<const f32x4*>(xb + o) * s;
+      }
+  }
+}
+
 }  // namespace lrp

@@ -306,6 +306,17 @@ def op_add_lrp(a, b, R):
     return Ra, Rb
 
 
+def op_avgpool_lrp(x, R, k):
+    """AveragePoolingReverseLayer (RA:289-316), k x k / stride k average pooling, channels-last."""
+    lib = _capi.load()
+    x, R = x.contiguous(), R.contiguous()
+    NB, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _capi.check(lib.lrp_op_avgpool_lrp(p(x), p(R), p(out), NB, H, W, Cc, int(k), _cur_stream(x.device)))
+    return out
+
+
 def heatmap_scores(R_img, mode):
     """LRP-inference score per heat-map (model.py:1675-1686) on the device: R_img (n,H,W,C) -> (n,) float64."""
     lib = _capi.load()

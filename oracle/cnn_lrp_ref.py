@@ -201,6 +201,16 @@ def batchnorm_reverse(x, gamma, beta, mean, var, bn_eps, R, dtype=torch.float64)
     return safe_divide(num, den).numpy()
 
 
+def avgpool_reverse(x, k, R, dtype=torch.float64):
+    """AveragePoolingReverseLayer (RA:289-316), literally: Z = layer(x); S = SafeDivide(R, Z);
+    R_in = x * gradient of Z w.r.t. x applied to S (IL:138-157).  k x k / stride k, channels-last."""
+    xt = _t(x, dtype).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    Z = F.avg_pool2d(xt, k)
+    S = safe_divide(_t(R, dtype).permute(0, 3, 1, 2), Z.detach())
+    (c,) = torch.autograd.grad(Z, xt, grad_outputs=S)
+    return (xt.detach() * c).permute(0, 2, 3, 1).numpy()
+
+
 def add_reverse(xs, R, dtype=torch.float64):
     """AddReverseLayer (RA:260-286): R_i = x_i * SafeDivide(R, sum_j x_j)."""
     xs = [_t(x, dtype) for x in xs]

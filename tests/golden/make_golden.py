@@ -187,12 +187,71 @@ def run_case(E, kind, seed, L, D, H, V, T, store_weights=True, tokens=None, sing
     return out
 
 
+def run_gradient_case(E, kind, seed, L, D, H, V, T, store_weights=True, tokens=None):
+    """The hand-written BPTT of the gradient baselines (E:780-832 adaptive, E:1452-1532 grid-TD) on the same
+    seeded inputs: d(logit_k)/d(image features) per token and the per-word sums r_words."""
+    E_ = H
+    w, feat, cap = decoder_case(kind, seed, L, D, H, V, T)
+    if kind == "adaptive":
+        o = build_adaptive(E, w, feat, L, D, H, E_)
+        o.__class__ = E.ExplainImgCaptioningAdaptiveAttentionGradient
+    else:
+        o = build_gridtd(E, w, feat, L, D, H, E_)
+        o.__class__ = E.ExplainImgCaptioningGridTDGradient
+    o._forward_beam_search((None, None), cap)
+    out = {"kind": kind, "seed": seed, "dims": np.array([L, D, H, E_, V, T]),
+           "feat": feat, "caption": np.array(cap, dtype=np.int64)}
+    if store_weights:
+        for k, v in w.items():
+            out["w_" + k] = v
+    toks = tokens if tokens is not None else list(range(1, len(cap)))
+    out["tokens"] = np.array(toks, dtype=np.int64)
+    gs = []
+    for t in toks:
+        g = o._lstm_decoder_backward(t)
+        gs.append(np.array(g, copy=True))
+        out["r_words_t%d" % t] = np.array(o.r_words, dtype=np.float64, copy=True)
+    out["d_feat"] = np.stack(gs)                      # (n_tok, 1, sqrtL, sqrtL, D) float32
+    for name in (("ot_act", "gt_act") if kind == "adaptive" else ("o1t_act", "o2t_act", "g1t_act", "g2t_act")):
+        out["state_" + name] = np.asarray(getattr(o, name))
+    if tokens is None:
+        rel = o._explain_sentence()                   # E:834-839 / E:1534-1539
+        assert all(np.array_equal(a, b) for a, b in zip(rel, gs))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.dirname(os.path.abspath(__file__)))
+    ap.add_argument("--only", default="all", choices=["all", "lrp", "grad"])
     args = ap.parse_args()
     E = import_reference(args.ref)
+    if args.only in ("all", "grad"):
+        gcases = [
+            ("adaptive_grad_small_s0", "adaptive", 0, 16, 24, 32, 50, 6, dict()),
+            ("adaptive_grad_small_s1", "adaptive", 1, 9, 32, 32, 40, 1, dict()),
+            ("adaptive_grad_small_s2", "adaptive", 2, 16, 64, 64, 120, 9, dict()),
+            ("gridtd_grad_small_s0", "gridtd", 0, 16, 24, 32, 50, 6, dict()),
+            ("gridtd_grad_small_s1", "gridtd", 1, 9, 32, 32, 40, 1, dict()),
+            ("gridtd_grad_small_s2", "gridtd", 2, 16, 64, 64, 120, 9, dict()),
+            ("adaptive_grad_full_s0", "adaptive", 0, 196, 512, 512, 2000, 10, dict(store_weights=False, tokens=[1, 10])),
+            ("gridtd_grad_full_s0", "gridtd", 0, 196, 512, 512, 2000, 10, dict(store_weights=False, tokens=[1, 10])),
+        ]
+        for name, kind, seed, L, D, H, V, T, kw in gcases:
+            out = run_gradient_case(E, kind, seed, L, D, H, V, T, **kw)
+            if name.endswith("full_s0"):
+                for k in list(out):
+                    if k.startswith("state_") and out[k].size > 20000:
+                        del out[k]
+                del out["feat"]
+            path = os.path.join(args.out, name + ".npz")
+            np.savez_compressed(path, **out)
+            print("%-24s tokens=%s  sum|d|=%s  size=%.1f KB" % (
+                name, list(out["tokens"]), np.round(np.abs(out["d_feat"]).reshape(len(out["d_feat"]), -1).sum(1), 5)[:3],
+                os.path.getsize(path) / 1024))
+    if args.only == "grad":
+        return
     cases = [
         # name, kind, seed, L, D, H, V, T, kwargs
         ("adaptive_small_s0", "adaptive", 0, 16, 24, 32, 50, 6, dict(single_word=True)),

@@ -78,3 +78,19 @@ def test_heatmap_scores_full_size_quantile_with_ties():
     got = heatmap_scores(torch.as_tensor(R).cuda(), "quantile").cpu().numpy()
     want = np.array([lrp_inference_score(R[i:i + 1], "quantile") for i in range(2)])
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape,k", [((2, 14, 14, 32), 7), ((3, 8, 12, 8), 2), ((1, 7, 7, 2048), 7)])
+def test_avgpool_reverse(shape, k):
+    """AveragePoolingReverseLayer (RA:289-316); post-ReLU inputs plus one all-zero window (SafeDivide branch)."""
+    from lrp_imagecaptioning_amd.engine import op_avgpool_lrp
+    rs = np.random.RandomState(k)
+    x = np.maximum(rs.standard_normal(shape), 0).astype(np.float32)
+    x[0, :k, :k, 0] = 0.0
+    R = rs.standard_normal((shape[0], shape[1] // k, shape[2] // k, shape[3])).astype(np.float32)
+    out = op_avgpool_lrp(torch.as_tensor(x).cuda(), torch.as_tensor(R).cuda(), k).cpu().numpy()
+    ref = C.avgpool_reverse(x, k, R)
+    err = rel_l1(out, ref)
+    report("rule_avgpool", case=list(shape) + [k], rel_l1=err)
+    assert out.shape == x.shape and np.isfinite(out).all() and err < 1e-5
+    assert (out[0, :k, :k, 0] == 0).all()

@@ -162,3 +162,11 @@ def test_float32_literal_close_to_float64():
     r64 = C.analyze(layers, X, R, torch.float64)
     r32 = C.analyze(layers, X, R, torch.float32)
     assert rel_l1(r32, r64) < 1e-4
+
+
+def test_avgpool_reverse_known_answer():
+    """2x2 average pool: Z = mean = 2.5, S = R/Z = 4, R_in = x * S / 4 = x  (conserves: sum R_in = 10 = R);
+    an all-zero window takes the SafeDivide branch and returns zeros."""
+    x = np.array([[1.0, 2.0, 0.0, 0.0], [3.0, 4.0, 0.0, 0.0]]).reshape(1, 2, 4, 1)
+    got = C.avgpool_reverse(x, 2, np.array([10.0, 7.0]).reshape(1, 1, 2, 1))
+    np.testing.assert_allclose(got[0, :, :, 0], [[1.0, 2.0, 0.0, 0.0], [3.0, 4.0, 0.0, 0.0]], rtol=1e-12)
