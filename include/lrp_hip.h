@@ -163,6 +163,22 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
                        const int32_t* t_host, int32_t variant, float* R_img_dev,
                        float* R_feat_dev, float* att_dev, double* r_words_dev, void* stream);
 
+/* ---- gradient baselines on the same caches -------------------------------------------------
+ * lrp_decoder_gradient == ExplainImgCaptioning{AdaptiveAttention,GridTD}Gradient._lstm_decoder_backward(t)
+ * (models/explainers.py:780-832, :1452-1532) for n (image, t) units at once: d_feat_dev (n, L, D) float32 =
+ * the reference's hand-written BPTT of logit[caption[t-1]-1] w.r.t. the CNN features (its simplifications
+ * included); r_words_dev (n, max_caption_len) float64 or NULL, columns >= t untouched zeros.
+ * Errors as lrp_decoder_explain. */
+int lrp_decoder_gradient(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const int32_t* t_host,
+                         float* d_feat_dev, double* r_words_dev, void* stream);
+/* lrp_cnn_walk == <Analyzer>(image_model, neuron_selection_mode="replace").analyze([X, head]) for
+ * Gradient / InputTimesGradient / GuidedBackprop (innvestigate/analyzer/gradient_based.py:101-265;
+ * explainers.py:672, :884, :928) — and LRPSequentialPresetA for LRP_WALK_LRP (same as lrp_cnn_explain).
+ * head_dev (n, L, D) -> out_dev (n, img_h, img_w, 3).  VGG-style encoders only for the gradient walks. */
+enum { LRP_WALK_LRP = 0, LRP_WALK_GRADIENT = 1, LRP_WALK_INPUT_X_GRADIENT = 2, LRP_WALK_GUIDED_BACKPROP = 3 };
+int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const float* head_dev, float* out_dev,
+                 int32_t walk, void* stream);
+
 /* Arithmetic of the per-token reverse walk through the encoder (lrp_cnn_explain / lrp_explain_tokens).
  * LRP_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * LRP_PREC_BF16X3 split-bf16: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void top_divide_split_kernel(const float* __re
 constexpr int IMG_T_COLS = 54;
 __global__ __launch_bounds__(256) void img_stencil_kernel(const float* __restrict__ T, const float* __restrict__ ximg,
                                                           const int* __restrict__ row2img, float* __restrict__ out,
-                                                          int n, int H, int W) {
+                                                          int n, int H, int W, int mode) {
   const size_t total = (size_t)n * H * W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int HW = H * W;
@@ -188,7 +188,28 @@ __global__ __launch_bounds__(256) void img_stencil_kernel(const float* __restric
     const float* x = ximg + ((size_t)img * HW + pix) * 3;
     float* o = out + i * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = x[c] >= 0.f ? x[c] * pos[c] : x[c] * neg[c];
+    for (int c = 0; c < 3; ++c) {
+      if (mode == 0) o[c] = x[c] >= 0.f ? x[c] * pos[c] : x[c] * neg[c];   // LRP alpha1beta0 at the image
+      else if (mode == 1) o[c] = pos[c] + neg[c];                          // plain gradient (w sits in the + columns)
+      else o[c] = x[c] * (pos[c] + neg[c]);                                // input x gradient
+    }
+  }
+}
+
+// Head of the gradient walks: the cut is AFTER block5_conv3's ReLU, so the head tensor first passes that ReLU's
+// backward: S_top = R * [feat > 0]  (guided backprop: max(R, 0) * [feat > 0], gradient_based.py:228-234)
+__global__ __launch_bounds__(256) void grad_top_kernel(const f32x4* __restrict__ R, const f32x4* __restrict__ feat,
+                                                       const int* __restrict__ row2img, f32x4* __restrict__ S, int n,
+                                                       size_t per4, int guided) {
+  const size_t total = (size_t)n * per4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t t = i / per4, r = i - t * per4;
+    const int img = row2img ? row2img[t] : (int)t;
+    const f32x4 rv = R[i], fv = feat[(size_t)img * per4 + r];
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = fv[c] > 0.f ? (guided ? fmaxf(rv[c], 0.f) : rv[c]) : 0.f;
+    S[i] = o;
   }
 }
 

@@ -75,6 +75,9 @@ struct ConvArgs {
   const int* row2img;  // per input image-slot n -> cache slot (nullptr = identity)
   int split;
   int out_plain;       // bf16x3 MUL epilogues: 1 = write fp32 instead of re-splitting (last GEMM of a chain)
+  // gradient baselines on the MUL epilogues: the cached LRP gate is used as a MASK (gate != 0 <=> the unit's ReLU was
+  // active and it won its pool window), and guided backprop also clamps the propagated value at 0
+  int gate_binary, relu_out;
   // halo-resident 3x3 variant (template HALO): a tile is th rows x tw (<= 14) columns of the image stack
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
@@ -587,9 +590,16 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
               float r[CW];
 #pragma unroll
               for (int q4 = 0; q4 < CW / 4; ++q4) {
-                const f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 4 * q4);
+                f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 4 * q4);
+                if (a.gate_binary) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) r[4 * q4 + q] = v[4 * q4 + q] * g[q];
+                  for (int q = 0; q < 4; ++q) g[q] = g[q] != 0.f ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float p = v[4 * q4 + q] * g[q];
+                  r[4 * q4 + q] = a.relu_out ? fmaxf(p, 0.f) : p;
+                }
               }
               if constexpr (SPLIT_OUT) {
                 if (a.out_plain) {

@@ -12,6 +12,7 @@
 #include "conv_igemm.h"
 #include "decoder_gridtd_kernels.h"
 #include "decoder_kernels.h"
+#include "gradient_kernels.h"
 
 namespace lrp {
 
@@ -42,6 +43,9 @@ struct Decoder {
   int prec = PREC_BF16X3;   // arithmetic of the tail GEMM (follows lrp_set_precision)
   // grid-TD only
   DevBuf Wcat2, bcat2, Wg2T, xh1d, xh2d, zg1d, zg2d, hprojd, sprojd, h2u, rho;
+  // gradient baselines (allocated and packed on first use)
+  bool grad_ready = false;
+  DevBuf gW1, gW2, gWglob, gWif, g_seed, g_dc1, g_dc2, g_dg, g_out1, g_out2, g_dglob, g_dwords, g_dctx, g_davg, g_tailA;
 
   int init(const lrp_config& c, int64_t* total) {
     kind = c.decoder; L = c.L; D = c.D; H = c.H; E = c.E; V = c.V; Tm = c.max_caption_len;
@@ -57,7 +61,7 @@ struct Decoder {
       return s.buf.alloc(elems * eb, total);
     };
     if (kind == LRP_DEC_ADAPTIVE) {
-      for (const char* nm : {"ht", "ct", "gt", "it_act", "ft_act", "st"}) LRP_TRY(st(nm, B * S * H, 4));
+      for (const char* nm : {"ht", "ct", "gt", "it_act", "ft_act", "st", "ot_act"}) LRP_TRY(st(nm, B * S * H, 4));
       LRP_TRY(st("attention", B * S * L, 4));
       LRP_TRY(st("beta", B * S, 4));
       LRP_TRY(st("context", B * S * H, 8));
@@ -67,7 +71,7 @@ struct Decoder {
     }
     if (kind == LRP_DEC_GRIDTD) {
       for (const char* nm : {"h1t", "c1t", "g1t", "i1t_act", "f1t_act", "h2t", "c2t", "g2t", "i2t_act", "f2t_act",
-                             "context", "st", "context_hat"})
+                             "context", "st", "context_hat", "o1t_act", "o2t_act"})
         LRP_TRY(st(nm, B * S * H, 8));
       LRP_TRY(st("attention", B * S * L, 8));
       LRP_TRY(st("beta", B * S, 8));
@@ -326,7 +330,8 @@ struct Decoder {
       LRP_HIP_CHECK((skinny<float, float, float>(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, bcat.as<float>(),
                                                  zgate.as<float>(), 5 * H, B, Kd, 5 * H, 0, st, KS_GATE, zslab)));
       hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B), dim3(256), 0, st, zgate.as<float>(), KS_GATE, zslab, ht,
-                         S_<float>("ct"), S_<float>("gt"), S_<float>("it_act"), S_<float>("ft_act"), stt, i, Tm, H);
+                         S_<float>("ct"), S_<float>("gt"), S_<float>("it_act"), S_<float>("ft_act"), stt,
+                         S_<float>("ot_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
       LRP_HIP_CHECK((skinny<float, float, float>(ht + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
                                                  hproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
@@ -361,7 +366,8 @@ struct Decoder {
       LRP_HIP_CHECK((skinny<double, double, double>(xh1d.as<double>(), K1 + H, Wcat.as<float>(), 5 * H, bcat.as<float>(),
                                                     zg1d.as<double>(), 5 * H, B, K1 + H, 5 * H, 0, st)));
       hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg1d.as<double>(), 5 * H, h1, S_<double>("c1t"),
-                         S_<double>("g1t"), S_<double>("i1t_act"), S_<double>("f1t_act"), stt, (double*)nullptr, i, Tm, H);
+                         S_<double>("g1t"), S_<double>("i1t_act"), S_<double>("f1t_act"), stt, (double*)nullptr,
+                         S_<double>("o1t_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
       LRP_HIP_CHECK((skinny<double, double, double>(h1 + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
                                                     hprojd.as<double>(), H, B, H, H, 0, st)));
@@ -377,7 +383,7 @@ struct Decoder {
                                                     zg2d.as<double>(), 4 * H, B, 3 * H, 4 * H, 0, st)));
       hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg2d.as<double>(), 4 * H, h2, S_<double>("c2t"),
                          S_<double>("g2t"), S_<double>("i2t_act"), S_<double>("f2t_act"), (double*)nullptr,
-                         h2u.as<double>(), i, Tm, H);
+                         h2u.as<double>(), S_<double>("o2t_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
     }
     // logits from h2 alone (E:1154 — the reference quirk), every step at once
@@ -410,6 +416,121 @@ struct Decoder {
     ta.avg = a.avg; ta.WifT = WifT.as<float>(); ta.rho = a.rho; ta.ravg = a.ravg; ta.R_feat = R_feat_dev;
     ta.Tm = Tm; ta.L = L; ta.D = D; ta.H = H;
     hipLaunchKernelGGL(gtd_tail_kernel, dim3(n, (L + 63) / 64, (D + 63) / 64), dim3(256), 0, st, ta);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+
+  // ---- gradient baselines: _lstm_decoder_backward (E:780-832 adaptive, E:1452-1532 grid-TD), see gradient_kernels.h
+  // B operand of a transposed-weight product on conv_igemm: rows = the Keras kernels (in_dim, K) stacked, K padded to 32
+  int pack_rows(const std::vector<std::pair<const char*, int>>& blocks, int K, DevBuf& dst, int64_t* total) {
+    int N = 0;
+    for (auto& b : blocks) N += b.second;
+    const int Kp = conv_cinp(K);
+    std::vector<float> pk((size_t)conv_npad(N) * Kp, 0.f);
+    int r0 = 0;
+    for (auto& b : blocks) {
+      const std::vector<float>& w = raw.at(b.first);
+      if (w.size() != (size_t)b.second * K) return fail(LRP_ERR_INVALID, "weight '%s' has the wrong size for the gradient path", b.first);
+      for (int r = 0; r < b.second; ++r) memcpy(&pk[(size_t)(r0 + r) * Kp], &w[(size_t)r * K], (size_t)K * sizeof(float));
+      r0 += b.second;
+    }
+    return upload(dst, pk, total);
+  }
+  int grad_prepare(int64_t* total) {
+    if (grad_ready) return LRP_OK;
+    if ((H & 3) || (E & 3) || (D & 3)) return fail(LRP_ERR_UNSUPPORTED, "gradient path: H, E, D must be multiples of 4");
+    const size_t NT = NT_max;
+    if (kind == LRP_DEC_ADAPTIVE) {
+      LRP_TRY(pack_rows({{"lstm_Wh", H}, {"lstm_Wi", 2 * E}}, 4 * H, gW1, total));
+      LRP_TRY(g_out1.alloc(NT * (H + 2 * E) * 4, total));
+    } else {
+      LRP_TRY(pack_rows({{"td_Wh", H}, {"td_Wi", H + 2 * E}}, 4 * H, gW1, total));
+      LRP_TRY(pack_rows({{"lang_Wh", H}, {"lang_Wi", 2 * H}}, 4 * H, gW2, total));
+      LRP_TRY(g_out1.alloc(NT * (2 * H + 2 * E) * 4, total));
+      LRP_TRY(g_out2.alloc(NT * 3 * H * 4, total));
+      LRP_TRY(g_dc2.alloc(NT * H * 4, total));
+      LRP_TRY(g_dctx.alloc(NT * Tm * H * 4, total));
+    }
+    LRP_TRY(pack_rows({{"global_W", D}}, E, gWglob, total));
+    LRP_TRY(pack_rows({{"image_features_W", D}}, H, gWif, total));
+    LRP_TRY(g_seed.alloc(NT * H * 4, total));
+    LRP_TRY(g_dc1.alloc(NT * H * 4, total));
+    LRP_TRY(g_dg.alloc(NT * 4 * H * 4, total));
+    LRP_TRY(g_dglob.alloc(NT * E * 4, total));
+    LRP_TRY(g_dwords.alloc(NT * Tm * 8, total));
+    LRP_TRY(g_davg.alloc(NT * D * 4, total));
+    LRP_TRY(g_tailA.alloc(NT * L * H * 4, total));
+    grad_ready = true;
+    return LRP_OK;
+  }
+  // out[M][N] = in[M][K] . W^T   (W packed by pack_rows)
+  static int gemm_nt(const float* in, int M, int K, const DevBuf& W, int N, float* out, hipStream_t st) {
+    ConvArgs c{};
+    c.in = in; c.NB = M; c.H = 1; c.W = 1; c.Cin = K; c.CinP = conv_cinp(K); c.taps = 1; c.N = N;
+    c.wpk = W.as<float>(); c.out = out;
+    LRP_HIP_CHECK(conv_launch(EPI_STORE, c, st, PREC_FP32));
+    return LRP_OK;
+  }
+  // n units (img_dev[u], t_dev[u]); t_max = largest t among them.  dfeat_dev (n, L, D) fp32, rwords_dev (n, Tm) fp64 or null.
+  int gradient(int n, const int* img_dev, const int* t_dev, int t_max, float* dfeat_dev, double* rwords_dev, int64_t* total,
+               hipStream_t st) {
+    LRP_TRY(grad_prepare(total));
+    const bool td = kind == LRP_DEC_GRIDTD;
+    float* seed = g_seed.as<float>();
+    double* dwords = rwords_dev ? rwords_dev : g_dwords.as<double>();
+    hipLaunchKernelGGL(grad_seed_kernel, dim3(n), dim3(256), 0, st, img_dev, t_dev, cap_dev.as<int>(), Wout.as<float>(), seed,
+                       g_dc1.as<float>(), td ? g_dc2.as<float>() : (float*)nullptr, g_dglob.as<float>(), dwords, Tm, H, E, V);
+    LRP_HIP_CHECK(hipGetLastError());
+    float* dg = g_dg.as<float>();
+    float* o1 = g_out1.as<float>();
+    float* o2 = g_out2.as<float>();
+    const int N1 = td ? 2 * H + 2 * E : H + 2 * E, N2 = 3 * H;
+    for (int s = 0; s < t_max; ++s) {
+      if (!td) {
+        hipLaunchKernelGGL(grad_cell_kernel<float>, dim3(n), dim3(256), 0, st, img_dev, t_dev, s, seed, o1, N1, 0,
+                           (const float*)nullptr, 0, 0, S_<float>("ct"), S_<float>("it_act"), S_<float>("ft_act"),
+                           S_<float>("gt"), S_<float>("ot_act"), g_dc1.as<float>(), dg, Tm, H);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(gemm_nt(dg, n, 4 * H, gW1, N1, o1, st));                  // [d_h[i] | d_x[i] = (words E | glob E)]
+        hipLaunchKernelGGL(grad_accum_kernel, dim3(n), dim3(256), 0, st, t_dev, s, o1, N1, H + E, H, g_dglob.as<float>(),
+                           dwords, Tm, E);
+        LRP_HIP_CHECK(hipGetLastError());
+      } else {
+        // language LSTM: d_h2[i+1] = seed (s = 0) | carried d_h2[i+1] + d_x1[i+1][:H] (E:1522)
+        hipLaunchKernelGGL(grad_cell_kernel<double>, dim3(n), dim3(256), 0, st, img_dev, t_dev, s, seed, o2, N2, 0,
+                           s > 0 ? o1 : (const float*)nullptr, N1, H, S_<double>("c2t"), S_<double>("i2t_act"),
+                           S_<double>("f2t_act"), S_<double>("g2t"), S_<double>("o2t_act"), g_dc2.as<float>(), dg, Tm, H);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(gemm_nt(dg, n, 4 * H, gW2, N2, o2, st));                  // [d_h2[i] | d_x2 = (c_hat H | h1 H)]
+        hipLaunchKernelGGL(gtd_grad_ctx_kernel, dim3(n), dim3(256), 0, st, img_dev, t_dev, s, seed, o2, N2, H,
+                           S_<double>("beta"), g_dctx.as<float>(), Tm, H);
+        LRP_HIP_CHECK(hipGetLastError());
+        // top-down LSTM: d_h1[i+1] = carried d_h1[i+1] + d_x2[H:] (E:1504)
+        hipLaunchKernelGGL(grad_cell_kernel<double>, dim3(n), dim3(256), 0, st, img_dev, t_dev, s, (const float*)nullptr, o1, N1,
+                           0, o2, N2, 2 * H, S_<double>("c1t"), S_<double>("i1t_act"), S_<double>("f1t_act"),
+                           S_<double>("g1t"), S_<double>("o1t_act"), g_dc1.as<float>(), dg, Tm, H);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(gemm_nt(dg, n, 4 * H, gW1, N1, o1, st));                  // [d_h1[i] | d_x1 = (h2 H | glob E | words E)]
+        hipLaunchKernelGGL(grad_accum_kernel, dim3(n), dim3(256), 0, st, t_dev, s, o1, N1, 2 * H, 2 * H + E,
+                           g_dglob.as<float>(), dwords, Tm, E);
+        LRP_HIP_CHECK(hipGetLastError());
+      }
+    }
+    hipLaunchKernelGGL(grad_glob_mask_kernel, dim3(n), dim3(256), 0, st, img_dev, glob_pre.as<float>(), g_dglob.as<float>(), E,
+                       td ? 0 : 1);
+    LRP_HIP_CHECK(hipGetLastError());
+    LRP_TRY(gemm_nt(g_dglob.as<float>(), n, E, gWglob, D, g_davg.as<float>(), st));
+    const dim3 tg((unsigned)std::min((L * H + 255) / 256, 64), n);
+    if (td)
+      hipLaunchKernelGGL(grad_tail_a_kernel<double>, tg, dim3(256), 0, st, img_dev, t_dev, seed, g_dctx.as<float>(),
+                         S_<double>("attention"), if_pre.as<float>(), g_tailA.as<float>(), Tm, L, H);
+    else
+      hipLaunchKernelGGL(grad_tail_a_kernel<float>, tg, dim3(256), 0, st, img_dev, t_dev, seed, (const float*)nullptr,
+                         S_<float>("attention"), if_pre.as<float>(), g_tailA.as<float>(), Tm, L, H);
+    LRP_HIP_CHECK(hipGetLastError());
+    LRP_TRY(gemm_nt(g_tailA.as<float>(), n * L, H, gWif, D, dfeat_dev, st));
+    hipLaunchKernelGGL(grad_tail_finish_kernel, dim3((unsigned)std::min((L * D + 255) / 256, 64), n), dim3(256), 0, st,
+                       g_davg.as<float>(), dfeat_dev, L, D);
     LRP_HIP_CHECK(hipGetLastError());
     return LRP_OK;
   }

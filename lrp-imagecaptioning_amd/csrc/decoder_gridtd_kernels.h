@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void gtd_prep_x1_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __restrict__ z, int ldz, double* __restrict__ ht,
                                                             double* __restrict__ ct, double* __restrict__ gt,
                                                             double* __restrict__ it, double* __restrict__ ft,
-                                                            double* __restrict__ st, double* __restrict__ hu, int step,
-                                                            int Tm, int H) {
+                                                            double* __restrict__ st, double* __restrict__ hu,
+                                                            double* __restrict__ ot, int step, int Tm, int H) {
   const int b = blockIdx.x, S = Tm + 1;
   const double* zb = z + (size_t)b * ldz;
   const size_t prev = ((size_t)b * S + step) * H, cur = prev + H;
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __rest
     gt[cur + j] = g_;
     it[cur + j] = i_;
     ft[cur + j] = f_;
+    ot[cur + j] = o_;                                  // (gradient baselines, E:1327-1342)
     if (st) st[cur + j] = tc * sigmoid_d(zb[4 * H + j]);
     if (hu) hu[((size_t)b * Tm + step) * H + j] = h;          // rows of the output-layer GEMM (h2 only, E:1154)
   }

@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restr
                                                             float* __restrict__ ht,
                                                             float* __restrict__ ct, float* __restrict__ gt,
                                                             float* __restrict__ it, float* __restrict__ ft,
-                                                            float* __restrict__ st, int step, int Tm, int H) {
+                                                            float* __restrict__ st, float* __restrict__ ot, int step,
+                                                            int Tm, int H) {
   const int b = blockIdx.x, S = Tm + 1;
   const float* zb = z + (size_t)b * 5 * H;
   const size_t prev = ((size_t)b * S + step) * H, cur = prev + H;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restr
     gt[cur + j] = g_;
     it[cur + j] = i_;
     ft[cur + j] = f_;
+    ot[cur + j] = o_;                                  // (read by the gradient baselines only, E:673-688)
     st[cur + j] = tc * sigmoidf_(zz[4]);
   }
 }

@@ -25,6 +25,7 @@ struct ConvLayer {
   DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
+  DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
   DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
@@ -165,6 +166,13 @@ struct Encoder {
         LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
       }
+      // gradient baselines: the same tap expansion with the whole w in the "+" columns
+      pk.assign((size_t)Npb * Kb, 0.f);
+      for (int t = 0; t < 9; ++t)
+        for (int c = 0; c < 3; ++c)
+          for (int co = 0; co < L.cout; ++co) pk[(size_t)(t * 6 + c) * Kb + co] = w[((size_t)t * 3 + c) * L.cout + co];
+      LRP_TRY(L.w_bwd_full.alloc(pk.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpy(L.w_bwd_full.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     } else {
       const int Np = conv_npad(2 * L.cout), K = 9 * conv_cinp(L.cin);
       pk.assign((size_t)Np * K, 0.f);
@@ -194,6 +202,10 @@ struct Encoder {
         LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
       }
+      pk.assign((size_t)Npb * Kb, 0.f);
+      pack_conv_bwd(w, 9, L.cin, L.cout, 0, pk.data());
+      LRP_TRY(L.w_bwd_full.alloc(pk.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpy(L.w_bwd_full.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     L.have_w = true;
     return LRP_OK;
@@ -337,18 +349,28 @@ struct Encoder {
 
   // ---- reverse walk, n relevance maps at once ---------------------------------------------
   // R_feat_dev (n, top_h*top_w, top_c) -> R_img_dev (n, img_h, img_w, 3); row2img_dev: device int[n]
-  int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st) {
+  // walk: 0 = LRP (LRPSequentialPresetA); gradient baselines (gradient_based.py:101-265) on the same caches:
+  //   1 = Gradient, 2 = InputTimesGradient, 3 = GuidedBackprop — backward-data convs with the full w, the LRP gate
+  //   used as the ReLU/arg-max mask, exact fp32.
+  int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st, int walk = 0) {
     if (n < 1 || n > max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, max_tokens);
+    if (walk < 0 || walk > 3) return fail(LRP_ERR_INVALID, "unknown walk %d", walk);
     if (encoded < 1 || features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before the CNN explain");
     if (gates_pending) LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));   // gates / Z_top come from the side stream
     const ConvLayer& T = layers.back();
     float* S = s0.as<float>();
     float* Snext = s1.as<float>();
-    bool split = prec == PREC_BF16X3;
+    bool split = prec == PREC_BF16X3 && walk == 0;
     for (const ConvLayer& L : layers)
       if (L.cout & 7) split = false;                    // split8 groups need widths % 8 == 0: exact fp32 otherwise
     const int run_prec = split ? PREC_BF16X3 : PREC_FP32;
-    if (split) {
+    if (walk != 0) {
+      const size_t per4 = T.act_elems() / 4;
+      hipLaunchKernelGGL(grad_top_kernel, dim3(stream_grid((size_t)n * per4)), dim3(256), 0, st,
+                         reinterpret_cast<const f32x4*>(R_feat_dev), feat.as<f32x4>(), row2img_dev,
+                         reinterpret_cast<f32x4*>(S), n, per4, walk == 3 ? 1 : 0);
+      LRP_HIP_CHECK(hipGetLastError());
+    } else if (split) {
       const size_t per8 = T.act_elems() / 8;
       hipLaunchKernelGGL(top_divide_split_kernel, dim3(stream_grid((size_t)n * per8)), dim3(256), 0, st, R_feat_dev,
                          ztop.as<float>(), row2img_dev, S, n, per8);
@@ -364,8 +386,9 @@ struct Encoder {
       const ConvLayer& L = layers[li];
       ConvArgs ca{};
       ca.in = S; ca.NB = n; ca.H = L.H; ca.W = L.W; ca.Cin = L.cout; ca.CinP = conv_cinp(L.cout); ca.taps = 9;
-      ca.wpk = split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
+      ca.wpk = walk != 0 ? L.w_bwd_full.as<float>() : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
       ca.row2img = row2img_dev;
+      ca.gate_binary = walk != 0; ca.relu_out = walk == 3;
       int epi;
       if (li == 0) {
         ca.NB = n * L.H * L.W; ca.H = 1; ca.W = 1; ca.taps = 1;          // 1-tap GEMM over the pixels
@@ -391,7 +414,7 @@ struct Encoder {
     {  // S now holds T (n, H, W, 54): 9-tap shift-and-add and the x+/x- selection
       const ConvLayer& L0 = layers[0];
       hipLaunchKernelGGL(img_stencil_kernel, dim3(stream_grid((size_t)n * L0.H * L0.W)), dim3(256), 0, st, S,
-                         images.as<float>(), row2img_dev, R_img_dev, n, L0.H, L0.W);
+                         images.as<float>(), row2img_dev, R_img_dev, n, L0.H, L0.W, walk == 0 ? 0 : walk == 2 ? 2 : 1);
       LRP_HIP_CHECK(hipGetLastError());
     }
     return LRP_OK;

@@ -210,6 +210,27 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host, co
   return h->enc.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
 }
 
+int lrp_decoder_gradient(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const int32_t* t_host, float* d_feat_dev,
+                         double* r_words_dev, void* stream) {
+  if (!h || !img_idx_host || !t_host || !d_feat_dev) return fail(LRP_ERR_INVALID, "null argument");
+  LRP_TRY(stage_indices(h, n, img_idx_host, t_host, true, S(stream)));
+  int t_max = 0;
+  for (int i = 0; i < n; ++i) t_max = t_host[i] > t_max ? t_host[i] : t_max;
+  return h->dec.gradient(n, h->idx_dev.as<int>(), h->idx_dev.as<int>() + n, t_max, d_feat_dev, r_words_dev, &h->ws_bytes,
+                         S(stream));
+}
+
+int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const float* head_dev, float* out_dev, int32_t walk,
+                 void* stream) {
+  if (!h || !img_idx_host || !head_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (walk < LRP_WALK_LRP || walk > LRP_WALK_GUIDED_BACKPROP) return fail(LRP_ERR_INVALID, "unknown walk %d", walk);
+  if (h->encoded() < 1 || h->features_only()) return fail(LRP_ERR_STATE, "lrp_encode_images must run before lrp_cnn_walk");
+  if (h->resnet && walk != LRP_WALK_LRP) return fail(LRP_ERR_UNSUPPORTED, "gradient walks exist for the conv-list (VGG) encoder only");
+  LRP_TRY(stage_indices(h, n, img_idx_host, nullptr, false, S(stream)));
+  if (h->resnet) return h->rn.explain(n, h->idx_dev.as<int>(), head_dev, out_dev, S(stream));
+  return h->enc.explain(n, h->idx_dev.as<int>(), head_dev, out_dev, S(stream), walk);
+}
+
 int lrp_set_precision(lrp_handle* h, int32_t mode) {
   if (!h) return fail(LRP_ERR_INVALID, "null handle");
   if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3) return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);

@@ -148,6 +148,7 @@ class LRPEngine(object):
     _STATE_SHAPES = {
         "ht": ("S", "H", torch.float32), "ct": ("S", "H", torch.float32), "gt": ("S", "H", torch.float32),
         "it_act": ("S", "H", torch.float32), "ft_act": ("S", "H", torch.float32), "st": ("S", "H", torch.float32),
+        "ot_act": ("S", "H", torch.float32),
         "attention": ("S", "L", torch.float32), "beta": ("S", 1, torch.float32),
         "context": ("S", "H", torch.float64), "c_hat": ("S", "H", torch.float64),
         "xt": ("T", "2E", torch.float32), "caption_preds": ("T", "V", torch.float64),
@@ -157,7 +158,7 @@ class LRPEngine(object):
 
     _STATE_SHAPES_GRIDTD = dict(
         [(n, ("S", "H", torch.float64)) for n in ("h1t", "c1t", "g1t", "i1t_act", "f1t_act", "h2t", "c2t", "g2t", "i2t_act",
-                                                  "f2t_act", "context", "st", "context_hat")] +
+                                                  "f2t_act", "context", "st", "context_hat", "o1t_act", "o2t_act")] +
         [("attention", ("S", "L", torch.float64)), ("beta", ("S", 1, torch.float64)),
          ("x1t", ("T", "H+2E", torch.float64)), ("x2t", ("T", "2H", torch.float64)),
          ("caption_preds", ("T", "V", torch.float64)),
@@ -197,6 +198,33 @@ class LRPEngine(object):
             out = torch.empty((n, self.img_hw[0], self.img_hw[1], 3), dtype=torch.float32, device=self.device)
         _capi.check(self._lib.lrp_cnn_explain(self._h, n, pi, C.c_void_p(R.data_ptr()), C.c_void_p(out.data_ptr()),
                                               self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ gradient baselines
+    WALKS = {"lrp": 0, "gradient": 1, "input_x_gradient": 2, "guided_backprop": 3}
+
+    def decoder_gradient(self, img_idx, t, want_r_words=True):
+        """_lstm_decoder_backward (explainers.py:780-832 / :1452-1532) for n (image, t) units: (n, L, D) float32
+        and the per-word sums r_words (n, Tm) float64 (columns >= t are zero)."""
+        n = len(img_idx)
+        ii, pi = _i32(img_idx)
+        tt, pt = _i32(t)
+        d = torch.empty((n, self.L, self.D), dtype=torch.float32, device=self.device)
+        rw = torch.zeros((n, self.Tm), dtype=torch.float64, device=self.device) if want_r_words else None
+        _capi.check(self._lib.lrp_decoder_gradient(self._h, n, pi, pt, C.c_void_p(d.data_ptr()),
+                                                   C.c_void_p(rw.data_ptr()) if rw is not None else None, self._stream()))
+        return d, rw
+
+    def cnn_walk(self, img_idx, head, walk="gradient", out=None):
+        """Gradient / InputTimesGradient / GuidedBackprop `.analyze([X, head])` (gradient_based.py:101-265) on the
+        cached forward of `lrp_encode_images`; walk='lrp' is cnn_explain."""
+        n = len(img_idx)
+        ii, pi = _i32(img_idx)
+        Hd = self._dev(head).reshape(n, self.L, self.D)
+        if out is None:
+            out = torch.empty((n, self.img_hw[0], self.img_hw[1], 3), dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.lrp_cnn_walk(self._h, n, pi, C.c_void_p(Hd.data_ptr()), C.c_void_p(out.data_ptr()),
+                                           self.WALKS[walk], self._stream()))
         return out
 
     def explain_tokens(self, img_idx, t, variant="sequence", out=None, want_R_feat=False, want_attention=False,

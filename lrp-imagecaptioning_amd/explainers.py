@@ -288,3 +288,99 @@ class ExplainImgCaptioningGridTDModel(ExplainImgCaptioningAttentionModel):
 
     def _explain_lstm_single_word(self, t=0):
         raise NotImplementedError()                   # E:167-172: the grid-TD class does not override it
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Gradient baselines: the reference's six comparison engines on the same cached forward.
+# Decoder half = its hand-written BPTT `_lstm_decoder_backward` (lrp_decoder_gradient); CNN half = iNNvestigate's
+# Gradient / InputTimesGradient / GuidedBackprop with neuron_selection_mode="replace" (lrp_cnn_walk).
+# ---------------------------------------------------------------------------------------------------------------
+class _GradientMixin(object):
+    _walk = "gradient"
+
+    def _lstm_decoder_backward(self, t):
+        """E:780-832 / E:1452-1532 -> d_img_feature (1, sqrtL, sqrtL, D) float32; sets self.r_words (t,)."""
+        self._check_t(t)
+        d, rw = self._engine.decoder_gradient([0], [t])
+        g = int(np.sqrt(self.L))
+        self.r_words = rw[0, :t].cpu().numpy()
+        return d.cpu().numpy().reshape(1, g, g, self.D)
+
+    def _explain_sentence(self):
+        """E:834-839 / E:1534-1539: a list of relevances only (no attention), all words in one batched call."""
+        n = len(self.caption) - 1
+        if n < 1:
+            return []
+        d, rw = self._engine.decoder_gradient([0] * n, list(range(1, n + 1)))
+        g = int(np.sqrt(self.L))
+        self.r_words = rw[n - 1, :n].cpu().numpy()
+        dn = d.cpu().numpy()
+        return [dn[i].reshape(1, g, g, self.D) for i in range(n)]
+
+    def _explain_CNN(self, X, relevance_value):
+        """`self._CNN_explainer.analyze([X, relevance])` with the class's analyzer (E:672 / :884 / :928)."""
+        X = np.asarray(X, dtype=np.float32)
+        R = np.asarray(relevance_value, dtype=np.float32)
+        cached = getattr(self, "_img_input", None)
+        if not (self.caption is not None and cached is not None and X.shape == cached[:1].shape and np.array_equal(X, cached[:1])):
+            self._engine.encode_images(X[:1])              # another image: the caches now belong to it
+            self._img_input = X[:1].copy()
+            self.caption = None
+            self._state_cache = {}
+        n = R.shape[0]
+        return self._engine.cnn_walk([0] * n, R.reshape(n, self.L, self.D), self._walk).cpu().numpy()
+
+    def _explain_lstm_single_word_sequence(self, t=0):
+        raise NotImplementedError("the gradient engines explain through _lstm_decoder_backward")   # E:174-177 base stub
+
+    def _explain_lstm_single_word(self, t=0):
+        raise NotImplementedError("the gradient engines explain through _lstm_decoder_backward")
+
+
+class _GuidedGradcamMixin(_GradientMixin):
+    _walk = "guided_backprop"
+
+    def grad_cam(self, img_feature, grads):
+        from .postprocess import grad_cam
+        return grad_cam(img_feature, grads, self.L, self.D, upscale=self._model.img_hw[0] // int(np.sqrt(self.L)))
+
+    def _explain_CNN(self, X, relevance_value):
+        """E:930-937 / E:1634-1641: guided backprop of the image model, gated by the Grad-CAM map of the features."""
+        R = np.asarray(relevance_value, dtype=np.float32)
+        gb = _GradientMixin._explain_CNN(self, X, R)
+        feat = self._engine.get_features()[0].cpu().numpy()
+        cam = self.grad_cam(feat, R[0])
+        return (gb[0] * cam[..., np.newaxis])[np.newaxis, :]
+
+
+class ExplainImgCaptioningAdaptiveAttentionGradient(_GradientMixin, ExplainImgCaptioningAdaptiveAttention):
+    """E:667-879."""
+    _STATE_ATTRS = ExplainImgCaptioningAdaptiveAttention._STATE_ATTRS + ("ot_act",)
+
+
+class ExplainImgCaptioningAdaptiveAttentionInputTimesGradient(ExplainImgCaptioningAdaptiveAttentionGradient):
+    """E:880-924."""
+    _walk = "input_x_gradient"
+
+
+class ExplainImgCaptioningAdaptiveAttentionGuidedGradcam(_GuidedGradcamMixin, ExplainImgCaptioningAdaptiveAttention):
+    """E:925-993."""
+    _STATE_ATTRS = ExplainImgCaptioningAdaptiveAttention._STATE_ATTRS + ("ot_act",)
+
+
+class ExplainImgCaptioningGridTDGradient(_GradientMixin, ExplainImgCaptioningGridTDModel):
+    """E:1322-1583."""
+    _STATE_ATTRS = ExplainImgCaptioningGridTDModel._STATE_ATTRS + ("o1t_act", "o2t_act")
+
+
+class ExplainImgCaptioningGridTDGradientTimesInput(ExplainImgCaptioningGridTDGradient):
+    """E:1584-1628."""
+    _walk = "input_x_gradient"
+
+
+class ExplainImgCaptioningGridTDGuidedGradcam(_GuidedGradcamMixin, ExplainImgCaptioningGridTDModel):
+    """E:1629-1700 (its guided_backproe helper, E:1655-1657, is `_explain_CNN` without the Grad-CAM factor)."""
+    _STATE_ATTRS = ExplainImgCaptioningGridTDModel._STATE_ATTRS + ("o1t_act", "o2t_act")
+
+    def guided_backproe(self, img_input, grads):
+        return _GradientMixin._explain_CNN(self, img_input, grads)

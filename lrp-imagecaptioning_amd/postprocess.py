@@ -92,3 +92,32 @@ def lrp_inference_score(relevance, mode, color_conversion="BGRtoRGB"):
     if mode == "quantile":
         return float(np.quantile(hp, [0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9])[8])
     raise NotImplementedError("the lrp inference mode is not available")
+
+
+# ---- Grad-CAM map of the Guided-Grad-CAM baselines (explainers.py:939-949 / :1643-1653)
+def pyramid_expand(image, upscale=2, sigma=None):
+    """skimage.transform.pyramid_expand(image, upscale, sigma, multichannel=False) restated with scipy (skimage is a
+    third-party dependency the reference imports, explainers.py:14): bilinear `resize` to upscale x the shape
+    (output pixel centres map to (o + 0.5) / upscale - 0.5, out-of-range samples mirrored, no anti-aliasing), then a
+    Gaussian smoothing with `sigma` (scipy mode 'reflect').  Host-side: a (14,14) -> (224,224) map per word."""
+    from scipy import ndimage as ndi
+    image = np.asarray(image, dtype=np.float64)
+    if sigma is None:
+        sigma = 2 * upscale / 6.0
+    out_shape = tuple(int(np.ceil(upscale * d)) for d in image.shape)
+    coords = np.meshgrid(*[(np.arange(o) + 0.5) * (s / float(o)) - 0.5 for o, s in zip(out_shape, image.shape)], indexing="ij")
+    resized = ndi.map_coordinates(image, coords, order=1, mode="mirror")
+    return ndi.gaussian_filter(resized, sigma, mode="reflect")
+
+
+def grad_cam(img_feature, grads, L, D, upscale=16):
+    """explainers.py:939-949: channel weights = spatial mean of the feature gradients; cam = relu(expand(sum_c w_c F_c))
+    / (max|cam| + 1e-6).  The reference hard-codes upscale=16 (14 -> 224) and sigma=20; `upscale` is the image / feature
+    size ratio so that other encoder geometries work too."""
+    g = int(np.sqrt(L))
+    weights = np.mean(np.asarray(grads).reshape(g, g, D), axis=(0, 1))
+    conv_output = np.asarray(img_feature).reshape(g, g, D)
+    cam = np.tensordot(conv_output, weights, axes=([2], [0])).astype(np.float32)
+    cam = pyramid_expand(cam, upscale=upscale, sigma=20)
+    cam = np.maximum(cam, 0)
+    return cam / (np.max(np.abs(cam)) + 1e-6)

@@ -127,6 +127,29 @@ def analyze(layers, X_nhwc, R_nhwc, dtype=torch.float64):
     return _nhwc(R).numpy()
 
 
+def gradient_analyze(layers, X_nhwc, head_nhwc, mode="gradient", dtype=torch.float64):
+    """The gradient baselines' CNN half (explainers.py:672, :884, :928): `<Analyzer>(image_model,
+    neuron_selection_mode="replace").analyze([X, head])` for innvestigate.analyzer.gradient_based
+      "gradient"         Gradient (:101-137)            reverse walk = plain gradients (IL:138-157 per layer)
+      "input_x_gradient" InputTimesGradient (:175-195)  gradient * X
+      "guided_backprop"  GuidedBackprop (:228-265)      every layer with a ReLU first clamps the incoming
+                                                        value at 0, then applies the layer's own gradient
+    written layer by layer like the reversed graph: one autograd call per Keras layer."""
+    _, inputs = forward(layers, X_nhwc, dtype, return_inputs=True)
+    g = _nchw(_t(head_nhwc, dtype))
+    for L, x in zip(reversed(layers), reversed(inputs)):
+        if L[0] == "conv":
+            if mode == "guided_backprop":
+                g = F.relu(g)                                   # GuidedBackpropReverseReLULayer, :228-234
+            w, b = _w_oihw(L[1], dtype), _t(L[2], dtype)
+            g = gradient_route(x, lambda v: F.relu(F.conv2d(v, w, b, padding=1)), g)
+        else:
+            g = gradient_route(x, lambda v: F.max_pool2d(v, 2, 2), g)
+    if mode == "input_x_gradient":
+        g = g * _nchw(_t(X_nhwc, dtype))
+    return _nhwc(g).numpy()
+
+
 def analyze_cached(layers, X_nhwc, R_nhwc, dtype=torch.float64):
     """The restructured algorithm the HIP path uses, in float64 on CPU, to
     show it is parity-neutral (tests/test_oracle_cnn.py):

@@ -170,3 +170,40 @@ def test_avgpool_reverse_known_answer():
     x = np.array([[1.0, 2.0, 0.0, 0.0], [3.0, 4.0, 0.0, 0.0]]).reshape(1, 2, 4, 1)
     got = C.avgpool_reverse(x, 2, np.array([10.0, 7.0]).reshape(1, 1, 2, 1))
     np.testing.assert_allclose(got[0, :, :, 0], [[1.0, 2.0, 0.0, 0.0], [3.0, 4.0, 0.0, 0.0]], rtol=1e-12)
+
+
+def test_gradient_walks_known_answers():
+    """1x1-image, 3x3 conv acting as its centre tap: y = relu(w x + b).  dy/dx = w where the unit is active.
+    Guided backprop additionally drops negative incoming values; input x gradient multiplies by x."""
+    w = np.zeros((3, 3, 1, 2))
+    w[1, 1, 0] = [2.0, -3.0]
+    layers = [("conv", w, np.array([0.5, 10.0]))]
+    X = np.array([1.0]).reshape(1, 1, 1, 1)                       # pre-activations: 2.5, 7.0 -> both active
+    head = np.array([1.0, -1.0]).reshape(1, 1, 1, 2)
+    assert C.gradient_analyze(layers, X, head, "gradient")[0, 0, 0, 0] == pytest.approx(2.0 * 1 + (-3.0) * (-1))
+    assert C.gradient_analyze(layers, X, head, "guided_backprop")[0, 0, 0, 0] == pytest.approx(2.0)      # -1 clamped
+    X2 = np.array([4.0]).reshape(1, 1, 1, 1)                      # second unit: -12 + 10 < 0 -> inactive
+    assert C.gradient_analyze(layers, X2, head, "gradient")[0, 0, 0, 0] == pytest.approx(2.0)
+    assert C.gradient_analyze(layers, X2, head, "input_x_gradient")[0, 0, 0, 0] == pytest.approx(8.0)
+
+
+def test_gradient_walk_is_the_true_gradient():
+    """The per-layer walk equals autograd through the whole network (fan-out free chain)."""
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(3)
+    cfg = [("a", 3, 8, True), ("b", 8, 8, False)]
+    from lrp_imagecaptioning_amd.synthetic import vgg_weights
+    wts = vgg_weights(rs, cfg, bias_std=0.3)
+    layers = C.vgg_layers(wts, cfg)
+    X = rs.standard_normal((2, 8, 8, 3))
+    head = rs.standard_normal((2, 4, 4, 8))
+    xt = torch.as_tensor(X).permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = xt
+    for L in layers:
+        if L[0] == "conv":
+            y = F.relu(F.conv2d(y, torch.as_tensor(L[1]).double().permute(3, 2, 0, 1), torch.as_tensor(L[2]).double(), padding=1))
+        else:
+            y = F.max_pool2d(y, 2, 2)
+    (g,) = torch.autograd.grad(y, xt, grad_outputs=torch.as_tensor(head).permute(0, 3, 1, 2))
+    np.testing.assert_allclose(C.gradient_analyze(layers, X, head, "gradient"), g.permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-12)
