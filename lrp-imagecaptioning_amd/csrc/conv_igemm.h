@@ -57,8 +57,14 @@ enum ConvEpi {
   EPI_MUL = 2,        // out = acc * aux[img(row)]               (conv-LRP, no pool)
   EPI_MUL_UP2 = 3,    // out(2x res) = acc * aux[img(row)](2x)   (conv-LRP through a 2x2 max-pool)
   EPI_FWD_DUAL = 4,   // cols [0,split): out = relu(acc+bias); cols [split,2split): out2 = acc+bias  (a_l and Z+_l)
-  EPI_STORE = 5       // out = acc (row stride = N)   (image layer: tap-expanded channel reduction, see img_stencil_kernel)
+  EPI_STORE = 5,      // out = acc (row stride = N)   (image layer: tap-expanded channel reduction, see img_stencil_kernel)
+  // Image layer in ONE launch: the rows of a tile are a 16 x 16 pixel PATCH (14 x 14 output pixels + 1 halo), the
+  // tile computes T = S_1 . W (54 tap-expanded columns, see cnn_kernels.h) for the patch, keeps it in LDS and applies
+  // the 9-tap shift-and-add for its 14 x 14 interior: S_1 is read once (x 1.31 halo) and only R_img is written,
+  // instead of writing and re-reading the 3.5 GB T tensor.  BM = 256, BN = 64, 1 tap.
+  EPI_IMG_STENCIL = 6
 };
+constexpr int IMG_PATCH = 16, IMG_TILE = 14;
 
 struct ConvArgs {
   const float* in;     // [NB][H][W][Cin] fp32
@@ -75,6 +81,9 @@ struct ConvArgs {
   const int* row2img;  // per input image-slot n -> cache slot (nullptr = identity)
   int split;
   int out_plain;       // bf16x3 MUL epilogues: 1 = write fp32 instead of re-splitting (last GEMM of a chain)
+  // EPI_IMG_STENCIL: tiles per image row / column, ximg = the images (x of the image layer), mode 0 LRP | 1 sum | 2 x*sum
+  int tiles_x, tiles_y, img_mode;
+  const float* ximg;
   // gradient baselines on the MUL epilogues: the cached LRP gate is used as a MASK (gate != 0 <=> the unit's ReLU was
   // active and it won its pool window), and guided backprop also clamps the propagated value at 0
   int gate_binary, relu_out;
@@ -129,6 +138,14 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   }
   const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
+  int pn = 0, py0 = 0, px0 = 0;                        // EPI_IMG_STENCIL: image slot and first OUTPUT pixel of the patch
+  if constexpr (EPI == EPI_IMG_STENCIL) {
+    const int tpi = a.tiles_x * a.tiles_y;
+    pn = mt / tpi;
+    const int r = mt - pn * tpi, ty = r / a.tiles_x;
+    py0 = ty * IMG_TILE;
+    px0 = (r - ty * a.tiles_x) * IMG_TILE;
+  }
   int Y0 = 0, x0 = 0, img0 = 0;                          // HALO: first stack row / column of the tile, its image
   if constexpr (HALO) {
     const int tyt = mt / a.cols_t;
@@ -176,6 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   }
   // A, non-HALO: descriptor base = pixel (m0 - W - 1), so that every tap offset is >= 0
   const float* abase = HALO ? a.in + (size_t)(Y0 > 0 ? Y0 - 1 : 0) * a.W * a.Cin
+                       : EPI == EPI_IMG_STENCIL ? a.in + (size_t)pn * HW * a.Cin
                             : a.in + ((long)m0 - (a.taps == 1 ? 0 : a.W + 1)) * (long)a.Cin;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7FFFFFFF, RSRC_FLAGS);
   int avo[HALO ? 1 : AP];
@@ -190,6 +208,16 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
     for (int p = 0; p < AP; ++p) {
       const int r = rfirst + 8 * p, m = m0 + r;
       unsigned mask = 0;
+      if constexpr (EPI == EPI_IMG_STENCIL) {
+        // patch row r = (py, px) -> pixel (py0 - 1 + py, px0 - 1 + px) of image slot pn; outside the image: zero row
+        const int y = py0 - 1 + (r >> 4), x = px0 - 1 + (r & 15);
+        const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        amask[p] = ok ? 1u : 0u;
+        const int lc = (pchk ^ ((r >> 1) & 7)) << 2;
+        acf[p] = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;
+        avo[p] = ok ? ((y * a.W + x) * a.Cin + lc) * 4 : 0;
+        continue;
+      }
       if (m < a.M) {
         if (a.taps == 1) {
           mask = 1u;
@@ -484,7 +512,42 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   // ---- conv-LRP epilogues: stage the C tile through the (now idle) LDS so that the gate loads
   // and the relevance stores are 16 B per lane along the channel axis (a pixel's channels are
   // contiguous in NHWC) instead of one dword per lane.
-  if constexpr (EPI != EPI_STORE) {
+  if constexpr (EPI == EPI_IMG_STENCIL) {
+    static_assert(BM == IMG_PATCH * IMG_PATCH && BN == 64 && BM * BN <= 2 * STAGE, "patch tile is 256 x 64");
+    float* Ts = smem;                                   // T of the patch: [256 patch pixels][64 columns (54 used)]
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Ts[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    __syncthreads();
+    // R_img[p] = sum_tap T[p - d(tap)][tap], d = (kh - 1, kw - 1): patch pixel (oy + 2 - kh, ox + 2 - kw)
+    for (int o = tid; o < IMG_TILE * IMG_TILE; o += NT) {
+      const int oy = o / IMG_TILE, ox = o - oy * IMG_TILE;
+      const int y = py0 + oy, x = px0 + ox;
+      if (y >= a.H || x >= a.W) continue;
+      float pos[3] = {0.f, 0.f, 0.f}, neg[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float* r = Ts + ((oy + 2 - tap / 3) * IMG_PATCH + (ox + 2 - tap % 3)) * BN + tap * 6;
+        pos[0] += r[0]; pos[1] += r[1]; pos[2] += r[2];
+        neg[0] += r[3]; neg[1] += r[4]; neg[2] += r[5];
+      }
+      const int img = a.row2img ? a.row2img[pn] : pn;
+      const float* xv = a.ximg + ((size_t)img * HW + (size_t)y * a.W + x) * 3;
+      float* ov = a.out + ((size_t)pn * HW + (size_t)y * a.W + x) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (a.img_mode == 0) ov[c] = xv[c] >= 0.f ? xv[c] * pos[c] : xv[c] * neg[c];   // LRP alpha1beta0 at the image
+        else if (a.img_mode == 1) ov[c] = pos[c] + neg[c];                                // plain gradient
+        else ov[c] = xv[c] * (pos[c] + neg[c]);                                           // input x gradient
+      }
+    }
+    return;
+  } else if constexpr (EPI != EPI_STORE) {
     // The C tile goes through the staging LDS in NH row slabs (a 256-row tile does not fit at once).
     constexpr int NH = (BM * BN + 2 * STAGE - 1) / (2 * STAGE);
     constexpr int RH = BM / NH;                         // rows per slab
@@ -694,6 +757,20 @@ inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) 
   return best;
 }
 
+// EPI_IMG_STENCIL: NB = image slots (tokens), H x W = the image; in = S_1 (NB, H, W, Cin); N = 54 <= 64
+template <int PREC>
+inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
+  if (a.taps != 1 || a.N > 64 || !a.ximg || (a.Cin & (PREC == PREC_BF16X3 ? 7 : 3))) return hipErrorInvalidValue;
+  if (a.NB <= 0) return hipSuccess;
+  a.M = a.NB * a.H * a.W;
+  a.tiles_x = (a.W + IMG_TILE - 1) / IMG_TILE;
+  a.tiles_y = (a.H + IMG_TILE - 1) / IMG_TILE;
+  a.n_tiles = 1;
+  a.m_tiles = a.NB * a.tiles_x * a.tiles_y;
+  hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 2, 2, EPI_IMG_STENCIL, PREC>), dim3(a.m_tiles), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
 template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
@@ -717,6 +794,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
+
   if constexpr (PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS)) {
     const int mode = conv_halo_mode();
     // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
@@ -766,6 +844,7 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
       case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_BF16X3>(a, st);
       case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_BF16X3>(a, st);
       case EPI_STORE: return conv_launch_epi<EPI_STORE, PREC_BF16X3>(a, st);
+      case EPI_IMG_STENCIL: return conv_launch_img<PREC_BF16X3>(a, st);
       case EPI_BIAS: return conv_launch_epi<EPI_BIAS, PREC_BF16X3>(a, st);     // forward Z+ conv (fp32 out)
     }
     return hipErrorInvalidValue;
@@ -777,6 +856,7 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
     case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_FP32>(a, st);
     case EPI_FWD_DUAL: return conv_launch_epi<EPI_FWD_DUAL, PREC_FP32>(a, st);
     case EPI_STORE: return conv_launch_epi<EPI_STORE, PREC_FP32>(a, st);
+    case EPI_IMG_STENCIL: return conv_launch_img<PREC_FP32>(a, st);
   }
   return hipErrorInvalidValue;
 }

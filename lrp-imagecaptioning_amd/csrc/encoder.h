@@ -65,6 +65,10 @@ struct Encoder {
     if (ev_fwd) (void)hipEventDestroy(ev_fwd);
     if (ev_gates) (void)hipEventDestroy(ev_gates);
   }
+  static bool img_fused() {                            // LRP_IMG_FUSED=0: separate T GEMM + img_stencil_kernel
+    const char* e = getenv("LRP_IMG_FUSED");
+    return !e || atoi(e) != 0;
+  }
   static bool overlap_enabled() {
     const char* e = getenv("LRP_ENCODE_OVERLAP");
     return !e || atoi(e) != 0;
@@ -390,7 +394,12 @@ struct Encoder {
       ca.row2img = row2img_dev;
       ca.gate_binary = walk != 0; ca.relu_out = walk == 3;
       int epi;
-      if (li == 0) {
+      if (li == 0 && img_fused()) {
+        // T GEMM + 9-tap stencil in one launch (patch tiles, T stays in LDS)
+        ca.taps = 1; ca.N = IMG_T_COLS; ca.out = R_img_dev; ca.ximg = images.as<float>();
+        ca.img_mode = walk == 0 ? 0 : walk == 2 ? 2 : 1;
+        epi = EPI_IMG_STENCIL;
+      } else if (li == 0) {
         ca.NB = n * L.H * L.W; ca.H = 1; ca.W = 1; ca.taps = 1;          // 1-tap GEMM over the pixels
         ca.N = IMG_T_COLS; ca.out = Snext; epi = EPI_STORE;
       } else {
@@ -411,7 +420,7 @@ struct Encoder {
       }
       float* t = S; S = Snext; Snext = t;
     }
-    {  // S now holds T (n, H, W, 54): 9-tap shift-and-add and the x+/x- selection
+    if (!img_fused()) {  // S now holds T (n, H, W, 54): 9-tap shift-and-add and the x+/x- selection
       const ConvLayer& L0 = layers[0];
       hipLaunchKernelGGL(img_stencil_kernel, dim3(stream_grid((size_t)n * L0.H * L0.W)), dim3(256), 0, st, S,
                          images.as<float>(), row2img_dev, R_img_dev, n, L0.H, L0.W, walk == 0 ? 0 : walk == 2 ? 2 : 1);
