@@ -779,6 +779,13 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if (PREC == PREC_BF16X3 && (a.Cin & 7)) return hipErrorInvalidValue;
   if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
   ConvTile t = conv_pick_tile(a.N);
+  if (PREC == PREC_FP32 && t.BN == 128 && (a.N % 64) == 0) {
+    // few M rows (the per-image forward at batch 32): 128 x 128 tiles leave CUs idle; halve the tile
+    // [MI355X] encode of 32 images 14.06 -> 13.54 ms with the threshold at 2200 blocks (~4 waves of 512 slots)
+    static const int thr = [] { const char* e = getenv("LRP_SMALLTILE_BLOCKS"); return e ? atoi(e) : 2200; }();
+    const long blocks = (((long)a.NB * a.H * a.W + 127) / 128) * ((a.N + 127) / 128);
+    if (blocks < thr) t = {128, 64};
+  }
   int wide = 0;
   if (PREC == PREC_BF16X3 && a.N >= 128 && (a.N % 128) == 0) {
     wide = (a.N % 256) == 0 ? 256 : 128;
