@@ -235,6 +235,7 @@ int lrp_set_precision(lrp_handle* h, int32_t mode) {
   if (!h) return fail(LRP_ERR_INVALID, "null handle");
   if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3) return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);
   h->enc.prec = mode;
+  h->rn.prec = mode;
   h->dec.prec = mode;
   return LRP_OK;
 }

@@ -24,7 +24,7 @@ struct RnUnit {            // conv + BN
   int Hin = 0, Win = 0, Hout = 0, Wout = 0;
   bool relu = false;
   bool have[6] = {false, false, false, false, false, false};   // W b gamma beta mean var
-  DevBuf w_a, w_z, w_b, bias, gamma, beta, mean, var;
+  DevBuf w_a, w_z, w_b, w_bs, bias, gamma, beta, mean, var;   // w_bs: w_b in split8 form (bf16x3 reverse walk)
   DevBuf gate;             // [B][Hout][Wout][cout]: act*Q (relu units) or Q (pre-Add units)
   size_t out_elems() const { return (size_t)Hout * Wout * cout; }
   size_t in_elems() const { return (size_t)Hin * Win * cin; }
@@ -50,6 +50,7 @@ struct ResNetEncoder {
   int encoded = 0;
   bool features_only = false;
   bool profile = false;
+  int prec = PREC_BF16X3;  // arithmetic of the reverse walk's conv chains (lrp_set_precision); forward stays exact fp32
   std::vector<ProfileRec> prof;
 
   int add_unit(const std::string& nm, int k, int cin, int cout, int stride, int Hin, int Win, bool relu) {
@@ -183,7 +184,10 @@ struct ResNetEncoder {
     const int Npb = conv_npad(u.cin), Kb = taps * conv_cinp(u.cout);
     pk.assign((size_t)Npb * Kb, 0.f);
     pack_conv_bwd(wp.data(), taps, u.cin, u.cout, 0, pk.data());
-    return up(u.w_b, pk, total);
+    LRP_TRY(up(u.w_b, pk, total));
+    std::vector<float> sp(pk.size());
+    pack_split8(pk.data(), pk.size(), sp.data());
+    return up(u.w_bs, sp, total);
   }
 
   int check_ready() const {
@@ -279,13 +283,17 @@ struct ResNetEncoder {
   }
 
   // conv-LRP step through one unit: S [n][Hout][Wout][cout] -> out [n][Hout'][..][cin] = convT(S, w+) * aux[img]
-  int unit_backward(const RnUnit& u, int n, const int* row2img, const float* S, const float* aux, float* out, hipStream_t st) {
+  // split: S is in split8 form and the conv runs as bf16x3; plain_out: the result feeds an element-wise kernel (fp32)
+  // instead of the next conv of the chain (split8)
+  int unit_backward(const RnUnit& u, int n, const int* row2img, const float* S, const float* aux, float* out, hipStream_t st,
+                    bool split = false, bool plain_out = true) {
     ConvArgs ca{};
-    ca.in = S; ca.wpk = u.w_b.as<float>(); ca.row2img = row2img; ca.aux = aux; ca.out = out; ca.N = u.cin;
+    ca.in = S; ca.wpk = split ? u.w_bs.as<float>() : u.w_b.as<float>(); ca.row2img = row2img; ca.aux = aux; ca.out = out;
+    ca.N = u.cin; ca.out_plain = plain_out ? 1 : 0;
     ca.Cin = u.cout; ca.CinP = conv_cinp(u.cout); ca.NB = n; ca.H = u.Hout; ca.W = u.Wout; ca.taps = u.k == 3 ? 9 : 1;
     ProfileRec pr{};
     if (profile) { (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1); (void)hipEventRecord(pr.e0, st); }
-    LRP_HIP_CHECK(conv_launch(EPI_MUL, ca, st));
+    LRP_HIP_CHECK(conv_launch(EPI_MUL, ca, st, split ? PREC_BF16X3 : PREC_FP32));
     if (profile) {
       (void)hipEventRecord(pr.e1, st);
       pr.flop = 2.0 * n * u.Hout * u.Wout * (double)(u.k == 3 ? 9 : 1) * u.cout * u.cin;
@@ -303,20 +311,30 @@ struct ResNetEncoder {
     for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
       const RnBlock& b = blocks[bi];
       const size_t per_o = (size_t)b.H * b.W * 4 * b.f;
-      // S3 = R_o * (fA Q3)
-      hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GA.as<float>(),
-                         row2img, (const float*)nullptr, r1.as<float>(), n, per_o);
+      // bf16x3 mode: the three convs of the main branch (and the projection) chain in split8 form; the products that
+      // enter a chain are written split, what leaves it for the add / scatter kernels is plain fp32
+      bool sp = prec == PREC_BF16X3;                     // split8 groups need channel counts % 8 == 0: exact fp32 otherwise
+      for (int ui : {b.u0, b.u1, b.u2, b.u3})
+        if (ui >= 0 && ((units[ui].cin | units[ui].cout) & 7)) sp = false;
+      auto head = [&](const float* G) {
+        if (sp)
+          hipLaunchKernelGGL(rn_mul_gate_split_kernel, dim3(stream_grid((size_t)n * per_o / 8)), dim3(256), 0, st, Ro, G, row2img,
+                             r1.as<float>(), n, per_o / 8);
+        else
+          hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, G, row2img,
+                             (const float*)nullptr, r1.as<float>(), n, per_o);
+      };
+      head(b.GA.as<float>());                            // S3 = R_o * (fA Q3)
       LRP_HIP_CHECK(hipGetLastError());
-      LRP_TRY(unit_backward(units[b.u3], n, row2img, r1.as<float>(), units[b.u2].gate.as<float>(), r2.as<float>(), st));  // S2
-      LRP_TRY(unit_backward(units[b.u2], n, row2img, r2.as<float>(), units[b.u1].gate.as<float>(), r1.as<float>(), st));  // S1
+      LRP_TRY(unit_backward(units[b.u3], n, row2img, r1.as<float>(), units[b.u2].gate.as<float>(), r2.as<float>(), st, sp, !sp));  // S2
+      LRP_TRY(unit_backward(units[b.u2], n, row2img, r2.as<float>(), units[b.u1].gate.as<float>(), r1.as<float>(), st, sp, !sp));  // S1
       const float* taux = b.stride == 2 ? b.t_sub.as<float>() : b.t_in.as<float>();
-      LRP_TRY(unit_backward(units[b.u1], n, row2img, r1.as<float>(), taux, r2.as<float>(), st));                          // t*C1 (coarse)
+      LRP_TRY(unit_backward(units[b.u1], n, row2img, r1.as<float>(), taux, r2.as<float>(), st, sp, true));               // t*C1 (coarse)
       const size_t per_c = (size_t)b.H * b.W * b.cin;          // coarse (= fine when stride 1)
       if (b.u0 >= 0) {
-        hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GS.as<float>(),
-                           row2img, (const float*)nullptr, r1.as<float>(), n, per_o);                                     // S0
+        head(b.GS.as<float>());                                                                                           // S0
         LRP_HIP_CHECK(hipGetLastError());
-        LRP_TRY(unit_backward(units[b.u0], n, row2img, r1.as<float>(), taux, r3.as<float>(), st));                        // t*C0
+        LRP_TRY(unit_backward(units[b.u0], n, row2img, r1.as<float>(), taux, r3.as<float>(), st, sp, true));              // t*C0
         if (b.stride == 2) {
           const size_t tot = (size_t)n * b.Hin * b.Win * b.cin;
           hipLaunchKernelGGL(rn_scatter2_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur, n,

@@ -46,6 +46,25 @@ __global__ __launch_bounds__(256) void rn_block_out_kernel(const float* __restri
   }
 }
 
+// the same product written in the split-bf16 operand format of the conv kernel (8 channels per thread; head of a
+// conv chain in the bf16x3 mode)
+__global__ __launch_bounds__(256) void rn_mul_gate_split_kernel(const float* __restrict__ R, const float* __restrict__ G,
+                                                                const int* __restrict__ row2img, float* __restrict__ out,
+                                                                int ntok, size_t per_img8) {
+  const size_t total = (size_t)ntok * per_img8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int t = (int)(i / per_img8);
+    const size_t e = i - (size_t)t * per_img8;
+    const int img = row2img ? row2img[t] : t;
+    const float* r = R + i * 8;
+    const float* g = G + ((size_t)img * per_img8 + e) * 8;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = r[q] * g[q];
+    split8_store(v, out + i * 8);
+  }
+}
+
 // out[t][e] = R[t][e] * G[img(t)][e]  (+ add[t][e])
 __global__ __launch_bounds__(256) void rn_mul_gate_kernel(const float* __restrict__ R, const float* __restrict__ G,
                                                           const int* __restrict__ row2img, const float* __restrict__ add,

@@ -23,14 +23,16 @@ def _engine(stacks, stem, hw, B, ntok, w, decoder="gridtd", H=32, V=50):
     return eng, side, D
 
 
-@pytest.mark.parametrize("name,stacks,stem,hw,B", [("tiny", ((4, 2), (8, 2)), 8, 32, 2),
+@pytest.mark.parametrize("prec", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("name,stacks,stem,hw,B", [("tiny", ((4, 2), (8, 2)), 8, 32, 2),      # widths % 8 != 0: fp32 either way
                                                    ("mid", ((8, 2), (16, 3), (32, 2)), 16, 64, 2)])
-def test_small_resnets_match_oracle(name, stacks, stem, hw, B):
+def test_small_resnets_match_oracle(name, stacks, stem, hw, B, prec):
     rs = np.random.RandomState(3)
     w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
     spec = RN.resnet_spec(stacks, stem=stem)
     X = rs.uniform(-120, 130, size=(B, hw, hw, 3)).astype(np.float32)
     eng, side, D = _engine(stacks, stem, hw, B, 2 * B, w)
+    eng.set_precision(prec)
     eng.encode_images(X)
     feat = eng.get_features().cpu().numpy().reshape(B, side, side, D)
     feat_ref = RN.forward(w, spec, X)
@@ -40,19 +42,22 @@ def test_small_resnets_match_oracle(name, stacks, stem, hw, B):
     out = eng.cnn_explain(idx, R).cpu().numpy()
     ref = RN.analyze(w, spec, X[idx], R)
     errs = [rel_l1(out[i], ref[i]) for i in range(2 * B)]
-    report("resnet_" + name, feat_rel_l1=rel_l1(feat, feat_ref), max_rel_l1=max(errs))
+    report("resnet_" + name, prec=prec, feat_rel_l1=rel_l1(feat, feat_ref), max_rel_l1=max(errs))
     assert np.isfinite(out).all()
     assert max(errs) < TOL, errs
 
 
-def test_resnet101_full_size_matches_oracle():
-    """ResNet-101, 224x224 -> (7,7,2048) (config.py:41-45), one image, two relevance maps."""
+@pytest.mark.parametrize("prec", ["bf16x3", "fp32"])
+def test_resnet101_full_size_matches_oracle(prec):
+    """ResNet-101, 224x224 -> (7,7,2048) (config.py:41-45), one image, two relevance maps; the reverse walk's conv
+    chains in the default split-bf16 mode and in exact fp32."""
     rs = np.random.RandomState(0)
     w = resnet_weights(rs)
     spec = RN.resnet_spec()
     X = rs.uniform(-120, 130, size=(1, 224, 224, 3)).astype(np.float32)
     eng, side, D = _engine(RESNET101_STACKS, 64, 224, 1, 2, w)
     assert (side, D) == (7, 2048)
+    eng.set_precision(prec)
     eng.encode_images(X)
     feat = eng.get_features().cpu().numpy().reshape(1, 7, 7, 2048)
     feat_ref = RN.forward(w, spec, X)
@@ -61,7 +66,7 @@ def test_resnet101_full_size_matches_oracle():
     out = eng.cnn_explain([0, 0], R).cpu().numpy()
     ref = RN.analyze(w, spec, np.repeat(X, 2, axis=0), R)
     errs = [rel_l1(out[i], ref[i]) for i in range(2)]
-    report("resnet101", feat_rel_l1=e_feat, max_rel_l1=max(errs))
+    report("resnet101", prec=prec, feat_rel_l1=e_feat, max_rel_l1=max(errs))
     assert e_feat < 1e-5
     assert max(errs) < TOL, errs
 
