@@ -203,7 +203,7 @@ def pmc_traffic_per_launch(precision="bf16x3"):
     tot = n = 0.0
     for k, v in d.items():
         # reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5)
-        m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)?>", k)
+        m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>", k)
         if m and m.group(1) in ("2", "3", "5") and m.group(2) == ("1" if precision == "bf16x3" else "0"):
             if "fetch_bytes_per_launch_x2corr" in v and "write_bytes_per_launch" in v:
                 tot += (v["fetch_bytes_per_launch_x2corr"] + v["write_bytes_per_launch"]) * v["launches"]

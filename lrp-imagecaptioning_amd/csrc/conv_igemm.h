@@ -69,6 +69,7 @@ constexpr int IMG_PATCH = 16, IMG_TILE = 14;
 struct ConvArgs {
   const float* in;     // [NB][H][W][Cin] fp32
   const float* wpk;    // [n_tiles*BN][K] fp32, K = taps*CinP, CinP = roundup(Cin,32), zero padded
+  const float* wpk_frag;  // BREG: the same weights fragment-major, [kc][step][hi|lo][lane half][BN = 64] x 16 B
   int NB, H, W, Cin, CinP;
   int N;               // valid output columns
   int taps;            // 9 (3x3 same) or 1
@@ -91,6 +92,11 @@ struct ConvArgs {
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
   int tw, th, hrows, cols_t, nyh;
+  // Token-grouped tile order (reverse walk, tokens of an image are consecutive image slots and share its gates):
+  // M tiles are token-aligned, tok_tiles per token, and run in the order (group of `grp` tokens, spatial tile,
+  // token in group), so the gate tile a spatial position needs is fetched from HBM once per group and re-used out
+  // of the XCD's L2 by the other tokens' tiles that run next to it, instead of once per token.  grp = 0: plain order.
+  int grp, tok_tiles;
 };
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -115,15 +121,21 @@ constexpr int conv_min_waves(int NW, int TM, int TN, bool halo = false) { return
 constexpr int HALO_PITCH = 16, HALO_PL = 4;
 constexpr int conv_halo_rows(int BM) { return BM == 256 ? 352 : 192; }   // x 128 B; 22 / 12 image rows
 
-template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false>
-__global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
+// BREG (HALO, bf16x3, N <= 64 layers): the weights never touch LDS.  With K <= 2 x 32 channels per group the whole A
+// operand of a group is resident (both LDS buffers hold one 32-channel chunk each), and the B fragments of a
+// (tap, chunk) are 4 coalesced 16 B loads per lane from a fragment-major copy of the packed weights (wpk_frag,
+// L1/L2 resident: 8 KB per tap), prefetched one tap ahead in registers.  The main loop then has NO barrier per tap —
+// only one per channel group — which is what the 12-MFMA-per-tap waves of the N = 64 tiles could not amortise.
+template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false, bool BREG = false>
+__global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;   // 1 KiB (8-row) DMA pieces per wave and chunk
   constexpr int HR = conv_halo_rows(BM);              // HALO: LDS rows (pixels) of the resident image
   constexpr int ABUF = (HALO ? HR : BM) * LDS_STRIDE;
-  constexpr int STAGE = ABUF + BN * LDS_STRIDE;
+  constexpr int STAGE = ABUF + (BREG ? 0 : BN) * LDS_STRIDE;
+  static_assert(!BREG || (HALO && PREC == PREC_BF16X3 && BM * BN <= 2 * STAGE), "BREG needs the resident image");
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
   static_assert(!HALO || EPI != EPI_STORE, "the image layer is a 1-tap GEMM");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
@@ -136,7 +148,16 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
+  int mt = logical / a.n_tiles;
+  const int nt = logical - mt * a.n_tiles;
+  int tok = 0, ltile = 0;                              // token (image slot) and its local tile, when token-aligned
+  if (a.grp > 0) {
+    const int per = a.grp * a.tok_tiles, gi = mt / per, rem = mt - gi * per;
+    const int left = a.NB - gi * a.grp, ge = left < a.grp ? left : a.grp;      // tokens in this (possibly last) group
+    ltile = rem / ge;
+    tok = gi * a.grp + (rem - ltile * ge);
+    mt = tok * a.tok_tiles + ltile;
+  }
   const int m0 = mt * BM, n0 = nt * BN;
   int pn = 0, py0 = 0, px0 = 0;                        // EPI_IMG_STENCIL: image slot and first OUTPUT pixel of the patch
   if constexpr (EPI == EPI_IMG_STENCIL) {
@@ -147,11 +168,20 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
     px0 = (r - ty * a.tiles_x) * IMG_TILE;
   }
   int Y0 = 0, x0 = 0, img0 = 0;                          // HALO: first stack row / column of the tile, its image
+  int Yend = a.nyh;                                    // HALO: first stack row this tile must not touch
   if constexpr (HALO) {
-    const int tyt = mt / a.cols_t;
-    Y0 = tyt * a.th;
-    x0 = (mt - tyt * a.cols_t) * a.tw;
-    img0 = Y0 / a.H;
+    if (a.grp > 0) {                                   // token-aligned tiles: (rows of tiles) x cols_t per token
+      const int tyt = ltile / a.cols_t;
+      Y0 = tok * a.H + tyt * a.th;
+      x0 = (ltile - tyt * a.cols_t) * a.tw;
+      img0 = tok;
+      Yend = (tok + 1) * a.H;
+    } else {
+      const int tyt = mt / a.cols_t;
+      Y0 = tyt * a.th;
+      x0 = (mt - tyt * a.cols_t) * a.tw;
+      img0 = Y0 / a.H;
+    }
   }
   // exact small-integer division (operands < 2^22): float estimate + one fix-up step
   auto divmod = [](int x, int d, float inv, int& q, int& r) {
@@ -318,12 +348,19 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   // has finished reading buffer kc&1) and is waited for at the barrier of iteration kc+1, so a load has a whole
   // iteration (48 MFMAs per wave on the 8-wave tile) to land — launching it at the top of iteration kc+1 instead
   // left it half of that, which the HBM / MALL latency of the A rows did not fit into in the bf16x3 mode.
-  if constexpr (HALO) {
-    for (int p = wave_s; p < halo_np; p += NW) fire_halo_piece(prep_halo_piece(p, 0, true), p, 0);
-    if (wave_s < halo_np) fire_halo_piece(prep_halo_piece(wave_s, 1, cpt > 1), wave_s, 1);   // slot 0 of chunk 1 (see the loop)
+  if constexpr (BREG) {
+    for (int p = wave_s; p < halo_np; p += NW) {         // channel chunks 0 and 1 -> LDS buffers 0 and 1
+      fire_halo_piece(prep_halo_piece(p, 0, true), p, 0);
+      fire_halo_piece(prep_halo_piece(p, 1, cpt > 1), p, 1);
+    }
+  } else {
+    if constexpr (HALO) {
+      for (int p = wave_s; p < halo_np; p += NW) fire_halo_piece(prep_halo_piece(p, 0, true), p, 0);
+      if (wave_s < halo_np) fire_halo_piece(prep_halo_piece(wave_s, 1, cpt > 1), wave_s, 1);   // slot 0 of chunk 1 (see the loop)
+    }
+    fire_chunk(prep_chunk(true), 0);
+    fire_chunk(prep_chunk(nk > 1), 1);
   }
-  fire_chunk(prep_chunk(true), 0);
-  fire_chunk(prep_chunk(nk > 1), 1);
   // hipcc gives __syncthreads() an lgkmcnt(0) only; the LDS-DMA completes on vmcnt, so the wait is explicit
   auto dma_landed_barrier = [] {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -345,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
       divmod(r, a.tw, inv_tw, ty, tx);
       const int Y = Y0 + ty;
       divmod(Y, a.H, inv_H, n_, h_);
-      const bool ok = r < a.th * a.tw && Y < a.nyh && x0 + tx < a.W;
+      const bool ok = r < a.th * a.tw && Y < Yend && x0 + tx < a.W;
       const int hy = ok ? ty + 1 + n_ - img0 : 1, hx = ok ? tx + 1 : 1;
       fbase[i] = hy * HALO_PITCH + hx;
       fu[i] = hy * a.tw + hx - 1;
@@ -437,11 +474,86 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
     }
   };
 
+  if constexpr (BREG) {
+    static_assert(NSTEP == 2, "bf16x3");
+    // B fragments of (kc = chunk*9 + tap): [step][hi|lo] x TN, one 16 B load each
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_frag, 0, nk * 8 * BN * 16, RSRC_FLAGS);
+    const int fvo = ((lane >> 5) * BN + wn * TN * 32 + (lane & 31)) * 16;
+    struct BFrag { u32x4 v[4 * TN]; };
+    auto load_b = [&](BFrag& b, int kc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)                        // q = 2*step + (0 hi | 1 lo)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b.v[q * TN + j] = __builtin_amdgcn_raw_buffer_load_b128(rsF, fvo + j * 32 * 16, ((kc * 4 + q) * 2) * BN * 16, 0);
+    };
+    struct AFrag { u32x4 v[4 * TM]; };                   // [step][hi|lo] x TM
+    auto load_a = [&](AFrag& f, const float* Ab) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          f.v[q * TM + i] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ (((q >> 1) * 4 + (q & 1)) << 2)));
+    };
+    auto mma = [&](const AFrag& f, const BFrag& b) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, f.v[(2 * st) * TM + i]), al = __builtin_bit_cast(bf16x8, f.v[(2 * st + 1) * TM + i]);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, b.v[(2 * st) * TN + j]), bl = __builtin_bit_cast(bf16x8, b.v[(2 * st + 1) * TN + j]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+          }
+    };
+    BFrag b0, b1;
+    AFrag a0, a1;
+    load_b(b0, 0);
+    for (int g = 0; g < cpt; g += 2) {                   // groups of two channel chunks = the two LDS buffers
+      if (g > 0) {
+        __syncthreads();                                 // everyone is done with the previous group's image
+        for (int p = wave_s; p < halo_np; p += NW) {
+          fire_halo_piece(prep_halo_piece(p, g, true), p, 0);
+          fire_halo_piece(prep_halo_piece(p, g + 1, g + 1 < cpt), p, 1);
+        }
+        dma_landed_barrier();
+      }
+      const int ng = (g + 2 <= cpt ? 2 : 1) * 9;         // (tap, chunk) pairs of this group
+      set_tap(0);
+      load_a(a0, smem);
+      // Two pairs per trip (the register double buffers alternate).  The body is branch-free on purpose — prefetches
+      // past the end are clamped re-loads — so that it stays ONE basic block and hipcc can wait for exactly the four
+      // older weight loads (vmcnt(4)); with branches around the loads it fell back to vmcnt(0) on every tap.
+      int nt = 0, nc = 0;                                // (tap, chunk in group) of the pair being prefetched
+      for (int q = 0; q < ng; q += 2) {
+        const int kc = g * 9 + q;
+        if (++nt == 9) { nt = 0; ++nc; }
+        load_b(b1, kc + 1 < nk ? kc + 1 : nk - 1);
+        set_tap(nt);
+        load_a(a1, smem + (nc > 1 ? 1 : nc) * STAGE);
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetches ABOVE the 12 MFMAs they hide behind
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (++nt == 9) { nt = 0; ++nc; }
+        load_b(b0, kc + 2 < nk ? kc + 2 : nk - 1);
+        set_tap(nt);
+        load_a(a0, smem + (nc > 1 ? 1 : nc) * STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < ng) mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
   Frag f0, f1;
   int ctap = 0, ccc = 0;                               // HALO: (tap, channel chunk) being COMPUTED; kc = ccc*9 + ctap
+  if constexpr (!BREG) {
   set_tap(0);
   read_frag(f0, smem + a_off, smem + b_off, 0);
-  for (int kc = 0; kc < nk; ++kc) {
+  }
+  for (int kc = 0; kc < (BREG ? 0 : nk); ++kc) {
     const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
     const int abuf = HALO ? (ccc & 1) : buf;
@@ -513,7 +625,10 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
   // and the relevance stores are 16 B per lane along the channel axis (a pixel's channels are
   // contiguous in NHWC) instead of one dword per lane.
   if constexpr (EPI == EPI_IMG_STENCIL) {
-    static_assert(BM == IMG_PATCH * IMG_PATCH && BN == 64 && BM * BN <= 2 * STAGE, "patch tile is 256 x 64");
+    // row stride 65 floats: with 64 (= 256 B = one sweep of the banks) the stencil's reads of one column across the
+    // 64 pixels of a wave all hit the same bank  [MI355X: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.75]
+    constexpr int TS = BN + 1;
+    static_assert(BM == IMG_PATCH * IMG_PATCH && BN == 64 && BM * TS <= 2 * STAGE, "patch tile is 256 x 64");
     float* Ts = smem;                                   // T of the patch: [256 patch pixels][64 columns (54 used)]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -521,7 +636,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
       for (int r = 0; r < 16; ++r) {
         const int lr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Ts[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
+        for (int j = 0; j < TN; ++j) Ts[lr * TS + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
       }
     __syncthreads();
     // R_img[p] = sum_tap T[p - d(tap)][tap], d = (kh - 1, kw - 1): patch pixel (oy + 2 - kh, ox + 2 - kw)
@@ -532,7 +647,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
       float pos[3] = {0.f, 0.f, 0.f}, neg[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const float* r = Ts + ((oy + 2 - tap / 3) * IMG_PATCH + (ox + 2 - tap % 3)) * BN + tap * 6;
+        const float* r = Ts + ((oy + 2 - tap / 3) * IMG_PATCH + (ox + 2 - tap % 3)) * TS + tap * 6;
         pos[0] += r[0]; pos[1] += r[1]; pos[2] += r[2];
         neg[0] += r[3]; neg[1] += r[4]; neg[2] += r[5];
       }
@@ -567,7 +682,7 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
         divmod(lr, a.tw, inv_tw, ty, tx);
         const int Y = Y0 + ty;
         w = x0 + tx;
-        if (lr >= a.th * a.tw || Y >= a.nyh || w >= a.W) return false;
+        if (lr >= a.th * a.tw || Y >= Yend || w >= a.W) return false;
         divmod(Y, a.H, inv_H, n, h);
         row = Y * a.W + w;
         return true;
@@ -636,54 +751,80 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(WM * WN, TM, TN, HALO)
           }
         }
       } else {
+        // out = acc * gate (fp32), stored as fp32 or re-split into [hi8 | lo8] for the next layer's MFMAs.
+        // The gate values are two dependent global loads away (row2img[n], then the gate row) and nothing in a pass
+        // depends on the pass before it, so the loads are issued in bulk: every pass's image slot first, then the
+        // gate rows one pass AHEAD of the arithmetic (written as explicit phases — left as load/multiply/store per
+        // pass, the possible aliasing of `out` and `aux` made hipcc serialise a full memory round trip per pass, which
+        // the short K = 576 layers could not hide).
         if (col < a.N) {
-#pragma unroll 4
-          for (int ps = 0; ps < RH / RPP; ++ps) {
-            const int ll = rin + ps * RPP;
-            int row, n, h, w;
-            if (!locate(hf * RH + ll, row, n, h, w)) continue;
-            float v[CW];
+          constexpr int NP = RH / RPP;
+          constexpr int UPN = EPI == EPI_MUL_UP2 ? 4 : 1;
+          const int W2 = 2 * a.W, H2 = 2 * a.H;
+          int rowv[NP], nv[NP], hv[NP], wv[NP], imgv[NP];
+          bool okv[NP];
 #pragma unroll
-            for (int q4 = 0; q4 < CW / 4; ++q4)
-              *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * CW + 4 * q4);
-            const int pix = h * a.W + w;
-            const int img = a.row2img ? a.row2img[n] : n;
-            // out = acc * gate (fp32), stored as fp32 or re-split into [hi8 | lo8] for the next layer's MFMAs
-            auto emit = [&](const float* gsrc, float* dst) {
-              float r[CW];
+          for (int ps = 0; ps < NP; ++ps) {
+            okv[ps] = locate(hf * RH + rin + ps * RPP, rowv[ps], nv[ps], hv[ps], wv[ps]);
+            if (!okv[ps]) { rowv[ps] = 0; nv[ps] = 0; hv[ps] = 0; wv[ps] = 0; }
+            imgv[ps] = a.row2img ? a.row2img[nv[ps]] : nv[ps];
+          }
+          struct Gates { f32x4 g[UPN][CW / 4]; };
+          auto gate_ptr = [&](int ps, int q) -> const float* {
+            if constexpr (EPI == EPI_MUL)
+              return a.aux + ((size_t)imgv[ps] * HW + hv[ps] * a.W + wv[ps]) * a.N + col;
+            else
+              return a.aux + (((size_t)imgv[ps] * H2 + 2 * hv[ps] + (q >> 1)) * W2 + 2 * wv[ps] + (q & 1)) * a.N + col;
+          };
+          auto load_gates = [&](Gates& G, int ps) {
 #pragma unroll
-              for (int q4 = 0; q4 < CW / 4; ++q4) {
-                f32x4 g = *reinterpret_cast<const f32x4*>(gsrc + 4 * q4);
-                if (a.gate_binary) {
+            for (int q = 0; q < UPN; ++q)
 #pragma unroll
-                  for (int q = 0; q < 4; ++q) g[q] = g[q] != 0.f ? 1.f : 0.f;
+              for (int q4 = 0; q4 < CW / 4; ++q4) G.g[q][q4] = *reinterpret_cast<const f32x4*>(gate_ptr(ps, q) + 4 * q4);
+          };
+          Gates cur, nxt;
+          load_gates(cur, 0);
+#pragma unroll
+          for (int ps = 0; ps < NP; ++ps) {
+            if (ps + 1 < NP) load_gates(nxt, ps + 1);
+            if (okv[ps]) {
+              const int ll = rin + ps * RPP;
+              float v[CW];
+#pragma unroll
+              for (int q4 = 0; q4 < CW / 4; ++q4)
+                *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * CW + 4 * q4);
+#pragma unroll
+              for (int q = 0; q < UPN; ++q) {
+                float r[CW];
+#pragma unroll
+                for (int q4 = 0; q4 < CW / 4; ++q4) {
+                  f32x4 g = cur.g[q][q4];
+                  if (a.gate_binary) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = g[e] != 0.f ? 1.f : 0.f;
+                  }
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float pr = v[4 * q4 + e] * g[e];
+                    r[4 * q4 + e] = a.relu_out ? fmaxf(pr, 0.f) : pr;
+                  }
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                  const float p = v[4 * q4 + q] * g[q];
-                  r[4 * q4 + q] = a.relu_out ? fmaxf(p, 0.f) : p;
-                }
-              }
-              if constexpr (SPLIT_OUT) {
-                if (a.out_plain) {
-                  *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
-                  *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(r + 4);
+                float* dst = EPI == EPI_MUL
+                                 ? a.out + (size_t)rowv[ps] * a.N + col
+                                 : a.out + (((size_t)nv[ps] * H2 + 2 * hv[ps] + (q >> 1)) * W2 + 2 * wv[ps] + (q & 1)) * a.N + col;
+                if constexpr (SPLIT_OUT) {
+                  if (a.out_plain) {
+                    *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+                    *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(r + 4);
+                  } else {
+                    split8_store(r, dst);
+                  }
                 } else {
-                  split8_store(r, dst);
+                  *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
                 }
-              } else {
-                *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
               }
-            };
-            if constexpr (EPI == EPI_MUL) {
-              emit(a.aux + ((size_t)img * HW + pix) * a.N + col, a.out + (size_t)row * a.N + col);
-            } else {
-              const int W2 = 2 * a.W, H2 = 2 * a.H;
-#pragma unroll
-              for (int q = 0; q < 4; ++q)
-                emit(a.aux + (((size_t)img * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col,
-                     a.out + (((size_t)n * H2 + 2 * h + (q >> 1)) * W2 + 2 * w + (q & 1)) * a.N + col);
             }
+            cur = nxt;
           }
         }
       }
@@ -771,6 +912,23 @@ inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
   return hipGetLastError();
 }
 
+// token-grouped tile order (ConvArgs::grp): env LRP_CONV_GROUP = group size, 0 = off
+inline int conv_group_size() {
+  // [MI355X] measured neutral (block1_conv2 3.84 -> 3.75 ms, block2_conv2 3.07 -> 3.21 ms): the gate re-reads of
+  // consecutive tokens already hit the 256 MB MALL.  Kept as an experiment knob, off by default.
+  static const int g = [] { const char* e = getenv("LRP_CONV_GROUP"); return e ? atoi(e) : 0; }();
+  return g;
+}
+// halo tiles aligned per token: worth it when the ragged last tile row wastes <= 5 % of the MFMA rows
+inline bool conv_group_halo(ConvArgs& a) {
+  const int rows_t = (a.H + a.th - 1) / a.th;
+  if (conv_group_size() < 2 || !a.row2img || a.NB < 2 || rows_t * a.th * 20 > a.H * 21) return false;
+  a.grp = conv_group_size();
+  a.tok_tiles = rows_t * a.cols_t;
+  a.m_tiles = a.NB * a.tok_tiles;
+  return true;
+}
+
 template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
@@ -806,12 +964,28 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     const int mode = conv_halo_mode();
     // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
     // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
+    if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
+      // N <= 64: resident image + weights in registers, no barrier per tap (LRP_CONV_BREG=0 disables)
+      static const int breg = [] { const char* e = getenv("LRP_CONV_BREG"); return e ? atoi(e) : 1; }();
+      if (a.taps == 9 && mode > 0 && breg && t.BN == 64 && a.n_tiles == 1 && a.wpk_frag) {
+        const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
+        if (u >= 0.9f || (mode == 2 && u > 0.f)) {
+          a.nyh = a.NB * a.H;
+          a.cols_t = (a.W + a.tw - 1) / a.tw;
+          a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+          conv_group_halo(a);
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(256), 0, st, a);
+          return hipGetLastError();
+        }
+      }
+    }
     if (a.taps == 9 && mode > 0 && (t.BN >= 128 || (mode == 2 && t.BN >= 64)) && wide != 128) {
       const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
       if (u >= 0.9f || (mode == 2 && u > 0.f)) {
         a.nyh = a.NB * a.H;
         a.cols_t = (a.W + a.tw - 1) / a.tw;
         a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+        if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) conv_group_halo(a);
         const dim3 hgrid(a.m_tiles * a.n_tiles);
         if (wide == 256)
           hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true>), hgrid, dim3(512), 0, st, a);
@@ -821,6 +995,27 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true>), hgrid, dim3(256), 0, st, a);
         return hipGetLastError();
       }
+    }
+  }
+  if constexpr (PREC == PREC_FP32 && EPI == EPI_BIAS_RELU) {
+    // exact-fp32 forward chain: same resident-image variant on the 128 x 128 tile (experiment knob LRP_CONV_HALO_FP32)
+    static const int on = [] { const char* e = getenv("LRP_CONV_HALO_FP32"); return e ? atoi(e) : 0; }();
+    if (on && a.taps == 9 && t.BN == 128) {
+      const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
+      if (u >= 0.9f) {
+        a.nyh = a.NB * a.H;
+        a.cols_t = (a.W + a.tw - 1) / a.tw;
+        a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+        return hipGetLastError();
+      }
+    }
+  }
+  if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
+    // linear M tiles are token-aligned when a token's pixels are a whole number of tiles
+    if (conv_group_size() >= 2 && a.row2img && a.NB >= 2 && a.taps == 9 && (a.H * a.W) % t.BM == 0) {
+      a.grp = conv_group_size();
+      a.tok_tiles = (a.H * a.W) / t.BM;
     }
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
@@ -903,6 +1098,21 @@ inline float bf16_to_f32(unsigned short h) {
   memcpy(&f, &u, 4);
   return f;
 }
+// BREG operand: split8-packed weights [64 rows][K = taps*CP] -> fragment-major [kc = chunk*9 + tap][step][hi|lo][lane half][64][4 dwords]
+inline void pack_frag64(const float* split8_pk, int taps, int CP, float* dst) {
+  const int K = taps * CP, cpt = CP / 32;
+  for (int cc = 0; cc < cpt; ++cc)
+    for (int t = 0; t < taps; ++t) {
+      const int kc = cc * taps + t;
+      for (int q = 0; q < 4; ++q)
+        for (int hh = 0; hh < 2; ++hh)
+          for (int n = 0; n < 64; ++n) {
+            const int c = 4 * (q >> 1) + 2 * hh + (q & 1);          // 16 B chunk of the 128 B tap-chunk row
+            memcpy(dst + ((((size_t)kc * 4 + q) * 2 + hh) * 64 + n) * 4, split8_pk + (size_t)n * K + t * CP + cc * 32 + c * 4, 16);
+          }
+    }
+}
+
 inline void pack_split8(const float* src, size_t n_floats, float* dst_as_float) {
   unsigned short* d = reinterpret_cast<unsigned short*>(dst_as_float);
   for (size_t g = 0; g < n_floats / 8; ++g)

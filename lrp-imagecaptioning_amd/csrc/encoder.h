@@ -26,6 +26,7 @@ struct ConvLayer {
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
+  DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
   DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
@@ -205,6 +206,12 @@ struct Encoder {
         pack_split8(pk.data(), pk.size(), sp.data());
         LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (Npb == 64) {
+          std::vector<float> fr((size_t)64 * Kb);
+          pack_frag64(sp.data(), 9, conv_cinp(L.cout), fr.data());
+          LRP_TRY(L.w_bwd_frag.alloc(fr.size() * sizeof(float), total));
+          LRP_HIP_CHECK(hipMemcpy(L.w_bwd_frag.p, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
       }
       pk.assign((size_t)Npb * Kb, 0.f);
       pack_conv_bwd(w, 9, L.cin, L.cout, 0, pk.data());
@@ -391,6 +398,7 @@ struct Encoder {
       ConvArgs ca{};
       ca.in = S; ca.NB = n; ca.H = L.H; ca.W = L.W; ca.Cin = L.cout; ca.CinP = conv_cinp(L.cout); ca.taps = 9;
       ca.wpk = walk != 0 ? L.w_bwd_full.as<float>() : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
+      ca.wpk_frag = (split && walk == 0) ? L.w_bwd_frag.as<float>() : nullptr;
       ca.row2img = row2img_dev;
       ca.gate_binary = walk != 0; ca.relu_out = walk == 3;
       int epi;

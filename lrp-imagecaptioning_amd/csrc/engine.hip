@@ -274,12 +274,18 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
   std::vector<float> pk((size_t)Np * K, 0.f);
   if (bwd) pack_conv_bwd(w_hwio_host, taps, Cin, Cout, 0, pk.data());
   else pack_conv_fwd(w_hwio_host, taps, Cin, Cout, 0, Np, pk.data());
-  DevBuf wdev, bdev, insplit;
+  DevBuf wdev, bdev, insplit, wfrag;
   if (split) {
     if ((inC & 7) || (bwd && (outC & 7))) return fail(LRP_ERR_UNSUPPORTED, "split-bf16 path: channels must be multiples of 8");
     std::vector<float> sp(pk.size());
     pack_split8(pk.data(), pk.size(), sp.data());
     pk.swap(sp);
+    if (bwd && taps == 9 && Np == 64) {                  // weights-in-registers variant of the N <= 64 backward convs
+      std::vector<float> fr((size_t)64 * K);
+      pack_frag64(pk.data(), 9, conv_cinp(inC), fr.data());
+      LRP_TRY(wfrag.alloc(fr.size() * sizeof(float), nullptr));
+      LRP_HIP_CHECK(hipMemcpy(wfrag.p, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     const size_t n8 = (size_t)NB * H * W * inC / 8;
     LRP_TRY(insplit.alloc(n8 * 32, nullptr));
     hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, S(stream), in_dev, insplit.as<float>(), n8);
@@ -290,6 +296,7 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
   LRP_HIP_CHECK(hipMemcpy(wdev.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
   ConvArgs ca{};
   ca.out_plain = 1;
+  ca.wpk_frag = wfrag.as<float>();
   ca.in = in_dev; ca.wpk = wdev.as<float>(); ca.NB = NB; ca.H = H; ca.W = W; ca.Cin = inC; ca.CinP = conv_cinp(inC);
   ca.N = outC; ca.taps = taps; ca.out = out_dev; ca.aux = aux_dev;
   if (!bwd) {

@@ -113,6 +113,9 @@ SPLIT_CASES = [  # NB, H, W, Cin, Cout   (forward: Cin -> Cout; backward: S has 
     (2, 16, 16, 64, 64),      # power-of-two width (the halo pitch equals tw + 2 only for 14 / 30)
     (33, 56, 56, 8, 256),     # 8-wave 256 x 256 tile (>= 400 blocks), tw = 28
     (140, 14, 14, 16, 256),   # 8-wave tile on 14 x 14 images: 18 stack rows per tile, ~1.3 images
+    (3, 28, 28, 64, 64),      # backward: N = 64, two channel chunks -> weights-in-registers kernel (one group)
+    (2, 14, 28, 64, 128),     # backward: N = 64, four chunks = two groups of the resident image
+    (2, 14, 14, 56, 96),      # backward: N = 56 (< 64), three chunks: the last group holds one chunk
 ]
 
 
