@@ -968,13 +968,21 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
       // N <= 64: resident image + weights in registers, no barrier per tap (LRP_CONV_BREG=0 disables)
       static const int breg = [] { const char* e = getenv("LRP_CONV_BREG"); return e ? atoi(e) : 1; }();
       if (a.taps == 9 && mode > 0 && breg && t.BN == 64 && a.n_tiles == 1 && a.wpk_frag) {
-        const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
+        // 256-row tiles (8 waves, one block per CU) halve the weight traffic per pixel — these layers are L2-bound on
+        // re-fetching the weight matrix per tile — but lose more to the single block per CU  [MI355X: block1_conv2 bwd
+        // 4.19 ms vs 3.83 ms with 128-row tiles, 3 blocks per CU].  Experiment knob, off by default.
+        static const int big = [] { const char* e = getenv("LRP_CONV_BREG_BM"); return e ? atoi(e) : 128; }();
+        const int bm = (big == 256 && (long)a.NB * a.H * a.W >= 256L * 2048) ? 256 : 128;
+        const float u = conv_halo_geom(bm, a.H, a.W, a.tw, a.th, a.hrows);
         if (u >= 0.9f || (mode == 2 && u > 0.f)) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
           conv_group_halo(a);
-          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(256), 0, st, a);
+          if (bm == 256)
+            hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(512), 0, st, a);
+          else
+            hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }
       }
