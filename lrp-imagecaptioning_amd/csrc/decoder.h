@@ -101,7 +101,7 @@ struct Decoder {
     LRP_TRY(u.alloc(B * Tm * H * 8, total));
     LRP_TRY(cap_dev.alloc(B * Tm * sizeof(int), total));
     LRP_TRY(rctx.alloc((size_t)NT_max * H * 8, total));
-    if (kind == LRP_DEC_ADAPTIVE && (H & 7) == 0) LRP_TRY(tailA.alloc((size_t)NT_max * L * H * 4, total));
+    if ((H & 7) == 0) LRP_TRY(tailA.alloc((size_t)NT_max * L * H * 4, total));
     LRP_TRY(ravg.alloc((size_t)NT_max * D * 8, total));
     cap_host.assign(B * Tm, eos);
     len_host.assign(B, 0);
@@ -411,6 +411,22 @@ struct Decoder {
     const size_t lds = (size_t)(7 * H + std::max(H, E) + E + 8) * sizeof(double);
     hipLaunchKernelGGL(gtd_explain_kernel, dim3(n), dim3(256), lds, st, a);
     LRP_HIP_CHECK(hipGetLastError());
+    if (tailA.p && (D & 7) == 0) {
+      // tail on the matrix cores, as for the adaptive decoder
+      const bool split = prec == PREC_BF16X3;
+      hipLaunchKernelGGL(gtd_tail_a_kernel, dim3((L * (H / 8) + 255) / 256, n), dim3(256), 0, st, img_dev, t_dev,
+                         if_pre.as<float>(), a.att, a.rho, tailA.as<float>(), Tm, L, H, split ? 1 : 0);
+      LRP_HIP_CHECK(hipGetLastError());
+      ConvArgs cg{};
+      cg.in = tailA.as<float>(); cg.NB = n; cg.H = L; cg.W = 1; cg.Cin = H; cg.CinP = conv_cinp(H); cg.taps = 1;
+      cg.wpk = split ? w_ifT_pks.as<float>() : w_ifT_pk.as<float>(); cg.N = D; cg.aux = feat_dev; cg.row2img = img_dev;
+      cg.out = R_feat_dev; cg.out_plain = 1;
+      LRP_HIP_CHECK(conv_launch(EPI_MUL, cg, st, split ? PREC_BF16X3 : PREC_FP32));
+      hipLaunchKernelGGL(tail_finish_kernel, dim3((L * D + 255) / 256 > 64 ? 64 : (L * D + 255) / 256, n), dim3(256), 0, st,
+                         img_dev, feat_dev, a.avg, a.ravg, R_feat_dev, L, D);
+      LRP_HIP_CHECK(hipGetLastError());
+      return LRP_OK;
+    }
     GtdTailArgs ta{};
     ta.img_idx = img_dev; ta.tpos = t_dev; ta.F = feat_dev; ta.if_pre = if_pre.as<float>(); ta.att = a.att;
     ta.avg = a.avg; ta.WifT = WifT.as<float>(); ta.rho = a.rho; ta.ravg = a.ravg; ta.R_feat = R_feat_dev;

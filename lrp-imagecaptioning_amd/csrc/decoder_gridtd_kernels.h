@@ -295,6 +295,37 @@ struct GtdTailArgs {
   int Tm, L, D, H;
 };
 
+// A operand of the same tail on the matrix cores (see tail_a_kernel in decoder_kernels.h): the per-step fold with its
+// float32 rounding after every += (E:1189, E:1293) and the division by stab(pre) happen here, the (L x H).(H x D)
+// product runs on conv_igemm with the F-multiply as its gate, tail_finish_kernel adds the mean-pool share.
+//   A[n][l][j] = float32( r_V[l][j] / stab(if_pre[l][j]) ),  r_V folded over i = t-1 .. 0 as in gtd_tail_kernel
+__global__ __launch_bounds__(256) void gtd_tail_a_kernel(const int* __restrict__ img_idx, const int* __restrict__ tpos,
+                                                         const float* __restrict__ if_pre, const double* __restrict__ att,
+                                                         const double* __restrict__ rho, float* __restrict__ A, int Tm,
+                                                         int L, int H, int split) {
+  const int n = blockIdx.y, b = img_idx[n], t = tpos[n], S = Tm + 1, H8 = H >> 3;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < L * H8; idx += gridDim.x * 256) {
+    const int l = idx / H8, j0 = (idx - l * H8) << 3;
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float pre = if_pre[((size_t)b * L + l) * H + j0 + q];
+      const double vf = (double)fmaxf(pre, 0.f);
+      float rV = 0.f;
+      for (int i = t - 1; i >= 0; --i)
+        rV = (float)((double)rV + vf * att[((size_t)b * S + i + 1) * L + l] * rho[((size_t)n * Tm + i) * H + j0 + q]);
+      v[q] = (float)((double)rV / stab((double)pre));
+    }
+    float* dst = A + ((size_t)n * L + l) * H + j0;
+    if (split) {
+      split8_store(v, dst);
+    } else {
+      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(v);
+      *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(v + 4);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gtd_tail_kernel(GtdTailArgs a) {
   __shared__ double As[16][65];
   __shared__ double Bs[16][65];
