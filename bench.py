@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=10, help="predicted words per caption")
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-tokens", type=int, default=3)
+    ap.add_argument("--cpu-sample-tokens", type=int, default=10, help="tokens of one caption the CPU port explains (~1 s each)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
