@@ -92,11 +92,6 @@ struct ConvArgs {
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
   int tw, th, hrows, cols_t, nyh;
-  // Token-grouped tile order (reverse walk, tokens of an image are consecutive image slots and share its gates):
-  // M tiles are token-aligned, tok_tiles per token, and run in the order (group of `grp` tokens, spatial tile,
-  // token in group), so the gate tile a spatial position needs is fetched from HBM once per group and re-used out
-  // of the XCD's L2 by the other tokens' tiles that run next to it, instead of once per token.  grp = 0: plain order.
-  int grp, tok_tiles;
 };
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -148,16 +143,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  int mt = logical / a.n_tiles;
-  const int nt = logical - mt * a.n_tiles;
-  int tok = 0, ltile = 0;                              // token (image slot) and its local tile, when token-aligned
-  if (a.grp > 0) {
-    const int per = a.grp * a.tok_tiles, gi = mt / per, rem = mt - gi * per;
-    const int left = a.NB - gi * a.grp, ge = left < a.grp ? left : a.grp;      // tokens in this (possibly last) group
-    ltile = rem / ge;
-    tok = gi * a.grp + (rem - ltile * ge);
-    mt = tok * a.tok_tiles + ltile;
-  }
+  const int mt = logical / a.n_tiles, nt = logical - mt * a.n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
   int pn = 0, py0 = 0, px0 = 0;                        // EPI_IMG_STENCIL: image slot and first OUTPUT pixel of the patch
   if constexpr (EPI == EPI_IMG_STENCIL) {
@@ -168,20 +154,11 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     px0 = (r - ty * a.tiles_x) * IMG_TILE;
   }
   int Y0 = 0, x0 = 0, img0 = 0;                          // HALO: first stack row / column of the tile, its image
-  int Yend = a.nyh;                                    // HALO: first stack row this tile must not touch
   if constexpr (HALO) {
-    if (a.grp > 0) {                                   // token-aligned tiles: (rows of tiles) x cols_t per token
-      const int tyt = ltile / a.cols_t;
-      Y0 = tok * a.H + tyt * a.th;
-      x0 = (ltile - tyt * a.cols_t) * a.tw;
-      img0 = tok;
-      Yend = (tok + 1) * a.H;
-    } else {
-      const int tyt = mt / a.cols_t;
-      Y0 = tyt * a.th;
-      x0 = (mt - tyt * a.cols_t) * a.tw;
-      img0 = Y0 / a.H;
-    }
+    const int tyt = mt / a.cols_t;
+    Y0 = tyt * a.th;
+    x0 = (mt - tyt * a.cols_t) * a.tw;
+    img0 = Y0 / a.H;
   }
   // exact small-integer division (operands < 2^22): float estimate + one fix-up step
   auto divmod = [](int x, int d, float inv, int& q, int& r) {
@@ -382,7 +359,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
       divmod(r, a.tw, inv_tw, ty, tx);
       const int Y = Y0 + ty;
       divmod(Y, a.H, inv_H, n_, h_);
-      const bool ok = r < a.th * a.tw && Y < Yend && x0 + tx < a.W;
+      const bool ok = r < a.th * a.tw && Y < a.nyh && x0 + tx < a.W;
       const int hy = ok ? ty + 1 + n_ - img0 : 1, hx = ok ? tx + 1 : 1;
       fbase[i] = hy * HALO_PITCH + hx;
       fu[i] = hy * a.tw + hx - 1;
@@ -682,7 +659,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         divmod(lr, a.tw, inv_tw, ty, tx);
         const int Y = Y0 + ty;
         w = x0 + tx;
-        if (lr >= a.th * a.tw || Y >= Yend || w >= a.W) return false;
+        if (lr >= a.th * a.tw || Y >= a.nyh || w >= a.W) return false;
         divmod(Y, a.H, inv_H, n, h);
         row = Y * a.W + w;
         return true;
@@ -912,23 +889,6 @@ inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// token-grouped tile order (ConvArgs::grp): env LRP_CONV_GROUP = group size, 0 = off
-inline int conv_group_size() {
-  // [MI355X] measured neutral (block1_conv2 3.84 -> 3.75 ms, block2_conv2 3.07 -> 3.21 ms): the gate re-reads of
-  // consecutive tokens already hit the 256 MB MALL.  Kept as an experiment knob, off by default.
-  static const int g = [] { const char* e = getenv("LRP_CONV_GROUP"); return e ? atoi(e) : 0; }();
-  return g;
-}
-// halo tiles aligned per token: worth it when the ragged last tile row wastes <= 5 % of the MFMA rows
-inline bool conv_group_halo(ConvArgs& a) {
-  const int rows_t = (a.H + a.th - 1) / a.th;
-  if (conv_group_size() < 2 || !a.row2img || a.NB < 2 || rows_t * a.th * 20 > a.H * 21) return false;
-  a.grp = conv_group_size();
-  a.tok_tiles = rows_t * a.cols_t;
-  a.m_tiles = a.NB * a.tok_tiles;
-  return true;
-}
-
 template <int EPI, int PREC>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
@@ -968,21 +928,14 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
       // N <= 64: resident image + weights in registers, no barrier per tap (LRP_CONV_BREG=0 disables)
       static const int breg = [] { const char* e = getenv("LRP_CONV_BREG"); return e ? atoi(e) : 1; }();
       if (a.taps == 9 && mode > 0 && breg && t.BN == 64 && a.n_tiles == 1 && a.wpk_frag) {
-        // 256-row tiles (8 waves, one block per CU) halve the weight traffic per pixel — these layers are L2-bound on
-        // re-fetching the weight matrix per tile — but lose more to the single block per CU  [MI355X: block1_conv2 bwd
-        // 4.19 ms vs 3.83 ms with 128-row tiles, 3 blocks per CU].  Experiment knob, off by default.
-        static const int big = [] { const char* e = getenv("LRP_CONV_BREG_BM"); return e ? atoi(e) : 128; }();
-        const int bm = (big == 256 && (long)a.NB * a.H * a.W >= 256L * 2048) ? 256 : 128;
-        const float u = conv_halo_geom(bm, a.H, a.W, a.tw, a.th, a.hrows);
+        // (256-row tiles, 8 waves, one block per CU, halve the weight traffic per pixel but lose more to the single
+        // block per CU  [MI355X: block1_conv2 bwd 4.19 ms vs 3.83 ms with these 128-row tiles, 3 blocks per CU])
+        const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
         if (u >= 0.9f || (mode == 2 && u > 0.f)) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-          conv_group_halo(a);
-          if (bm == 256)
-            hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(512), 0, st, a);
-          else
-            hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(256), 0, st, a);
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }
       }
@@ -993,7 +946,6 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
         a.nyh = a.NB * a.H;
         a.cols_t = (a.W + a.tw - 1) / a.tw;
         a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-        if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) conv_group_halo(a);
         const dim3 hgrid(a.m_tiles * a.n_tiles);
         if (wide == 256)
           hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true>), hgrid, dim3(512), 0, st, a);
@@ -1003,27 +955,6 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true>), hgrid, dim3(256), 0, st, a);
         return hipGetLastError();
       }
-    }
-  }
-  if constexpr (PREC == PREC_FP32 && EPI == EPI_BIAS_RELU) {
-    // exact-fp32 forward chain: same resident-image variant on the 128 x 128 tile (experiment knob LRP_CONV_HALO_FP32)
-    static const int on = [] { const char* e = getenv("LRP_CONV_HALO_FP32"); return e ? atoi(e) : 0; }();
-    if (on && a.taps == 9 && t.BN == 128) {
-      const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
-      if (u >= 0.9f) {
-        a.nyh = a.NB * a.H;
-        a.cols_t = (a.W + a.tw - 1) / a.tw;
-        a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
-        return hipGetLastError();
-      }
-    }
-  }
-  if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
-    // linear M tiles are token-aligned when a token's pixels are a whole number of tiles
-    if (conv_group_size() >= 2 && a.row2img && a.NB >= 2 && a.taps == 9 && (a.H * a.W) % t.BM == 0) {
-      a.grp = conv_group_size();
-      a.tok_tiles = (a.H * a.W) / t.BM;
     }
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
