@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=10, help="tokens of one caption the CPU port explains (~1 s each)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16x3_fast"],
                     help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                         "the N>1 control path with several ranks on one GPU)")
@@ -154,10 +154,11 @@ def main():
     eng.profile_enable(False)
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
-    traffic, traffic_src = pmc_traffic_per_launch(args.precision)
+    split = args.precision != "fp32"
+    traffic, traffic_src = pmc_traffic_per_launch("bf16x3" if split else "fp32")
     if rank == 0:
         heatmaps = world * B * T * args.steps
-        if args.precision == "bf16x3":
+        if split:
             peak, dtype = PEAK_BF16_MFMA_TFLOPS, "bf16x3"
             kname = ("conv_igemm_kernel<..., PREC_BF16X3> (conv-LRP alpha1beta0 backward, 13 launches/step; every fp32 "
                      "product = 3 bf16 MFMAs hi*hi+hi*lo+lo*hi, fp32 accumulate; forward/decoder stay fp32/fp64)")
@@ -169,7 +170,7 @@ def main():
                 "traffic_unit": "HBM+MALL bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                 "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
                 "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2)}
-        if args.precision == "bf16x3":
+        if split:
             roof["mfma_flop_per_algorithmic_flop"] = 3
             roof["issued_mfma_frac"] = round(3 * achieved / peak, 4)
             roof["vs_fp32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 3)

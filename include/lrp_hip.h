@@ -185,8 +185,12 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
  *                 Default.  Measured parity of the heat-maps vs the float64 reference graph: 5.9e-6 relative L1
  *                 (fp32 mode: 3.9e-6; bar 1e-4).  Conv widths % 8 != 0 silently use the fp32 path.
- * The per-image forward (lrp_encode_images) and the decoder are not affected. */
-enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1 };
+ *                 The per-image forward keeps its activation convs in exact fp32 (only the denominators Z+ are
+ *                 split): an error in a_l upstream of a max-pool flips arg-maxes, and a_top are the decoder's features.
+ * LRP_PREC_BF16X3_FAST  the same with EVERY activation conv but the image layer's split as well: 14 % faster,
+ *                 parity 5e-6 ... 4e-5 (dominated by the few arg-max flips), still inside the 1e-4 bar.  Opt-in.
+ * The decoder is fp32 / fp64 in every mode. */
+enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2 };
 int lrp_set_precision(lrp_handle* h, int32_t mode);
 
 /* Dominant-kernel timing for bench.py's roofline block: when enabled, HIP

@@ -920,7 +920,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
 
-  if constexpr (PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS)) {
+  if constexpr (PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU)) {
     const int mode = conv_halo_mode();
     // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
     // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
@@ -987,6 +987,7 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
       case EPI_STORE: return conv_launch_epi<EPI_STORE, PREC_BF16X3>(a, st);
       case EPI_IMG_STENCIL: return conv_launch_img<PREC_BF16X3>(a, st);
       case EPI_BIAS: return conv_launch_epi<EPI_BIAS, PREC_BF16X3>(a, st);     // forward Z+ conv (fp32 out)
+      case EPI_BIAS_RELU: return conv_launch_epi<EPI_BIAS_RELU, PREC_BF16X3>(a, st);   // forward a conv of the late layers
     }
     return hipErrorInvalidValue;
   }

@@ -23,6 +23,7 @@ struct ConvLayer {
   DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)          [fp32 mode, and the image layer]
   DevBuf w_fwd_a;  // forward weights w, fp32                            [mixed mode: exact activation conv]
   DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
+  DevBuf w_fwd_as; // forward weights w, split8                          [late layers: bf16x3 activation conv]
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
@@ -69,6 +70,17 @@ struct Encoder {
   static bool img_fused() {                            // LRP_IMG_FUSED=0: separate T GEMM + img_stencil_kernel
     const char* e = getenv("LRP_IMG_FUSED");
     return !e || atoi(e) != 0;
+  }
+  // First layer whose ACTIVATION conv runs split-bf16 too.  A ~1e-5 relative error in a_l is harmless by itself, but
+  // upstream of a 2x2 max-pool it flips the arg-max of near-tied windows (~1e-5 of them), and a flipped window moves
+  // its whole relevance to a neighbour pixel: measured on VGG16, relative L1 of the heat-maps 5e-6 ... 3.6e-5 instead
+  // of 5.6e-6.  Default: none (splitting only the layers behind the last pool is flip-free but makes the features the
+  // decoder consumes 10x less exact, 7.4e-7 -> 7.8e-6, for 0.5 ms); lrp_set_precision(LRP_PREC_BF16X3_FAST): every layer
+  // but the image layer (-5 ms, heat-map parity <= 4e-5).
+  bool fwd_fast = false;
+  int fwd_split_from() const {
+    if (const char* e = getenv("LRP_FWD_SPLIT_FROM")) return atoi(e);
+    return fwd_fast ? 1 : 1000;
   }
   static bool overlap_enabled() {
     const char* e = getenv("LRP_ENCODE_OVERLAP");
@@ -195,6 +207,9 @@ struct Encoder {
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_a.p, pa.data(), pa.size() * sizeof(float), hipMemcpyHostToDevice));
         LRP_TRY(L.w_fwd_zs.alloc(pzs.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_zs.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
+        pack_split8(pa.data(), pa.size(), pzs.data());
+        LRP_TRY(L.w_fwd_as.alloc(pzs.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_fwd_as.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
       }
       const int Npb = conv_npad(L.cin), Kb = 9 * conv_cinp(L.cout);
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -270,7 +285,16 @@ struct Encoder {
         ca.bias = L.bias.as<float>(); ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout;
         float* a_out = top ? feat.as<float>() : L.G.as<float>();
         ca.out = a_out;
-        LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, ca, st));
+        if ((int)li >= fwd_split_from()) {
+          // late layers: activation conv in split-bf16 as well (its error passes through few further layers)
+          const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
+          hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8);
+          LRP_HIP_CHECK(hipGetLastError());
+          ca.in = bufXs.as<float>(); ca.wpk = L.w_fwd_as.as<float>();
+          LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, ca, st, PREC_BF16X3));
+        } else {
+          LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, ca, st));
+        }
         if (top) break;
         if (L.pool_after) {
           const size_t n = (size_t)B * L.act_elems();

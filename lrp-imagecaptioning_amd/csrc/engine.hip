@@ -233,10 +233,13 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
 
 int lrp_set_precision(lrp_handle* h, int32_t mode) {
   if (!h) return fail(LRP_ERR_INVALID, "null handle");
-  if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3) return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);
-  h->enc.prec = mode;
-  h->rn.prec = mode;
-  h->dec.prec = mode;
+  if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3 && mode != LRP_PREC_BF16X3_FAST)
+    return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);
+  const int km = mode == LRP_PREC_FP32 ? PREC_FP32 : PREC_BF16X3;
+  h->enc.prec = km;
+  h->enc.fwd_fast = mode == LRP_PREC_BF16X3_FAST;
+  h->rn.prec = km;
+  h->dec.prec = km;
   return LRP_OK;
 }
 

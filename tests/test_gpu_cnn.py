@@ -52,10 +52,11 @@ def test_small_nets_match_oracle(name, cfg, hw, B, prec):
     assert max(errs) < TOL, errs
 
 
-@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16x3_fast"])
 def test_vgg16_full_size_matches_oracle(prec):
-    """BASELINE geometry: 224x224, VGG16 to block5_conv3, 2 images x 2 relevance maps, both arithmetic
-    modes of the reverse walk (exact fp32 MFMA / split-bf16 x3)."""
+    """BASELINE geometry: 224x224, VGG16 to block5_conv3, 2 images x 2 relevance maps, in every arithmetic mode:
+    exact fp32 MFMA / split-bf16 reverse walk (default) / split-bf16 forward activations too (opt-in; its heat-map
+    error is dominated by the handful of max-pool arg-max flips a 1e-5 activation error causes)."""
     rs = np.random.RandomState(0)
     w = vgg_weights(rs)
     layers = C.vgg_layers(w, VGG16_CFG)
@@ -73,7 +74,7 @@ def test_vgg16_full_size_matches_oracle(prec):
     ref = C.analyze(layers, X[idx], R)
     errs = [rel_l1(out[i], ref[i]) for i in range(4)]
     report("cnn_vgg16_" + prec, feat_rel_l1=e_feat, max_rel_l1=max(errs))
-    assert e_feat < 1e-5
+    assert e_feat < (1e-5 if prec != "bf16x3_fast" else 5e-5)
     assert max(errs) < TOL, errs
     # linearity in R (size-independent property): analyze(a*R1 + R2) = a*analyze(R1) + analyze(R2)
     out2 = eng.cnn_explain([0, 0], np.stack([2.5 * R[0] + R[3], R[3]])).cpu().numpy()
