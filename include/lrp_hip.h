@@ -185,10 +185,11 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
  *                 Default.  Measured parity of the heat-maps vs the float64 reference graph: 5.9e-6 relative L1
  *                 (fp32 mode: 3.9e-6; bar 1e-4).  Conv widths % 8 != 0 silently use the fp32 path.
- *                 The per-image forward keeps its activation convs in exact fp32 (only the denominators Z+ are
- *                 split): an error in a_l upstream of a max-pool flips arg-maxes, and a_top are the decoder's features.
- * LRP_PREC_BF16X3_FAST  the same with EVERY activation conv but the image layer's split as well: 14 % faster,
- *                 parity 5e-6 ... 4e-5 (dominated by the few arg-max flips), still inside the 1e-4 bar.  Opt-in.
+ *                 The per-image forward keeps fp32-grade activations (three-way split operands, six bf16 MFMAs per
+ *                 product, measured 7e-7 on the features like the fp32 MFMA); only the denominators Z+ are two-way
+ *                 split: an error in a_l upstream of a max-pool flips arg-maxes, and a_top are the decoder's features.
+ * LRP_PREC_BF16X3_FAST  two-way split activation convs as well: 10 % faster, but the arg-max flips put the heat-map
+ *                 parity at 2e-5 ... 9e-5 (five seeds) — inside the 1e-4 bar without margin.  Opt-in, not recommended.
  * The decoder is fp32 / fp64 in every mode. */
 enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2 };
 int lrp_set_precision(lrp_handle* h, int32_t mode);

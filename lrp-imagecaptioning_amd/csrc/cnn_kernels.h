@@ -120,6 +120,28 @@ __global__ __launch_bounds__(256) void split_copy_kernel(const float* __restrict
   }
 }
 
+// fp32 NHWC -> the two operand tensors of the three-way split forward product: x1 = [h8 | m8], x2 = [h8 | l8]
+__global__ __launch_bounds__(256) void split3_copy_kernel(const float* __restrict__ x, float* __restrict__ x1,
+                                                          float* __restrict__ x2, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    bf16x8 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      h[q] = (__bf16)v[q];
+      const float r1 = v[q] - (float)h[q];
+      m[q] = (__bf16)r1;
+      l[q] = (__bf16)(r1 - (float)m[q]);
+    }
+    u32x4* d1 = reinterpret_cast<u32x4*>(x1 + i * 8);
+    u32x4* d2 = reinterpret_cast<u32x4*>(x2 + i * 8);
+    d1[0] = __builtin_bit_cast(u32x4, h); d1[1] = __builtin_bit_cast(u32x4, m);
+    d2[0] = __builtin_bit_cast(u32x4, h); d2[1] = __builtin_bit_cast(u32x4, l);
+  }
+}
+
 // Head of the reverse walk (KG:898-900): S_top = R_feat / safe(Z_top[img])
 __global__ __launch_bounds__(256) void top_divide_kernel(const f32x4* __restrict__ R, const f32x4* __restrict__ Ztop,
                                                          const int* __restrict__ row2img, f32x4* __restrict__ S,

@@ -85,6 +85,7 @@ struct ConvArgs {
   // EPI_IMG_STENCIL: tiles per image row / column, ximg = the images (x of the image layer), mode 0 LRP | 1 sum | 2 x*sum
   int tiles_x, tiles_y, img_mode;
   const float* ximg;
+  const float* addend; // BIAS / BIAS_RELU epilogues: out = [relu](acc + bias + addend)  (bias may be null)
   // gradient baselines on the MUL epilogues: the cached LRP gate is used as a MASK (gate != 0 <=> the unit's ReLU was
   // active and it won its pool window), and guided backprop also clamps the propagated value at 0
   int gate_binary, relu_out;
@@ -121,7 +122,13 @@ constexpr int conv_halo_rows(int BM) { return BM == 256 ? 352 : 192; }   // x 12
 // (tap, chunk) are 4 coalesced 16 B loads per lane from a fragment-major copy of the packed weights (wpk_frag,
 // L1/L2 resident: 8 KB per tap), prefetched one tap ahead in registers.  The main loop then has NO barrier per tap —
 // only one per channel group — which is what the 12-MFMA-per-tap waves of the N = 64 tiles could not amortise.
-template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false, bool BREG = false>
+// TERMS (bf16x3 operand format only): which of the four partial products of (ah + al)(bh + bl) are issued —
+// bit 0: al*bh, bit 1: ah*bl, bit 2: ah*bh, bit 3: al*bl.  7 = the split-bf16 product of the reverse walk.  The
+// exact forward uses two passes over THREE-way split operands x = h + m + l (24 mantissa bits):
+//   pass A  (h|m) x (h|m), TERMS 15: hh + hm + mh + mm      pass B  (h|l) x (h|l), TERMS 3: hl + lh
+// = every partial product down to 2^-16 of the leading one, i.e. an fp32-grade product in 6 bf16 MFMAs of 32 cycles
+// per 16 k (192) instead of 8 fp32 MFMAs of 64 (512).
+template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false, bool BREG = false, int TERMS = 7>
 __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
@@ -309,7 +316,9 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   // chunks (256 k) the running block is folded into `tot` and restarted: chains of 256 + K/256.
   // (bf16x3: one MFMA already folds 16 k internally and the chain is K/16 long — no second level.)
   constexpr int FLUSH = 8;
-  constexpr bool BLOCKED = PREC == PREC_FP32;
+  // (the four-term pass of the exact forward product rounds its accumulator 4 x K/16 times: blocked as well — measured
+  //  feature error of VGG16 2.3e-6 without)
+  constexpr bool BLOCKED = PREC == PREC_FP32 || TERMS == 15;
   f32x16 acc[TM][TN], tot[BLOCKED ? TM : 1][BLOCKED ? TN : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -435,9 +444,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         for (int j = 0; j < TN; ++j) {
           const bf16x8 ah = __builtin_bit_cast(bf16x8, f.a[2 * i]), al = __builtin_bit_cast(bf16x8, f.a[2 * i + 1]);
           const bf16x8 bh = __builtin_bit_cast(bf16x8, f.b[2 * j]), bl = __builtin_bit_cast(bf16x8, f.b[2 * j + 1]);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);    // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+          if constexpr ((TERMS & 8) != 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bl, acc[i][j], 0, 0, 0);
+          if constexpr ((TERMS & 1) != 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);    // small terms first
+          if constexpr ((TERMS & 2) != 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+          if constexpr ((TERMS & 4) != 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -693,13 +703,15 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
       __syncthreads();
       if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
         if (col < a.N) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col) : zero4;
 #pragma unroll 4
           for (int ps = 0; ps < RH / RPP; ++ps) {
             const int ll = rin + ps * RPP;
             int row, n_, h_, w_;
             if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
+            if (a.addend) v += *reinterpret_cast<const f32x4*>(a.addend + (size_t)row * a.N + col);   // second pass of a product
             if constexpr (EPI == EPI_BIAS_RELU) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
@@ -889,7 +901,7 @@ inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int EPI, int PREC>
+template <int EPI, int PREC, int TERMS = 7>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
   if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & need)) return hipErrorInvalidValue;
@@ -905,7 +917,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     if (blocks < thr) t = {128, 64};
   }
   int wide = 0;
-  if (PREC == PREC_BF16X3 && a.N >= 128 && (a.N % 128) == 0) {
+  if (PREC == PREC_BF16X3 && TERMS == 7 && a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
     wide = (a.N % 256) == 0 ? 256 : 128;
     if (wide == 128) wide = 0;                           // measured: 256 x 128 loses to two 128 x 128 blocks per CU
     if (conv_tile_override() == 128 && (a.N % 128) == 0) wide = 128;
@@ -948,11 +960,11 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
         a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
         const dim3 hgrid(a.m_tiles * a.n_tiles);
         if (wide == 256)
-          hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true>), hgrid, dim3(512), 0, st, a);
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true, false, TERMS>), hgrid, dim3(512), 0, st, a);
         else if (t.BN == 128)
-          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true>), hgrid, dim3(256), 0, st, a);
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true, false, TERMS>), hgrid, dim3(256), 0, st, a);
         else
-          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true>), hgrid, dim3(256), 0, st, a);
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, false, TERMS>), hgrid, dim3(256), 0, st, a);
         return hipGetLastError();
       }
     }
@@ -960,26 +972,31 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   const dim3 grid(a.m_tiles * a.n_tiles);
   if constexpr (PREC == PREC_BF16X3) {
     if (wide == 256) {
-      hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC>), grid, dim3(512), 0, st, a);
+      hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, false, false, TERMS>), grid, dim3(512), 0, st, a);
       return hipGetLastError();
     }
     if (wide == 128) {
-      hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, EPI, PREC>), grid, dim3(512), 0, st, a);
+      hipLaunchKernelGGL((conv_igemm_kernel<4, 2, 2, 2, EPI, PREC, false, false, TERMS>), grid, dim3(512), 0, st, a);
       return hipGetLastError();
     }
   }
   const dim3 block(256);
   if (t.BN == 128)
-    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, false, false, TERMS>), grid, block, 0, st, a);
   else if (t.BN == 64)
-    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, false, false, TERMS>), grid, block, 0, st, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, EPI, PREC>), grid, block, 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<4, 1, 1, 1, EPI, PREC, false, false, TERMS>), grid, block, 0, st, a);
   return hipGetLastError();
 }
 
 // prec = PREC_BF16X3 exists for the reverse-walk epilogues (MUL, MUL_UP2, STORE) and the forward Z+ conv (BIAS)
-inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int prec = PREC_FP32) {
+inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int prec = PREC_FP32, int terms = 7) {
+  if (prec == PREC_BF16X3 && terms != 7) {             // the two passes of the three-way split forward product
+    if (epi == EPI_BIAS && terms == 15) return conv_launch_epi<EPI_BIAS, PREC_BF16X3, 15>(a, st);
+    if (epi == EPI_BIAS_RELU && terms == 3) return conv_launch_epi<EPI_BIAS_RELU, PREC_BF16X3, 3>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (prec == PREC_BF16X3) {
     switch (epi) {
       case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_BF16X3>(a, st);
@@ -1050,6 +1067,22 @@ inline void pack_frag64(const float* split8_pk, int taps, int CP, float* dst) {
             const int c = 4 * (q >> 1) + 2 * hh + (q & 1);          // 16 B chunk of the 128 B tap-chunk row
             memcpy(dst + ((((size_t)kc * 4 + q) * 2 + hh) * 64 + n) * 4, split8_pk + (size_t)n * K + t * CP + cc * 32 + c * 4, 16);
           }
+    }
+}
+
+// three-way split x = h + m + l; out1 = [h8 | m8] (== pack_split8), out2 = [h8 | l8]
+inline void pack_split8_3way(const float* src, size_t n_floats, float* out1, float* out2) {
+  unsigned short* d1 = reinterpret_cast<unsigned short*>(out1);
+  unsigned short* d2 = reinterpret_cast<unsigned short*>(out2);
+  for (size_t g = 0; g < n_floats / 8; ++g)
+    for (int q = 0; q < 8; ++q) {
+      const float x = src[g * 8 + q];
+      const unsigned short h = f32_to_bf16_rne(x);
+      const float r1 = x - bf16_to_f32(h);
+      const unsigned short m = f32_to_bf16_rne(r1);
+      const unsigned short l = f32_to_bf16_rne(r1 - bf16_to_f32(m));
+      d1[g * 16 + q] = h; d1[g * 16 + 8 + q] = m;
+      d2[g * 16 + q] = h; d2[g * 16 + 8 + q] = l;
     }
 }
 

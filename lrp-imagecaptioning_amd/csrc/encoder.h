@@ -23,7 +23,8 @@ struct ConvLayer {
   DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)          [fp32 mode, and the image layer]
   DevBuf w_fwd_a;  // forward weights w, fp32                            [mixed mode: exact activation conv]
   DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
-  DevBuf w_fwd_as; // forward weights w, split8                          [late layers: bf16x3 activation conv]
+  DevBuf w_fwd_as; // forward weights w, split8 = [h | m] of the three-way split   [activation conv, passes A / fast mode]
+  DevBuf w_fwd_al; // forward weights w, [h | l] of the three-way split            [activation conv, pass B]
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
@@ -47,6 +48,7 @@ struct Encoder {
   DevBuf a1;               // im2col of the image layer [max_images*H*W][64]
   DevBuf bufX, bufA, bufZ; // forward ping-pong (per call, all images)
   DevBuf bufXs;            // split8 copy of the current conv input (mixed-precision forward)
+  DevBuf bufXl;            // its [h | l] companion (three-way split forward product)
   DevBuf feat;             // [max_images][top_h*top_w][top_c]  top activations (== CNN features)
   DevBuf ztop;             // [max_images][top...] Z+ of the top layer
   DevBuf s0, s1;           // reverse-walk ping-pong [max_tokens][biggest layer]
@@ -81,6 +83,10 @@ struct Encoder {
   int fwd_split_from() const {
     if (const char* e = getenv("LRP_FWD_SPLIT_FROM")) return atoi(e);
     return fwd_fast ? 1 : 1000;
+  }
+  static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
+    const char* e = getenv("LRP_FWD_X6");
+    return !e || atoi(e) != 0;
   }
   static bool overlap_enabled() {
     const char* e = getenv("LRP_ENCODE_OVERLAP");
@@ -120,6 +126,7 @@ struct Encoder {
     LRP_TRY(bufA.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(bufZ.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(bufXs.alloc(B * max_act * sizeof(float), total));
+    LRP_TRY(bufXl.alloc(B * max_act * sizeof(float), total));
     LRP_TRY(feat.alloc(B * T.act_elems() * sizeof(float), total));
     LRP_TRY(ztop.alloc(B * T.act_elems() * sizeof(float), total));
     LRP_TRY(s0.alloc(NT * max_tok_act * sizeof(float), total));
@@ -207,9 +214,12 @@ struct Encoder {
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_a.p, pa.data(), pa.size() * sizeof(float), hipMemcpyHostToDevice));
         LRP_TRY(L.w_fwd_zs.alloc(pzs.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_zs.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
-        pack_split8(pa.data(), pa.size(), pzs.data());
+        std::vector<float> pal(pa.size());
+        pack_split8_3way(pa.data(), pa.size(), pzs.data(), pal.data());
         LRP_TRY(L.w_fwd_as.alloc(pzs.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_as.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
+        LRP_TRY(L.w_fwd_al.alloc(pal.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_fwd_al.p, pal.data(), pal.size() * sizeof(float), hipMemcpyHostToDevice));
       }
       const int Npb = conv_npad(L.cin), Kb = 9 * conv_cinp(L.cout);
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -285,7 +295,19 @@ struct Encoder {
         ca.bias = L.bias.as<float>(); ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout;
         float* a_out = top ? feat.as<float>() : L.G.as<float>();
         ca.out = a_out;
-        if ((int)li >= fwd_split_from()) {
+        if (fwd_x6() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
+          // fp32-grade product on the bf16 matrix cores: three-way split operands, two passes (see conv_igemm.h TERMS)
+          const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
+          hipLaunchKernelGGL(split3_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(),
+                             bufXl.as<float>(), n8);
+          LRP_HIP_CHECK(hipGetLastError());
+          ConvArgs c1 = ca;
+          c1.in = bufXs.as<float>(); c1.wpk = L.w_fwd_as.as<float>(); c1.out = bufZ.as<float>();       // pre-activation, big terms
+          LRP_HIP_CHECK(conv_launch(EPI_BIAS, c1, st, PREC_BF16X3, 15));
+          ConvArgs c2 = ca;
+          c2.in = bufXl.as<float>(); c2.wpk = L.w_fwd_al.as<float>(); c2.bias = nullptr; c2.addend = bufZ.as<float>();
+          LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, c2, st, PREC_BF16X3, 3));
+        } else if ((int)li >= fwd_split_from()) {
           // late layers: activation conv in split-bf16 as well (its error passes through few further layers)
           const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
           hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8);
