@@ -183,8 +183,8 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  * LRP_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
  * LRP_PREC_BF16X3 split-bf16: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
  *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
- *                 Default.  Measured parity of the heat-maps vs the float64 reference graph: 5.9e-6 relative L1
- *                 (fp32 mode: 3.9e-6; bar 1e-4).  Conv widths % 8 != 0 silently use the fp32 path.
+ *                 Default.  Measured parity of the heat-maps vs the float64 reference graph: 2e-6 ... 7e-6 relative L1
+ *                 over five seeds (fp32 mode: 1e-7 ... 8e-6; bar 1e-4; single arg-max flips reach 3e-5 in any mode).  Conv widths % 8 != 0 silently use the fp32 path.
  *                 The per-image forward keeps fp32-grade activations (three-way split operands, six bf16 MFMAs per
  *                 product, measured 7e-7 on the features like the fp32 MFMA); only the denominators Z+ are two-way
  *                 split: an error in a_l upstream of a max-pool flips arg-maxes, and a_top are the decoder's features.
