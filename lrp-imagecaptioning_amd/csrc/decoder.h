@@ -80,10 +80,10 @@ struct Decoder {
       LRP_TRY(st("caption_preds", B * Tm * V, 8));
       LRP_TRY(xh1d.alloc(B * (2 * H + 2 * E) * 8, total));
       LRP_TRY(xh2d.alloc(B * 3 * H * 8, total));
-      LRP_TRY(zg1d.alloc(B * 5 * H * 8, total));
-      LRP_TRY(zg2d.alloc(B * 4 * H * 8, total));
-      LRP_TRY(hprojd.alloc(B * H * 8, total));
-      LRP_TRY(sprojd.alloc(B * H * 8, total));
+      LRP_TRY(zg1d.alloc(B * 5 * H * 8 * KS_GATE, total));
+      LRP_TRY(zg2d.alloc(B * 4 * H * 8 * KS_GATE, total));
+      LRP_TRY(hprojd.alloc(B * H * 8 * KS_PROJ, total));
+      LRP_TRY(sprojd.alloc(B * H * 8 * KS_PROJ, total));
       LRP_TRY(h2u.alloc(B * Tm * H * 8, total));
       LRP_TRY(rho.alloc((size_t)NT_max * Tm * H * 8, total));
     }
@@ -363,25 +363,26 @@ struct Decoder {
       hipLaunchKernelGGL(gtd_prep_x1_kernel, dim3(B), dim3(256), 0, st, emb.as<float>(), glob_pre.as<float>(), h1, h2,
                          cap_dev.as<int>(), xh1d.as<double>(), S_<double>("x1t"), i, Tm, E, H, V, sos);
       LRP_HIP_CHECK(hipGetLastError());
+      const size_t zs1 = (size_t)B_max * 5 * H, zs2 = (size_t)B_max * 4 * H, ps = (size_t)B_max * H;   // split-K slabs
       LRP_HIP_CHECK((skinny<double, double, double>(xh1d.as<double>(), K1 + H, Wcat.as<float>(), 5 * H, bcat.as<float>(),
-                                                    zg1d.as<double>(), 5 * H, B, K1 + H, 5 * H, 0, st)));
-      hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg1d.as<double>(), 5 * H, h1, S_<double>("c1t"),
+                                                    zg1d.as<double>(), 5 * H, B, K1 + H, 5 * H, 0, st, KS_GATE, zs1)));
+      hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg1d.as<double>(), 5 * H, KS_GATE, zs1, h1, S_<double>("c1t"),
                          S_<double>("g1t"), S_<double>("i1t_act"), S_<double>("f1t_act"), stt, (double*)nullptr,
                          S_<double>("o1t_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
       LRP_HIP_CHECK((skinny<double, double, double>(h1 + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
-                                                    hprojd.as<double>(), H, B, H, H, 0, st)));
+                                                    hprojd.as<double>(), H, B, H, H, 0, st, KS_PROJ, ps)));
       LRP_HIP_CHECK((skinny<double, double, double>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
-                                                    sprojd.as<double>(), H, B, H, H, 0, st)));
+                                                    sprojd.as<double>(), H, B, H, H, 0, st, KS_PROJ, ps)));
       const size_t lds = (size_t)(2 * H + L + 8) * sizeof(double);
-      hipLaunchKernelGGL(gtd_attention_kernel, dim3(B), dim3(256), lds, st, hprojd.as<double>(), sprojd.as<double>(),
+      hipLaunchKernelGGL(gtd_attention_kernel, dim3(B), dim3(256), lds, st, hprojd.as<double>(), sprojd.as<double>(), KS_PROJ, ps,
                          stat.as<float>(), vvec.as<float>(), if_pre.as<float>(), h1, h2, stt, S_<double>("attention"),
                          S_<double>("beta"), S_<double>("context"), S_<double>("context_hat"), xh2d.as<double>(),
                          S_<double>("x2t"), i, Tm, L, H);
       LRP_HIP_CHECK(hipGetLastError());
       LRP_HIP_CHECK((skinny<double, double, double>(xh2d.as<double>(), 3 * H, Wcat2.as<float>(), 4 * H, bcat2.as<float>(),
-                                                    zg2d.as<double>(), 4 * H, B, 3 * H, 4 * H, 0, st)));
-      hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg2d.as<double>(), 4 * H, h2, S_<double>("c2t"),
+                                                    zg2d.as<double>(), 4 * H, B, 3 * H, 4 * H, 0, st, KS_GATE, zs2)));
+      hipLaunchKernelGGL(gtd_pointwise_kernel, dim3(B), dim3(256), 0, st, zg2d.as<double>(), 4 * H, KS_GATE, zs2, h2, S_<double>("c2t"),
                          S_<double>("g2t"), S_<double>("i2t_act"), S_<double>("f2t_act"), (double*)nullptr,
                          h2u.as<double>(), S_<double>("o2t_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());

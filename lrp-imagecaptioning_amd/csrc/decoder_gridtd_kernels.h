@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void gtd_prep_x1_kernel(const float* __restric
 }
 
 // LSTM pointwise (E:129-138), optionally with the sentinel s = tanh(c) * sigmoid(gate)  (E:1145)
-__global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __restrict__ z, int ldz, double* __restrict__ ht,
+// z arrives as `ks` split-K slabs (`slab` doubles apart), added here in a fixed order
+__global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __restrict__ z, int ldz, int ks, size_t slab,
+                                                            double* __restrict__ ht,
                                                             double* __restrict__ ct, double* __restrict__ gt,
                                                             double* __restrict__ it, double* __restrict__ ft,
                                                             double* __restrict__ st, double* __restrict__ hu,
@@ -46,7 +48,14 @@ __global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __rest
   const double* zb = z + (size_t)b * ldz;
   const size_t prev = ((size_t)b * S + step) * H, cur = prev + H;
   for (int j = threadIdx.x; j < H; j += 256) {
-    const double i_ = sigmoid_d(zb[j]), f_ = sigmoid_d(zb[H + j]), g_ = zb[2 * H + j], o_ = sigmoid_d(zb[3 * H + j]);
+    double zz[5];
+    const int ng = st ? 5 : 4;
+    for (int g = 0; g < ng; ++g) {
+      double v = zb[g * H + j];
+      for (int q = 1; q < ks; ++q) v += zb[(size_t)q * slab + g * H + j];
+      zz[g] = v;
+    }
+    const double i_ = sigmoid_d(zz[0]), f_ = sigmoid_d(zz[1]), g_ = zz[2], o_ = sigmoid_d(zz[3]);
     const double c = f_ * ct[prev + j] + i_ * tanh(g_);
     const double tc = tanh(c);
     const double h = o_ * tc;
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __rest
     it[cur + j] = i_;
     ft[cur + j] = f_;
     ot[cur + j] = o_;                                  // (gradient baselines, E:1327-1342)
-    if (st) st[cur + j] = tc * sigmoid_d(zb[4 * H + j]);
+    if (st) st[cur + j] = tc * sigmoid_d(zz[4]);
     if (hu) hu[((size_t)b * Tm + step) * H + j] = h;          // rows of the output-layer GEMM (h2 only, E:1154)
   }
 }
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(256) void gtd_pointwise_kernel(const double* __rest
 // attention + sentinel mix on h1 (E:1140-1149), then xh2[b] = [ c_hat | h1 | h2_{i} ] and x2t (E:1151)
 // dynamic LDS: double hp[H], sp[H], pre[L+1]
 __global__ __launch_bounds__(256) void gtd_attention_kernel(const double* __restrict__ hproj, const double* __restrict__ sproj,
-                                                            const float* __restrict__ proj, const float* __restrict__ wa,
+                                                            int ks, size_t slab, const float* __restrict__ proj, const float* __restrict__ wa,
                                                             const float* __restrict__ if_pre, const double* __restrict__ h1t,
                                                             const double* __restrict__ h2t, const double* __restrict__ st,
                                                             double* __restrict__ att, double* __restrict__ beta,
@@ -76,7 +85,11 @@ __global__ __launch_bounds__(256) void gtd_attention_kernel(const double* __rest
   double* sp = gsm + H;
   double* pre = gsm + 2 * H;
   const int b = blockIdx.x, S = Tm + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int j = tid; j < H; j += 256) { hp[j] = hproj[(size_t)b * H + j]; sp[j] = sproj[(size_t)b * H + j]; }
+  for (int j = tid; j < H; j += 256) {
+    double hv = hproj[(size_t)b * H + j], sv = sproj[(size_t)b * H + j];
+    for (int q = 1; q < ks; ++q) { hv += hproj[(size_t)q * slab + (size_t)b * H + j]; sv += sproj[(size_t)q * slab + (size_t)b * H + j]; }
+    hp[j] = hv; sp[j] = sv;
+  }
   __syncthreads();
   for (int l = wave; l <= L; l += 4) {
     double p = 0.0;
