@@ -96,6 +96,7 @@ struct ResNetEncoder {
     LRP_TRY(stemA.alloc(B * stem_hw * 2 * RN_STEM_K * 4, total));
     LRP_TRY(a0.alloc(B * stem_hw * stem_c * 4, total));
     LRP_TRY(q_stem.alloc(B * stem_hw * stem_c * 4, total));
+    LRP_TRY(pool_win.alloc(B * (stem_hw / 4) * stem_c, total));      // winner of every 3x3/2 pool window (one byte)
     for (DevBuf* d : {&fa, &fb, &fc, &fz, &fsc}) LRP_TRY(d->alloc(B * max_act * 4, total));
     LRP_TRY(feat.alloc(B * (size_t)top_h * top_w * top_c * 4, total));
     const size_t max_tok = std::max(max_act, stem_hw * (size_t)std::max(RN_STEM_TCOLS, stem_c));
@@ -248,7 +249,7 @@ struct ResNetEncoder {
       LRP_HIP_CHECK(hipGetLastError());
       const size_t np = (size_t)B * (s.Hout / 2) * (s.Wout / 2) * s.cout;
       hipLaunchKernelGGL(rn_pool3_kernel, dim3(stream_grid(np)), dim3(256), 0, st, a0.as<float>(), blocks[0].t_in.as<float>(),
-                         B, s.Hout, s.Wout, s.cout);
+                         pool_win.as<unsigned char>(), B, s.Hout, s.Wout, s.cout);
       LRP_HIP_CHECK(hipGetLastError());
     }
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
@@ -356,7 +357,7 @@ struct ResNetEncoder {
     // stem: pool routing * Q_stem -> T = S . W (K = stem_c, N = 294) -> 7x7/2 stencil with the x+/x- selection
     const RnUnit& s = units[0];
     const size_t tot = (size_t)n * s.Hout * s.Wout * s.cout;
-    hipLaunchKernelGGL(rn_pool3_route_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, Ro, a0.as<float>(),
+    hipLaunchKernelGGL(rn_pool3_route_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
                        q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
     LRP_HIP_CHECK(hipGetLastError());
     ConvArgs ca{};
@@ -372,6 +373,7 @@ struct ResNetEncoder {
   // the stem's routing needs Q alone: what arrives at a0 = relu(y) through the pool is already a relevance
   // (t * C1 of the first block), so multiplying by the relu-unit gate a0*Q would count a0 twice
   DevBuf q_stem;
+  DevBuf pool_win;
 
   int profile_records(int cap, double* ms_out, double* flop_out, int* n_out) {
     int k = 0;

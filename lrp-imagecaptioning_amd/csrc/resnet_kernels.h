@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256) void rn_scatter2_kernel(const float* __restric
 __device__ __forceinline__ float rn_padded_at(const float* __restrict__ a, int n, int i, int j, int c, int H, int W, int C) {
   return (i >= 0 && i < H && j >= 0 && j < W) ? a[(((size_t)n * H + i) * W + j) * C + c] : 0.f;   // zero padding is a candidate
 }
-__global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__ a, float* __restrict__ out, int NB, int H,
-                                                       int W, int C) {
+// win[i] = kh*3 + kw of the FIRST maximum in window scan order (what tf.gradients routes to): the per-token routing
+// reads this byte instead of re-deriving the arg-max of up to four windows (36 loads) for every token
+__global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__ a, float* __restrict__ out,
+                                                       unsigned char* __restrict__ win, int NB, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2;
   const size_t total = (size_t)NB * Ho * Wo * C;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -138,15 +140,20 @@ __global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__
     const int oh = (int)(r % Ho);
     const int n = (int)(r / Ho);
     float m = -INFINITY;
+    int arg = 0;
     for (int kh = 0; kh < 3; ++kh)
-      for (int kw = 0; kw < 3; ++kw) m = fmaxf(m, rn_padded_at(a, n, 2 * oh + kh - 1, 2 * ow + kw - 1, c, H, W, C));
+      for (int kw = 0; kw < 3; ++kw) {
+        const float v = rn_padded_at(a, n, 2 * oh + kh - 1, 2 * ow + kw - 1, c, H, W, C);
+        if (v > m) { m = v; arg = kh * 3 + kw; }
+      }
     out[i] = m;
+    win[i] = (unsigned char)arg;
   }
 }
 
 // Relevance routing through that pool (gradient of max-pool = first arg-max of each window, windows overlap),
 // fused with the stem gate:  S[n][i][j][c] = Q[img][i][j][c] * sum_{windows (oh,ow) whose arg-max is (i,j)} R[n][oh][ow][c]
-__global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __restrict__ R, const float* __restrict__ a,
+__global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __restrict__ R, const unsigned char* __restrict__ win,
                                                              const float* __restrict__ Q, const int* __restrict__ row2img,
                                                              float* __restrict__ S, int ntok, int H, int W, int C) {
   const int Ho = H / 2, Wo = W / 2;
@@ -165,16 +172,9 @@ __global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __rest
       if (oh < 0 || oh >= Ho || 2 * oh - 1 > i || 2 * oh + 1 < i) continue;
       for (int ow = (j) / 2; ow <= (j + 1) / 2; ++ow) {
         if (ow < 0 || ow >= Wo || 2 * ow - 1 > j || 2 * ow + 1 < j) continue;
-        // first maximum in window scan order
-        float m = -INFINITY;
-        int ai = 0, aj = 0;
-        for (int kh = 0; kh < 3; ++kh)
-          for (int kw = 0; kw < 3; ++kw) {
-            const int ii = 2 * oh + kh - 1, jj = 2 * ow + kw - 1;
-            const float v = rn_padded_at(a, img, ii, jj, c, H, W, C);
-            if (v > m) { m = v; ai = ii; aj = jj; }
-          }
-        if (ai == i && aj == j) acc += R[(((size_t)t * Ho + oh) * Wo + ow) * C + c];
+        // (i, j) is position (kh, kw) = (i - 2 oh + 1, j - 2 ow + 1) of this window: did it win?
+        const int mine = (i - 2 * oh + 1) * 3 + (j - 2 * ow + 1);
+        if (win[(((size_t)img * Ho + oh) * Wo + ow) * C + c] == mine) acc += R[(((size_t)t * Ho + oh) * Wo + ow) * C + c];
       }
     }
     S[idx] = acc * Q[(((size_t)img * H + i) * W + j) * C + c];
