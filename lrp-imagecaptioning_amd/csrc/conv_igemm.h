@@ -86,6 +86,14 @@ struct ConvArgs {
   int tiles_x, tiles_y, img_mode;
   const float* ximg;
   const float* addend; // BIAS / BIAS_RELU epilogues: out = [relu](acc + bias + addend)  (bias may be null)
+  // EPI_MUL only — tail of a residual block in one epilogue (ResNet walk):
+  //   r    = acc * aux[img] + join[row] * join_gate[img]     (the shortcut's share joins the main branch, KG:799-803)
+  //   out  = r                                               (fp32 / split8 as usual)
+  //   out2 = r * gate2[img]                                  (head of the NEXT block's conv chain; split8 in bf16x3 mode)
+  const float* join;
+  const float* join_gate;
+  const float* gate2;
+  float* out2s;
   // gradient baselines on the MUL epilogues: the cached LRP gate is used as a MASK (gate != 0 <=> the unit's ReLU was
   // active and it won its pool window), and guided backprop also clamps the propagated value at 0
   int gate_binary, relu_out;
@@ -758,7 +766,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
             if (!okv[ps]) { rowv[ps] = 0; nv[ps] = 0; hv[ps] = 0; wv[ps] = 0; }
             imgv[ps] = a.row2img ? a.row2img[nv[ps]] : nv[ps];
           }
-          struct Gates { f32x4 g[UPN][CW / 4]; };
+          const bool tail = EPI == EPI_MUL && a.join != nullptr, head2 = EPI == EPI_MUL && a.out2s != nullptr;
+          struct Gates { f32x4 g[UPN][CW / 4]; f32x4 jn[CW / 4], jg[CW / 4], g2[CW / 4]; };
           auto gate_ptr = [&](int ps, int q) -> const float* {
             if constexpr (EPI == EPI_MUL)
               return a.aux + ((size_t)imgv[ps] * HW + hv[ps] * a.W + wv[ps]) * a.N + col;
@@ -770,6 +779,17 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
             for (int q = 0; q < UPN; ++q)
 #pragma unroll
               for (int q4 = 0; q4 < CW / 4; ++q4) G.g[q][q4] = *reinterpret_cast<const f32x4*>(gate_ptr(ps, q) + 4 * q4);
+            if constexpr (EPI == EPI_MUL) {
+              const size_t go = ((size_t)imgv[ps] * HW + hv[ps] * a.W + wv[ps]) * a.N + col;
+#pragma unroll
+              for (int q4 = 0; q4 < CW / 4; ++q4) {
+                if (tail) {
+                  G.jn[q4] = *reinterpret_cast<const f32x4*>(a.join + (size_t)rowv[ps] * a.N + col + 4 * q4);
+                  G.jg[q4] = *reinterpret_cast<const f32x4*>(a.join_gate + go + 4 * q4);
+                }
+                if (head2) G.g2[q4] = *reinterpret_cast<const f32x4*>(a.gate2 + go + 4 * q4);
+              }
+            }
           };
           Gates cur, nxt;
           load_gates(cur, 0);
@@ -794,7 +814,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
                   }
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
-                    const float pr = v[4 * q4 + e] * g[e];
+                    float pr = v[4 * q4 + e] * g[e];
+                    if (tail) pr += cur.jn[q4][e] * cur.jg[q4][e];
                     r[4 * q4 + e] = a.relu_out ? fmaxf(pr, 0.f) : pr;
                   }
                 }
@@ -810,6 +831,19 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
                   }
                 } else {
                   *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+                }
+                if (head2) {
+                  float r2[CW];
+#pragma unroll
+                  for (int q4 = 0; q4 < CW / 4; ++q4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r2[4 * q4 + e] = r[4 * q4 + e] * cur.g2[q4][e];
+                  float* d2 = a.out2s + (size_t)rowv[ps] * a.N + col;
+                  if constexpr (SPLIT_OUT) {
+                    split8_store(r2, d2);
+                  } else {
+                    *reinterpret_cast<f32x4*>(d2) = *reinterpret_cast<const f32x4*>(r2);
+                  }
                 }
               }
             }

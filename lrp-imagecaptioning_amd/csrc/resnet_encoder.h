@@ -46,7 +46,7 @@ struct ResNetEncoder {
   DevBuf images, stemA, a0;        // image copy, stem im2col, stem activation [B][H/2][W/2][stem]
   DevBuf fa, fb, fc, fz, fsc;      // forward scratch
   DevBuf feat;                     // [B][top...]
-  DevBuf r0, r1, r2, r3, r4;       // reverse scratch (per token)
+  DevBuf r0, r1, r2, r3, r4, r5;   // reverse scratch (per token)
   int encoded = 0;
   bool features_only = false;
   bool profile = false;
@@ -100,7 +100,7 @@ struct ResNetEncoder {
     for (DevBuf* d : {&fa, &fb, &fc, &fz, &fsc}) LRP_TRY(d->alloc(B * max_act * 4, total));
     LRP_TRY(feat.alloc(B * (size_t)top_h * top_w * top_c * 4, total));
     const size_t max_tok = std::max(max_act, stem_hw * (size_t)std::max(RN_STEM_TCOLS, stem_c));
-    for (DevBuf* d : {&r0, &r1, &r2, &r3, &r4}) LRP_TRY(d->alloc(NT * max_tok * 4, total));
+    for (DevBuf* d : {&r0, &r1, &r2, &r3, &r4, &r5}) LRP_TRY(d->alloc(NT * max_tok * 4, total));
     for (RnUnit& u : units) LRP_TRY(u.gate.alloc(B * u.out_elems() * 4, total));
     for (RnBlock& b : blocks) {
       LRP_TRY(b.t_in.alloc(B * (size_t)b.Hin * b.Win * b.cin * 4, total));
@@ -286,9 +286,13 @@ struct ResNetEncoder {
   // conv-LRP step through one unit: S [n][Hout][Wout][cout] -> out [n][Hout'][..][cin] = convT(S, w+) * aux[img]
   // split: S is in split8 form and the conv runs as bf16x3; plain_out: the result feeds an element-wise kernel (fp32)
   // instead of the next conv of the chain (split8)
+  struct BlockTail {                // optional: residual join and the next block's chain head, fused into the epilogue
+    const float* join = nullptr; const float* join_gate = nullptr; const float* gate2 = nullptr; float* out2 = nullptr;
+  };
   int unit_backward(const RnUnit& u, int n, const int* row2img, const float* S, const float* aux, float* out, hipStream_t st,
-                    bool split = false, bool plain_out = true) {
+                    bool split = false, bool plain_out = true, const BlockTail* tail = nullptr) {
     ConvArgs ca{};
+    if (tail) { ca.join = tail->join; ca.join_gate = tail->join_gate; ca.gate2 = tail->gate2; ca.out2s = tail->out2; }
     ca.in = S; ca.wpk = split ? u.w_bs.as<float>() : u.w_b.as<float>(); ca.row2img = row2img; ca.aux = aux; ca.out = out;
     ca.N = u.cin; ca.out_plain = plain_out ? 1 : 0;
     ca.Cin = u.cout; ca.CinP = conv_cinp(u.cout); ca.NB = n; ca.H = u.Hout; ca.W = u.Wout; ca.taps = u.k == 3 ? 9 : 1;
@@ -309,9 +313,50 @@ struct ResNetEncoder {
     const float* Ro = R_feat_dev;          // relevance at the current block's output
     float* cur = r0.as<float>();           // where the next R_t is written (ping-pong r0 / r4)
     float* other = r4.as<float>();
+    float* s3 = r1.as<float>();            // S3 = R_o * GA of the block being walked (r1 / r5 alternate)
+    float* s3_other = r5.as<float>();
+    bool have_s3 = false;                  // already written by the previous block's fused epilogue
+    auto block_split = [&](const RnBlock& bb) {
+      bool v = prec == PREC_BF16X3;
+      for (int ui : {bb.u0, bb.u1, bb.u2, bb.u3})
+        if (ui >= 0 && ((units[ui].cin | units[ui].cout) & 7)) v = false;
+      return v;
+    };
     for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
       const RnBlock& b = blocks[bi];
       const size_t per_o = (size_t)b.H * b.W * 4 * b.f;
+      if (b.u0 < 0 && fuse_tail()) {
+        // identity block, 3 conv launches: S3 -> S2 -> S1 -> R_t = t*C1 + R_o*GS, the join and (when the next block
+        // agrees on the operand format) the next block's S3 = R_t * GA_next written by unit 1's epilogue
+        const bool sp = block_split(b);
+        if (!have_s3) {
+          if (sp)
+            hipLaunchKernelGGL(rn_mul_gate_split_kernel, dim3(stream_grid((size_t)n * per_o / 8)), dim3(256), 0, st, Ro,
+                               b.GA.as<float>(), row2img, s3, n, per_o / 8);
+          else
+            hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GA.as<float>(),
+                               row2img, (const float*)nullptr, s3, n, per_o);
+          LRP_HIP_CHECK(hipGetLastError());
+        }
+        LRP_TRY(unit_backward(units[b.u3], n, row2img, s3, units[b.u2].gate.as<float>(), r2.as<float>(), st, sp, !sp));
+        LRP_TRY(unit_backward(units[b.u2], n, row2img, r2.as<float>(), units[b.u1].gate.as<float>(), r3.as<float>(), st, sp, !sp));
+        BlockTail tl;
+        tl.join = Ro; tl.join_gate = b.GS.as<float>();
+        have_s3 = false;
+        if (bi > 0 && block_split(blocks[bi - 1]) == sp) {
+          tl.gate2 = blocks[bi - 1].GA.as<float>(); tl.out2 = s3_other;
+          have_s3 = true;
+        }
+        LRP_TRY(unit_backward(units[b.u1], n, row2img, r3.as<float>(), b.t_in.as<float>(), cur, st, sp, true, &tl));
+        std::swap(s3, s3_other);
+        Ro = cur;
+        std::swap(cur, other);
+        continue;
+      }
+      if (have_s3) {                       // (projection block after a fused identity block: its S3 is already there)
+        // fall through to the generic path, which recomputes S3 into r1; keep it simple and just ignore the fused copy
+        have_s3 = false;
+      }
       // bf16x3 mode: the three convs of the main branch (and the projection) chain in split8 form; the products that
       // enter a chain are written split, what leaves it for the add / scatter kernels is plain fp32
       bool sp = prec == PREC_BF16X3;                     // split8 groups need channel counts % 8 == 0: exact fp32 otherwise
@@ -374,6 +419,10 @@ struct ResNetEncoder {
   // (t * C1 of the first block), so multiplying by the relu-unit gate a0*Q would count a0 twice
   DevBuf q_stem;
   DevBuf pool_win;
+  static bool fuse_tail() {                // LRP_RN_FUSE=0: separate element-wise join / head kernels
+    const char* e = getenv("LRP_RN_FUSE");
+    return !e || atoi(e) != 0;
+  }
 
   int profile_records(int cap, double* ms_out, double* flop_out, int* n_out) {
     int k = 0;
