@@ -97,6 +97,7 @@ struct ConvArgs {
   // gradient baselines on the MUL epilogues: the cached LRP gate is used as a MASK (gate != 0 <=> the unit's ReLU was
   // active and it won its pool window), and guided backprop also clamps the propagated value at 0
   int gate_binary, relu_out;
+  int dual_norelu;     // EPI_FWD_DUAL: first half without the relu (a conv + BatchNorm unit: c and Z+ in one pass)
   // halo-resident 3x3 variant (template HALO): a tile is th rows x tw (<= 14) columns of the image stack
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
@@ -740,7 +741,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
             int row, n_, h_, w_;
             if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
-            if (!isz) {
+            if (!isz && !a.dual_norelu) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }

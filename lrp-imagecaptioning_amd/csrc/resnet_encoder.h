@@ -25,6 +25,7 @@ struct RnUnit {            // conv + BN
   bool relu = false;
   bool have[6] = {false, false, false, false, false, false};   // W b gamma beta mean var
   DevBuf w_a, w_z, w_b, w_bs, bias, gamma, beta, mean, var;   // w_bs: w_b in split8 form (bf16x3 reverse walk)
+  DevBuf w_dual;   // [w rows | w+ rows]: c and Z+ of the unit in one conv pass (EPI_FWD_DUAL without the relu)
   DevBuf gate;             // [B][Hout][Wout][cout]: act*Q (relu units) or Q (pre-Add units)
   size_t out_elems() const { return (size_t)Hout * Wout * cout; }
   size_t in_elems() const { return (size_t)Hin * Win * cin; }
@@ -182,6 +183,13 @@ struct ResNetEncoder {
     pk.assign((size_t)Np * K, 0.f);
     pack_conv_fwd(wp.data(), taps, u.cin, u.cout, 0, Np, pk.data());           // inputs are post-ReLU: Z = conv(x, w+) + b
     LRP_TRY(up(u.w_z, pk, total));
+    if (!(u.cout & 3)) {
+      const int Nd = conv_npad(2 * u.cout);
+      pk.assign((size_t)Nd * K, 0.f);
+      pack_conv_fwd(w, taps, u.cin, u.cout, 0, Nd, pk.data());
+      pack_conv_fwd(wp.data(), taps, u.cin, u.cout, u.cout, Nd, pk.data());
+      LRP_TRY(up(u.w_dual, pk, total));
+    }
     const int Npb = conv_npad(u.cin), Kb = taps * conv_cinp(u.cout);
     pk.assign((size_t)Npb * Kb, 0.f);
     pack_conv_bwd(wp.data(), taps, u.cin, u.cout, 0, pk.data());
@@ -212,10 +220,17 @@ struct ResNetEncoder {
     if (u.k == 3) { ca.NB = B; ca.H = u.Hout; ca.W = u.Wout; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 9; }
     else { ca.NB = B * u.Hout * u.Wout; ca.H = 1; ca.W = 1; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 1; }
     ConvArgs cz = ca;
-    ca.wpk = u.w_a.as<float>(); ca.out = fc.as<float>();
-    LRP_HIP_CHECK(conv_launch(EPI_BIAS, ca, st));
-    cz.wpk = u.w_z.as<float>(); cz.out = fz.as<float>();
-    LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, st));
+    if (u.w_dual.p && dual_fwd()) {
+      // c = conv(x, w) + b and Z = conv(x, w+) + b in ONE pass over x: the A tile is staged once for both
+      ca.wpk = u.w_dual.as<float>(); ca.N = 2 * u.cout; ca.split = u.cout; ca.dual_norelu = 1;
+      ca.out = fc.as<float>(); ca.out2 = fz.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st));
+    } else {
+      ca.wpk = u.w_a.as<float>(); ca.out = fc.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_BIAS, ca, st));
+      cz.wpk = u.w_z.as<float>(); cz.out = fz.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, st));
+    }
     const size_t n = (size_t)B * u.out_elems();
     hipLaunchKernelGGL(rn_bn_unit_kernel, dim3(stream_grid(n)), dim3(256), 0, st, fc.as<float>(), fz.as<float>(),
                        u.gamma.as<float>(), u.beta.as<float>(), u.mean.as<float>(), u.var.as<float>(), RN_BN_EPS, act,
@@ -419,6 +434,10 @@ struct ResNetEncoder {
   // (t * C1 of the first block), so multiplying by the relu-unit gate a0*Q would count a0 twice
   DevBuf q_stem;
   DevBuf pool_win;
+  static bool dual_fwd() {                 // LRP_RN_DUAL=0: separate c / Z+ convs
+    const char* e = getenv("LRP_RN_DUAL");
+    return !e || atoi(e) != 0;
+  }
   static bool fuse_tail() {                // LRP_RN_FUSE=0: separate element-wise join / head kernels
     const char* e = getenv("LRP_RN_FUSE");
     return !e || atoi(e) != 0;
