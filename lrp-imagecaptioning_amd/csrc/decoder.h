@@ -11,6 +11,7 @@
 #include "common.h"
 #include "conv_igemm.h"
 #include "decoder_gridtd_kernels.h"
+#include "decoder_batched_kernels.h"
 #include "decoder_kernels.h"
 #include "gradient_kernels.h"
 
@@ -43,6 +44,9 @@ struct Decoder {
   int prec = PREC_BF16X3;   // arithmetic of the tail GEMM (follows lrp_set_precision)
   // grid-TD only
   DevBuf Wcat2, bcat2, Wg2T, xh1d, xh2d, zg1d, zg2d, hprojd, sprojd, h2u, rho;
+  // step-synchronous LRP scan (decoder_batched_kernels.h; allocated and packed on first use)
+  bool bx_ready = false;
+  DevBuf bxWg1, bxWg2, bx_rc, bx_rh, bx_rglob, bx_q32, bx_acc32;
   // gradient baselines (allocated and packed on first use)
   bool grad_ready = false;
   DevBuf gW1, gW2, gWglob, gWif, g_seed, g_dc1, g_dc2, g_dg, g_out1, g_out2, g_dglob, g_dwords, g_dctx, g_davg, g_tailA;
@@ -559,7 +563,43 @@ struct Decoder {
     return LRP_OK;
   }
 
-  int explain(int n, const int* img_dev, const int* t_dev, const int32_t*, const int32_t*, int variant,
+  // B operand [rows][K] (fp32, padded like pack_rows) from a host matrix
+  int pack_matrix(const std::vector<float>& m, int N, int K, DevBuf& dst, int64_t* total) {
+    const int Kp = conv_cinp(K);
+    std::vector<float> pk((size_t)conv_npad(N) * Kp, 0.f);
+    for (int r = 0; r < N; ++r) memcpy(&pk[(size_t)r * Kp], &m[(size_t)r * K], (size_t)K * sizeof(float));
+    return upload(dst, pk, total);
+  }
+  // gate-g block of an LSTM, [Wi;Wh][:, 2H:3H] (E:556-558), as (Kx + H) rows x H
+  std::vector<float> gate_g_block(const char* wi, const char* wh, int Kx) const {
+    const std::vector<float>& Wi = raw.at(wi);
+    const std::vector<float>& Wh = raw.at(wh);
+    std::vector<float> g((size_t)(Kx + H) * H);
+    for (int d = 0; d < Kx + H; ++d)
+      for (int j = 0; j < H; ++j)
+        g[(size_t)d * H + j] = d < Kx ? Wi[(size_t)d * 4 * H + 2 * H + j] : Wh[(size_t)(d - Kx) * 4 * H + 2 * H + j];
+    return g;
+  }
+  static bool batched_scan() {            // LRP_DEC_BATCHED=0: one workgroup per unit (dec_explain_adaptive_kernel)
+    const char* e = getenv("LRP_DEC_BATCHED");
+    return !e || atoi(e) != 0;
+  }
+  int bx_prepare(int64_t* total) {
+    if (bx_ready) return LRP_OK;
+    const size_t NT = NT_max;
+    if (kind == LRP_DEC_ADAPTIVE) {
+      LRP_TRY(pack_matrix(gate_g_block("lstm_Wi", "lstm_Wh", 2 * E), 2 * E + H, H, bxWg1, total));
+      LRP_TRY(bx_acc32.alloc(NT * (2 * E + H) * 4, total));
+    }
+    LRP_TRY(bx_rc.alloc(NT * H * 8, total));
+    LRP_TRY(bx_rh.alloc(NT * H * 8, total));
+    LRP_TRY(bx_rglob.alloc(NT * E * 8, total));
+    LRP_TRY(bx_q32.alloc(NT * H * 4, total));
+    bx_ready = true;
+    return LRP_OK;
+  }
+
+  int explain(int n, const int* img_dev, const int* t_dev, const int32_t*, const int32_t* t_host, int variant,
               const float* feat_dev, float* R_feat_dev, float* att_dev, double* rwords_dev, hipStream_t st) {
     if (variant != LRP_EXPLAIN_SEQUENCE && variant != LRP_EXPLAIN_SINGLE_STEP) return fail(LRP_ERR_INVALID, "bad variant");
     if (kind == LRP_DEC_GRIDTD) {
@@ -578,9 +618,36 @@ struct Decoder {
     a.rctx = rctx.as<double>(); a.ravg = ravg.as<double>();
     a.att_out = att_dev; a.rwords_out = rwords_dev;
     a.Tm = Tm; a.L = L; a.D = D; a.H = H; a.E = E; a.V = V; a.single_step = variant == LRP_EXPLAIN_SINGLE_STEP;
-    const size_t lds = (size_t)(2 * H + std::max(H, E) + E + 8) * sizeof(double);
-    hipLaunchKernelGGL(dec_explain_adaptive_kernel, dim3(n), dim3(256), lds, st, a);
-    LRP_HIP_CHECK(hipGetLastError());
+    if (batched_scan() && (H & 3) == 0 && t_host) {
+      // step-synchronous scan: per step one pointwise kernel, ONE GEMM over all units, one routing kernel
+      int64_t dummy = 0;
+      LRP_TRY(bx_prepare(&dummy));
+      int t_max = 0;
+      for (int i = 0; i < n; ++i) t_max = std::max(t_max, (int)t_host[i]);
+      BxArgs x{};
+      x.img_idx = img_dev; x.tpos = t_dev; x.cap = a.cap; x.ht = a.ht; x.ct = a.ct; x.gt = a.gt; x.it = a.it; x.ft = a.ft;
+      x.st = a.st; x.beta = a.beta; x.att = a.att; x.xt = a.xt; x.ctx = a.ctx; x.chat = a.chat; x.preds = a.preds;
+      x.Wout = a.Wout; x.WglobT = a.WglobT; x.avg = a.avg; x.glob_pre = a.glob_pre;
+      x.rc = bx_rc.as<double>(); x.rh = bx_rh.as<double>(); x.rglob = bx_rglob.as<double>(); x.q32 = bx_q32.as<float>();
+      x.acc32 = bx_acc32.as<float>(); x.rctx = a.rctx; x.ravg = a.ravg; x.att_out = att_dev; x.rwords_out = rwords_dev;
+      x.Tm = Tm; x.L = L; x.D = D; x.H = H; x.E = E; x.V = V; x.single_step = a.single_step;
+      hipLaunchKernelGGL(bx_head_kernel, dim3(n), dim3(256), 0, st, x);
+      LRP_HIP_CHECK(hipGetLastError());
+      const int steps = a.single_step ? 1 : t_max;
+      for (int s = 0; s < steps; ++s) {
+        hipLaunchKernelGGL(bx_pre_kernel, dim3(n), dim3(256), 0, st, x, s);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(gemm_nt(bx_q32.as<float>(), n, H, bxWg1, 2 * E + H, bx_acc32.as<float>(), st));
+        hipLaunchKernelGGL(bx_post_kernel, dim3(n), dim3(256), 0, st, x, s);
+        LRP_HIP_CHECK(hipGetLastError());
+      }
+      hipLaunchKernelGGL(bx_tail_kernel, dim3(n), dim3(256), (size_t)E * sizeof(double), st, x);
+      LRP_HIP_CHECK(hipGetLastError());
+    } else {
+      const size_t lds = (size_t)(2 * H + std::max(H, E) + E + 8) * sizeof(double);
+      hipLaunchKernelGGL(dec_explain_adaptive_kernel, dim3(n), dim3(256), lds, st, a);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
     if (tailA.p && (D & 7) == 0) {
       // tail on the matrix cores: A operand -> 1-tap conv_igemm with the F-multiply as its gate -> mean-pool share
       const bool split = prec == PREC_BF16X3;

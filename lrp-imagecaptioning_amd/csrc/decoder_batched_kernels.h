@@ -1,0 +1,126 @@
+// decoder_batched_kernels.h — the per-token decoder LRP (E:537-666, E:1180-1321) run STEP-SYNCHRONOUSLY over all
+// (image, token) units of a call: at scan step s every unit handles its LSTM step i = t-1-s, so the gate-g rule's
+// product with the (2E+H) x H weight block is ONE (n x H).(H x Nd) GEMM on the matrix cores per step (conv_igemm,
+// 1 tap, exact fp32) instead of one GEMV per unit that re-reads 3 MB of weights from L2 (dec_explain_adaptive_kernel /
+// gtd_explain_kernel: one workgroup per unit, kept as the fallback for H % 4 != 0).  The element-wise rule arithmetic
+// stays in float64 exactly as in those kernels; only the GEMM operand q = r_g / stab(g) and its result pass through
+// float32 (6e-8 relative, bar 1e-4).
+#pragma once
+#include "decoder_kernels.h"
+
+namespace lrp {
+
+struct BxArgs {                                    // adaptive
+  const int* img_idx; const int* tpos; const int* cap;
+  const float *ht, *ct, *gt, *it, *ft, *st, *beta, *att, *xt;
+  const double *ctx, *chat, *preds;
+  const float* Wout; const float* WglobT; const float *avg, *glob_pre;
+  double *rc, *rh, *rglob;                         // [n][H], [n][H], [n][E]   scan state
+  float* q32;                                      // [n][H]      GEMM operand
+  const float* acc32;                              // [n][2E+H]   GEMM result
+  double *rctx, *ravg;
+  float* att_out; double* rwords_out;
+  int Tm, L, D, H, E, V, single_step;
+};
+
+// head (E:552-602), identical arithmetic to dec_explain_adaptive_kernel
+__global__ __launch_bounds__(256) void bx_head_kernel(BxArgs a) {
+  const int H = a.H, E = a.E, Tm = a.Tm, S = Tm + 1;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], t = a.tpos[n];
+  const size_t rowt = (size_t)b * S + t;
+  const int k = a.cap[b * Tm + t - 1] - 1;
+  const double zk = a.preds[((size_t)b * Tm + (t - 1)) * a.V + k];
+  const double bt32_1m = (double)(1.f - a.beta[rowt]);
+  const float btf = a.beta[rowt];
+  for (int j = tid; j < H; j += 256) {
+    const double h = (double)a.ht[rowt * H + j], ch = a.chat[rowt * H + j];
+    const double u = h + ch;
+    const double r_u = ((double)a.Wout[(size_t)j * a.V + k] * u) / stab(zk) * zk;
+    const double su = stab(u);
+    const double r_h = h / su * r_u;
+    const double r_ch = ch / su * r_u;
+    const double sch = stab(ch);
+    const double r_ctx = (bt32_1m * a.ctx[rowt * H + j]) / sch * r_ch;
+    const double r_s = (double)(btf * a.st[rowt * H + j]) / sch * r_ch;
+    a.rctx[(size_t)n * H + j] = r_ctx / stab(a.ctx[rowt * H + j]);
+    a.rc[(size_t)n * H + j] = r_s;
+    a.rh[(size_t)n * H + j] = r_h;
+  }
+  for (int e = tid; e < E; e += 256) a.rglob[(size_t)n * E + e] = 0.0;
+  if (a.att_out)
+    for (int l = tid; l < a.L; l += 256) a.att_out[(size_t)n * a.L + l] = a.att[rowt * a.L + l];
+  if (a.rwords_out)
+    for (int i = tid; i < Tm; i += 256) a.rwords_out[(size_t)n * Tm + i] = 0.0;
+}
+
+// cell rules of scan step s (E:604-619) -> q; units that are done write a zero row
+__global__ __launch_bounds__(256) void bx_pre_kernel(BxArgs a, int s) {
+  const int H = a.H, S = a.Tm + 1;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], i = a.tpos[n] - 1 - s;
+  float* q = a.q32 + (size_t)n * H;
+  if (i < 0 || (a.single_step && s > 0)) {
+    for (int j = tid; j < H; j += 256) q[j] = 0.f;
+    return;
+  }
+  const size_t r1 = ((size_t)b * S + i + 1) * H, r0 = ((size_t)b * S + i) * H;
+  double* rc = a.rc + (size_t)n * H;
+  const double* rh = a.rh + (size_t)n * H;
+  for (int j = tid; j < H; j += 256) {
+    const double rcj = rc[j] + rh[j];
+    const double sc = stab((double)a.ct[r1 + j]);
+    const float pg = a.it[r1 + j] * tanhf(a.gt[r1 + j]);
+    const float pc = a.ft[r1 + j] * a.ct[r0 + j];
+    const double r_g = (double)pg / sc * rcj;
+    rc[j] = (double)pc / sc * rcj;
+    q[j] = (float)(r_g / stab((double)a.gt[r1 + j]));
+  }
+}
+
+// input rule of scan step s (E:620-632): r_x = x * (W_g q), routed to r_words / r_glob / r_h
+__global__ __launch_bounds__(256) void bx_post_kernel(BxArgs a, int s) {
+  __shared__ double red[4];
+  const int H = a.H, E = a.E, Tm = a.Tm, S = Tm + 1, Nd = 2 * E + H;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], i = a.tpos[n] - 1 - s;
+  if (i < 0 || (a.single_step && s > 0)) return;
+  const size_t r0 = ((size_t)b * S + i) * H;
+  const float* acc = a.acc32 + (size_t)n * Nd;
+  double wsum = 0.0;
+  for (int d = tid; d < Nd; d += 256) {
+    const float x = d < 2 * E ? a.xt[((size_t)b * Tm + i) * 2 * E + d] : a.ht[r0 + d - 2 * E];
+    const double rx = (double)x * (double)acc[d];
+    if (d < E) wsum += rx;
+    else if (d < 2 * E) a.rglob[(size_t)n * E + d - E] += rx;
+    else a.rh[(size_t)n * H + d - 2 * E] = rx;
+  }
+  const double ws = block_sum_d(wsum, red);
+  if (tid == 0 && a.rwords_out) a.rwords_out[(size_t)n * Tm + i] = ws;
+}
+
+// global-feature rule (E:634-639) + r_words post-processing (E:660-665)
+__global__ __launch_bounds__(256) void bx_tail_kernel(BxArgs a) {
+  extern __shared__ double dsm[];
+  double* q = dsm;
+  const int E = a.E, D = a.D, Tm = a.Tm;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], t = a.tpos[n];
+  for (int e = tid; e < E; e += 256) q[e] = a.rglob[(size_t)n * E + e] / stab((double)a.glob_pre[(size_t)b * E + e]);
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    double s = 0.0;
+    for (int e = 0; e < E; ++e) s += (double)a.WglobT[(size_t)e * D + d] * q[e];
+    a.ravg[(size_t)n * D + d] = (double)a.avg[(size_t)b * D + d] * s;
+  }
+  if (a.rwords_out && !a.single_step && tid == 0) {
+    double* rw = a.rwords_out + (size_t)n * Tm;
+    rw[0] = 0.0;
+    double m = 0.0;
+    for (int i = 0; i < t; ++i) m = fmax(m, fabs(rw[i]));
+    for (int i = 0; i + 1 < t; ++i) rw[i] = m != 0.0 ? rw[i + 1] / m : rw[i + 1];
+    rw[t - 1] = 0.0;
+  }
+}
+
+}  // namespace lrp
