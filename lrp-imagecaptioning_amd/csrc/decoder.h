@@ -47,6 +47,7 @@ struct Decoder {
   // step-synchronous LRP scan (decoder_batched_kernels.h; allocated and packed on first use)
   bool bx_ready = false;
   DevBuf bxWg1, bxWg2, bx_rc, bx_rh, bx_rglob, bx_q32, bx_acc32;
+  DevBuf bx_g[7];          // grid-TD scan state: rc1 rc2 rh1 rh2 rchat nh1 nh2
   // gradient baselines (allocated and packed on first use)
   bool grad_ready = false;
   DevBuf gW1, gW2, gWglob, gWif, g_seed, g_dc1, g_dc2, g_dg, g_out1, g_out2, g_dglob, g_dwords, g_dctx, g_davg, g_tailA;
@@ -399,8 +400,8 @@ struct Decoder {
     return LRP_OK;
   }
 
-  int explain_gridtd(int n, const int* img_dev, const int* t_dev, const float* feat_dev, float* R_feat_dev, float* att_dev,
-                     double* rwords_dev, hipStream_t st) {
+  int explain_gridtd(int n, const int* img_dev, const int* t_dev, const int32_t* t_host, const float* feat_dev,
+                     float* R_feat_dev, float* att_dev, double* rwords_dev, hipStream_t st) {
     GtdExplainArgs a{};
     a.img_idx = img_dev; a.tpos = t_dev; a.cap = cap_dev.as<int>();
     a.h1t = S_<double>("h1t"); a.c1t = S_<double>("c1t"); a.g1t = S_<double>("g1t"); a.i1t = S_<double>("i1t_act");
@@ -413,9 +414,40 @@ struct Decoder {
     a.rho = rho.as<double>(); a.ravg = ravg.as<double>();
     a.att_out = att_dev; a.rwords_out = rwords_dev;
     a.Tm = Tm; a.L = L; a.D = D; a.H = H; a.E = E; a.V = V;
-    const size_t lds = (size_t)(7 * H + std::max(H, E) + E + 8) * sizeof(double);
-    hipLaunchKernelGGL(gtd_explain_kernel, dim3(n), dim3(256), lds, st, a);
-    LRP_HIP_CHECK(hipGetLastError());
+    if (batched_scan() && (H & 3) == 0 && t_host) {
+      int64_t dummy = 0;
+      LRP_TRY(bx_prepare(&dummy));
+      int t_max = 0;
+      for (int i = 0; i < n; ++i) t_max = std::max(t_max, (int)t_host[i]);
+      GbxArgs x{};
+      x.img_idx = img_dev; x.tpos = t_dev; x.cap = a.cap;
+      x.h1t = a.h1t; x.c1t = a.c1t; x.g1t = a.g1t; x.i1t = a.i1t; x.f1t = a.f1t; x.h2t = a.h2t; x.c2t = a.c2t; x.g2t = a.g2t;
+      x.i2t = a.i2t; x.f2t = a.f2t; x.x1t = a.x1t; x.x2t = a.x2t; x.ctx = a.ctx; x.st = a.st; x.chat = a.chat; x.beta = a.beta;
+      x.att = a.att; x.preds = a.preds; x.Wout = a.Wout; x.WglobT = a.WglobT; x.avg = a.avg; x.glob_pre = a.glob_pre;
+      x.rc1 = bx_g[0].as<double>(); x.rc2 = bx_g[1].as<double>(); x.rh1 = bx_g[2].as<double>(); x.rh2 = bx_g[3].as<double>();
+      x.rchat = bx_g[4].as<double>(); x.nh1 = bx_g[5].as<double>(); x.nh2 = bx_g[6].as<double>();
+      x.rglob = bx_rglob.as<double>(); x.q32 = bx_q32.as<float>(); x.acc32 = bx_acc32.as<float>();
+      x.rho = a.rho; x.ravg = a.ravg; x.att_out = att_dev; x.rwords_out = rwords_dev;
+      x.Tm = Tm; x.L = L; x.D = D; x.H = H; x.E = E; x.V = V;
+      hipLaunchKernelGGL(gbx_head_kernel, dim3(n), dim3(256), 0, st, x);
+      LRP_HIP_CHECK(hipGetLastError());
+      for (int s = 0; s < t_max; ++s) {
+        hipLaunchKernelGGL(gbx_pre2_kernel, dim3(n), dim3(256), 0, st, x, s);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(gemm_nt(bx_q32.as<float>(), n, H, bxWg2, 3 * H, bx_acc32.as<float>(), st));
+        hipLaunchKernelGGL(gbx_mid_kernel, dim3(n), dim3(256), 0, st, x, s);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_TRY(gemm_nt(bx_q32.as<float>(), n, H, bxWg1, 2 * H + 2 * E, bx_acc32.as<float>(), st));
+        hipLaunchKernelGGL(gbx_post_kernel, dim3(n), dim3(256), 0, st, x, s);
+        LRP_HIP_CHECK(hipGetLastError());
+      }
+      hipLaunchKernelGGL(gbx_tail_kernel, dim3(n), dim3(256), (size_t)E * sizeof(double), st, x);
+      LRP_HIP_CHECK(hipGetLastError());
+    } else {
+      const size_t lds = (size_t)(7 * H + std::max(H, E) + E + 8) * sizeof(double);
+      hipLaunchKernelGGL(gtd_explain_kernel, dim3(n), dim3(256), lds, st, a);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
     if (tailA.p && (D & 7) == 0) {
       // tail on the matrix cores, as for the adaptive decoder
       const bool split = prec == PREC_BF16X3;
@@ -590,6 +622,11 @@ struct Decoder {
     if (kind == LRP_DEC_ADAPTIVE) {
       LRP_TRY(pack_matrix(gate_g_block("lstm_Wi", "lstm_Wh", 2 * E), 2 * E + H, H, bxWg1, total));
       LRP_TRY(bx_acc32.alloc(NT * (2 * E + H) * 4, total));
+    } else {
+      LRP_TRY(pack_matrix(gate_g_block("td_Wi", "td_Wh", H + 2 * E), 2 * H + 2 * E, H, bxWg1, total));
+      LRP_TRY(pack_matrix(gate_g_block("lang_Wi", "lang_Wh", 2 * H), 3 * H, H, bxWg2, total));
+      LRP_TRY(bx_acc32.alloc(NT * (size_t)std::max(2 * H + 2 * E, 3 * H) * 4, total));
+      for (DevBuf& d : bx_g) LRP_TRY(d.alloc(NT * H * 8, total));
     }
     LRP_TRY(bx_rc.alloc(NT * H * 8, total));
     LRP_TRY(bx_rh.alloc(NT * H * 8, total));
@@ -605,7 +642,7 @@ struct Decoder {
     if (kind == LRP_DEC_GRIDTD) {
       if (variant != LRP_EXPLAIN_SEQUENCE)      // E:167-172: the grid-TD class does not override _explain_lstm_single_word
         return fail(LRP_ERR_UNSUPPORTED, "the grid-TD decoder has no single-step variant");
-      return explain_gridtd(n, img_dev, t_dev, feat_dev, R_feat_dev, att_dev, rwords_dev, st);
+      return explain_gridtd(n, img_dev, t_dev, t_host, feat_dev, R_feat_dev, att_dev, rwords_dev, st);
     }
     ExplainArgs a{};
     a.img_idx = img_dev; a.tpos = t_dev; a.cap = cap_dev.as<int>();

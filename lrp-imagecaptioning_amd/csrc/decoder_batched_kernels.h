@@ -123,4 +123,132 @@ __global__ __launch_bounds__(256) void bx_tail_kernel(BxArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// grid-TD (E:1180-1321): the same step-synchronous scan with two LSTMs per step — language cell -> GEMM (3H columns)
+// -> routing + c_hat split + top-down cell -> GEMM (H+2E+H columns) -> routing.  Arithmetic transcribed from
+// gtd_explain_kernel (decoder_gridtd_kernels.h), state in float64 per unit instead of LDS.
+// ------------------------------------------------------------------------------------------------------------
+struct GbxArgs {
+  const int* img_idx; const int* tpos; const int* cap;
+  const double *h1t, *c1t, *g1t, *i1t, *f1t, *h2t, *c2t, *g2t, *i2t, *f2t, *x1t, *x2t;
+  const double *ctx, *st, *chat, *beta, *att, *preds;
+  const float* Wout; const float* WglobT; const float *avg, *glob_pre;
+  double *rc1, *rc2, *rh1, *rh2, *rchat, *nh1, *nh2, *rglob;      // [n][H] each, rglob [n][E]
+  float* q32; const float* acc32;
+  double *rho, *ravg;
+  float* att_out; double* rwords_out;
+  int Tm, L, D, H, E, V;
+};
+
+__global__ __launch_bounds__(256) void gbx_head_kernel(GbxArgs a) {                  // E:1212-1229
+  const int H = a.H, E = a.E, Tm = a.Tm, S = Tm + 1;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], t = a.tpos[n];
+  const size_t rowt = (size_t)b * S + t, o = (size_t)n * H;
+  const int k = a.cap[b * Tm + t - 1] - 1;
+  const double zk = a.preds[((size_t)b * Tm + (t - 1)) * a.V + k];
+  for (int j = tid; j < H; j += 256) {
+    const double h2 = a.h2t[rowt * H + j], ch = a.chat[rowt * H + j];
+    const double u = h2 + ch;
+    const double r_u = ((double)a.Wout[(size_t)j * a.V + k] * u) / stab(zk) * zk;
+    a.rh2[o + j] = h2 / stab(u) * r_u;
+    a.rchat[o + j] = ch / stab(u) * r_u;
+    a.rc1[o + j] = 0.0; a.rc2[o + j] = 0.0; a.rh1[o + j] = 0.0;
+  }
+  for (int e = tid; e < E; e += 256) a.rglob[(size_t)n * E + e] = 0.0;
+  if (a.att_out)
+    for (int l = tid; l < a.L; l += 256) a.att_out[(size_t)n * a.L + l] = (float)a.att[rowt * a.L + l];
+  if (a.rwords_out)
+    for (int i = tid; i < Tm; i += 256) a.rwords_out[(size_t)n * Tm + i] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void gbx_pre2_kernel(GbxArgs a, int s) {           // language LSTM cell, E:1233-1251
+  const int H = a.H, S = a.Tm + 1;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], i = a.tpos[n] - 1 - s;
+  float* q = a.q32 + (size_t)n * H;
+  if (i < 0) {
+    for (int j = tid; j < H; j += 256) q[j] = 0.f;
+    return;
+  }
+  const size_t r1 = ((size_t)b * S + i + 1) * H, r0 = ((size_t)b * S + i) * H, o = (size_t)n * H;
+  for (int j = tid; j < H; j += 256) {
+    const double rc = a.rc2[o + j] + a.rh2[o + j];
+    const double sc = stab(a.c2t[r1 + j]);
+    const double r_g = (a.i2t[r1 + j] * tanh(a.g2t[r1 + j])) / sc * rc;
+    a.rc2[o + j] = (a.f2t[r1 + j] * a.c2t[r0 + j]) / sc * rc;
+    q[j] = (float)(r_g / stab(a.g2t[r1 + j]));
+  }
+}
+
+// routing of the language LSTM's input relevance (E:1252-1254), c_hat split (E:1255-1266), top-down cell (E:1268-1281)
+__global__ __launch_bounds__(256) void gbx_mid_kernel(GbxArgs a, int s) {
+  const int H = a.H, Tm = a.Tm, S = Tm + 1, Nd2 = 3 * H;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], t = a.tpos[n], i = t - 1 - s;
+  float* q = a.q32 + (size_t)n * H;
+  if (i < 0) {
+    for (int j = tid; j < H; j += 256) q[j] = 0.f;
+    return;
+  }
+  const size_t r1 = ((size_t)b * S + i + 1) * H, r0 = ((size_t)b * S + i) * H, o = (size_t)n * H;
+  const float* acc = a.acc32 + (size_t)n * Nd2;
+  for (int d = tid; d < Nd2; d += 256) {
+    const double x = d < 2 * H ? a.x2t[((size_t)b * Tm + i) * 2 * H + d] : a.h2t[r0 + d - 2 * H];
+    const double rx = x * (double)acc[d];
+    if (d < H) a.rchat[o + d] = (i == t - 1 ? a.rchat[o + d] : 0.0) + rx;
+    else if (d < 2 * H) a.rh1[o + d - H] += rx;
+    else a.nh2[o + d - 2 * H] = rx;
+  }
+  __syncthreads();                                   // (one workgroup per unit: its own writes above are all it needs)
+  const double bt = a.beta[(size_t)b * S + i + 1];
+  for (int j = tid; j < H; j += 256) {
+    const double sch = stab(a.chat[r1 + j]);
+    const double r_s = (bt * a.st[r1 + j]) / sch * a.rchat[o + j];
+    const double r_ctx = (a.ctx[r1 + j] * (1.0 - bt)) / sch * a.rchat[o + j];
+    a.rho[((size_t)n * Tm + i) * H + j] = r_ctx / stab(a.ctx[r1 + j]);
+    const double rc = (a.rc1[o + j] + r_s) + a.rh1[o + j];
+    const double sc = stab(a.c1t[r1 + j]);
+    const double r_g = (a.i1t[r1 + j] * tanh(a.g1t[r1 + j])) / sc * rc;
+    a.rc1[o + j] = (a.f1t[r1 + j] * a.c1t[r0 + j]) / sc * rc;
+    q[j] = (float)(r_g / stab(a.g1t[r1 + j]));
+  }
+}
+
+__global__ __launch_bounds__(256) void gbx_post_kernel(GbxArgs a, int s) {           // E:1282-1300
+  __shared__ double red[4];
+  const int H = a.H, E = a.E, Tm = a.Tm, S = Tm + 1, K1 = H + 2 * E, Nd1 = K1 + H;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int b = a.img_idx[n], i = a.tpos[n] - 1 - s;
+  if (i < 0) return;
+  const size_t r0 = ((size_t)b * S + i) * H, o = (size_t)n * H;
+  const float* acc = a.acc32 + (size_t)n * Nd1;
+  double wsum = 0.0;
+  for (int d = tid; d < Nd1; d += 256) {
+    const double x = d < K1 ? a.x1t[((size_t)b * Tm + i) * K1 + d] : a.h1t[r0 + d - K1];
+    const double rx = x * (double)acc[d];
+    if (d < H) a.nh2[o + d] += rx;
+    else if (d < H + E) a.rglob[(size_t)n * E + d - H] += rx;
+    else if (d < K1) wsum += rx;
+    else a.nh1[o + d - K1] = rx;
+  }
+  const double ws = block_sum_d(wsum, red);          // (its barriers also order the nh1 / nh2 writes before the copies)
+  if (tid == 0 && a.rwords_out) a.rwords_out[(size_t)n * Tm + i] = ws;
+  for (int j = tid; j < H; j += 256) { a.rh2[o + j] = a.nh2[o + j]; a.rh1[o + j] = a.nh1[o + j]; }
+}
+
+__global__ __launch_bounds__(256) void gbx_tail_kernel(GbxArgs a) {                  // E:1301-1306
+  extern __shared__ double dsm[];
+  double* q = dsm;
+  const int E = a.E, D = a.D;
+  const int n = blockIdx.x, tid = threadIdx.x, b = a.img_idx[n];
+  for (int e = tid; e < E; e += 256) q[e] = a.rglob[(size_t)n * E + e] / stab((double)a.glob_pre[(size_t)b * E + e]);
+  __syncthreads();
+  for (int d = tid; d < D; d += 256) {
+    double s = 0.0;
+    for (int e = 0; e < E; ++e) s += (double)a.WglobT[(size_t)e * D + d] * q[e];
+    a.ravg[(size_t)n * D + d] = (double)a.avg[(size_t)b * D + d] * s;
+  }
+}
+
 }  // namespace lrp
