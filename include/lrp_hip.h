@@ -240,6 +240,12 @@ int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, f
 int lrp_op_avgpool_lrp(const float* x_dev, const float* R_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
                        int32_t C, int32_t k, void* stream);
 
+/* Image preprocessing (models/preprocessors.py:38-53, vgg16 / vgg19 / resnet101 = keras preprocess_input 'caffe'):
+ * rgb_dev (NB, H0, W0, 3) decoded uint8 RGB -> out_dev (NB, H, W, 3) float32: nearest-neighbour resize as PIL does
+ * for load_img(target_size=(H, W)), RGB -> BGR, minus the ImageNet means.  The result feeds lrp_encode_images. */
+int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, int32_t H0, int32_t W0, int32_t H,
+                          int32_t W, void* stream);
+
 /* Score reduction of the LRP-inference layer (models/model.py:1675-1686) for n heat-maps:
  * hp = mean over channels, hp /= max|hp|, then mode 0 = mean, 1 = mean(max(hp,0)), 2 = np.quantile(hp, 0.9).
  * R_img_dev (n, npix, C) float32, scores_dev (n) float64. */

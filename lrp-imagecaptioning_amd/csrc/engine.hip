@@ -379,6 +379,16 @@ int lrp_op_avgpool_lrp(const float* x_dev, const float* R_dev, float* out_dev, i
   return LRP_OK;
 }
 
+int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, int32_t H0, int32_t W0, int32_t H, int32_t W,
+                          void* stream) {
+  if (!rgb_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (NB < 1 || H0 < 1 || W0 < 1 || H < 1 || W < 1) return fail(LRP_ERR_INVALID, "sizes must be positive");
+  hipLaunchKernelGGL(preprocess_caffe_kernel, dim3(stream_grid((size_t)NB * H * W)), dim3(256), 0, S(stream), rgb_dev, out_dev,
+                     NB, H0, W0, H, W);
+  LRP_HIP_CHECK(hipGetLastError());
+  return LRP_OK;
+}
+
 int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, int32_t npix, int32_t C, int32_t mode,
                        void* stream) {
   if (!R_img_dev || !scores_dev) return fail(LRP_ERR_INVALID, "null argument");

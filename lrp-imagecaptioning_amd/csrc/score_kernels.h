@@ -102,4 +102,35 @@ __global__ __launch_bounds__(256) void heatmap_score_kernel(const float* __restr
   if (tid == 0) scores[blockIdx.x] = s / (double)npix;
 }
 
+// Image preprocessing of models/preprocessors.py:38-53 for the caffe-style encoders (vgg16 / vgg19 / resnet101 all use
+// keras `preprocess_input` in 'caffe' mode): decoded RGB bytes (H0, W0, 3) -> nearest-neighbour resize to (H, W) as
+// PIL does for keras `load_img(target_size=...)` (source pixel = floor((o + 0.5) * H0 / H)), RGB -> BGR, minus the
+// ImageNet channel means.  One launch for a batch of equally sized inputs.
+__global__ __launch_bounds__(256) void preprocess_caffe_kernel(const unsigned char* __restrict__ rgb, float* __restrict__ out,
+                                                              int NB, int H0, int W0, int H, int W) {
+  const float mean[3] = {103.939f, 116.779f, 123.68f};                    // B, G, R
+  const size_t total = (size_t)NB * H * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    size_t r = i / W;
+    const int y = (int)(r % H);
+    const int n = (int)(r / H);
+    // PIL's ImagingScaleAffine walks the source coordinate incrementally in double (xo = a0/2; xo += a0 per output
+    // pixel) and truncates; where (o + 0.5) * a0 is an exact integer the accumulated rounding decides the pixel, so the
+    // recurrence is replayed literally (<= 224 additions per axis) rather than evaluated in closed form.
+    const double fy = (double)H0 / (double)H, fx = (double)W0 / (double)W;
+    double yo = fy * 0.5, xo = fx * 0.5;
+    for (int q = 0; q < y; ++q) yo += fy;
+    for (int q = 0; q < x; ++q) xo += fx;
+    int sy = (int)yo, sx = (int)xo;
+    sy = sy < H0 ? sy : H0 - 1;
+    sx = sx < W0 ? sx : W0 - 1;
+    const unsigned char* p = rgb + (((size_t)n * H0 + sy) * W0 + sx) * 3;
+    float* o = out + i * 3;
+    o[0] = (float)p[2] - mean[0];
+    o[1] = (float)p[1] - mean[1];
+    o[2] = (float)p[0] - mean[2];
+  }
+}
+
 }  // namespace lrp

@@ -346,6 +346,20 @@ def op_avgpool_lrp(x, R, k):
     return out
 
 
+def preprocess_images(rgb_u8, size=(224, 224)):
+    """models/preprocessors.py:38-53 on the device: (NB, H0, W0, 3) uint8 RGB tensor -> (NB, H, W, 3) float32 BGR,
+    mean-subtracted, nearest-neighbour resized like keras `load_img(target_size=size)`."""
+    lib = _capi.load()
+    x = rgb_u8.contiguous()
+    if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[-1] != 3:
+        raise ValueError("expected a (NB, H0, W0, 3) uint8 tensor")
+    NB, H0, W0, _ = x.shape
+    out = torch.empty((NB, size[0], size[1], 3), dtype=torch.float32, device=x.device)
+    _capi.check(lib.lrp_preprocess_images(C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), NB, H0, W0, size[0], size[1],
+                                          _cur_stream(x.device)))
+    return out
+
+
 def heatmap_scores(R_img, mode):
     """LRP-inference score per heat-map (model.py:1675-1686) on the device: R_img (n,H,W,C) -> (n,) float64."""
     lib = _capi.load()

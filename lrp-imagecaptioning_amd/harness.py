@@ -32,6 +32,12 @@ class ImagePreprocessor(object):
     def preprocess_batch(self, img_list):
         return np.array(img_list)
 
+    def preprocess_on_device(self, rgb_u8):
+        """The same transformation for a batch of decoded RGB images already on the GPU ((NB, H0, W0, 3) uint8 tensor):
+        lrp_preprocess_images -> (NB, 224, 224, 3) float32 tensor, ready for lrp_encode_images."""
+        from .engine import preprocess_images
+        return preprocess_images(rgb_u8, self.IMAGE_SIZE)
+
 
 class Explainer(object):
     def __init__(self, model, weight_path, explainer, max_caption_length, beam_size):
