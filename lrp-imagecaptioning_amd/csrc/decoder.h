@@ -37,6 +37,12 @@ struct Decoder {
   std::map<std::string, StateBuf> state;
   DevBuf cap_dev;
   std::vector<int> cap_host, len_host;
+  int* cap_pinned = nullptr;       // staging of the captions' H2D copy; ev_cap = that copy (guards reuse without a stream sync)
+  hipEvent_t ev_cap = nullptr;
+  ~Decoder() {
+    if (ev_cap) { (void)hipEventSynchronize(ev_cap); (void)hipEventDestroy(ev_cap); }
+    if (cap_pinned) (void)hipHostFree(cap_pinned);
+  }
   int B_cur = 0;
   bool have_forward = false;
   // explain scratch
@@ -291,12 +297,18 @@ struct Decoder {
           return fail(LRP_ERR_INVALID, "caption %d: token id %d outside [1,%d]", b, caps[b * Tm + i], V);
       Tmax = std::max(Tmax, (int)lens[b]);
     }
-    LRP_HIP_CHECK(hipStreamSynchronize(st));
+    if (!cap_pinned) {
+      LRP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&cap_pinned), (size_t)B_max * Tm * sizeof(int)));
+      LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_cap, hipEventDisableTiming));
+    } else {
+      LRP_HIP_CHECK(hipEventSynchronize(ev_cap));        // (the previous call's copy, long done — not the whole stream)
+    }
     for (int b = 0; b < B; ++b) {
       len_host[b] = lens[b];
-      for (int i = 0; i < Tm; ++i) cap_host[b * Tm + i] = i < lens[b] ? caps[b * Tm + i] : eos;
+      for (int i = 0; i < Tm; ++i) cap_pinned[b * Tm + i] = cap_host[b * Tm + i] = i < lens[b] ? caps[b * Tm + i] : eos;
     }
-    LRP_HIP_CHECK(hipMemcpyAsync(cap_dev.p, cap_host.data(), (size_t)B * Tm * sizeof(int), hipMemcpyHostToDevice, st));
+    LRP_HIP_CHECK(hipMemcpyAsync(cap_dev.p, cap_pinned, (size_t)B * Tm * sizeof(int), hipMemcpyHostToDevice, st));
+    LRP_HIP_CHECK(hipEventRecord(ev_cap, st));
     for (auto& kv : state) LRP_HIP_CHECK(hipMemsetAsync(kv.second.buf.p, 0, kv.second.buf.bytes, st));
     LRP_HIP_CHECK(hipMemsetAsync(u.p, 0, u.bytes, st));
 

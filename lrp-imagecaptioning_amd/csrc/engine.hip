@@ -38,7 +38,9 @@ struct lrp_handle {
   DevBuf idx_dev;          // staged (img_idx | t) for the current explain call
   DevBuf rfeat_tmp;        // R_feat when the caller does not want it back
   int* idx_pinned = nullptr;
+  hipEvent_t ev_idx = nullptr;   // the last H2D copy out of idx_pinned (guards its reuse without a stream sync)
   ~lrp_handle() {
+    if (ev_idx) { (void)hipEventSynchronize(ev_idx); (void)hipEventDestroy(ev_idx); }
     if (idx_pinned) (void)hipHostFree(idx_pinned);
   }
 };
@@ -168,7 +170,11 @@ int lrp_read_state(lrp_handle* h, const char* name, void* out_dev, size_t out_by
 // stage (img_idx | t) into device memory; validates ranges against the cached captions
 static int stage_indices(lrp_handle* h, int n, const int32_t* img_idx, const int32_t* t, bool need_t, hipStream_t st) {
   if (n < 1 || n > h->cfg.max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, h->cfg.max_tokens);
-  LRP_HIP_CHECK(hipStreamSynchronize(st));      // the pinned staging buffer may still be in flight
+  // the pinned staging buffer may still feed the previous call's copy: wait for THAT copy only (no stream sync —
+  // the stream usually holds the decoder replay at this point, and draining it would leave the GPU idle while the
+  // host enqueues the explain launches)
+  if (!h->ev_idx) LRP_HIP_CHECK(hipEventCreateWithFlags(&h->ev_idx, hipEventDisableTiming));
+  else LRP_HIP_CHECK(hipEventSynchronize(h->ev_idx));
   for (int i = 0; i < n; ++i) {
     if (img_idx[i] < 0 || img_idx[i] >= h->encoded())
       return fail(LRP_ERR_INVALID, "img_idx[%d]=%d outside the %d cached images", i, img_idx[i], h->encoded());
@@ -179,6 +185,7 @@ static int stage_indices(lrp_handle* h, int n, const int32_t* img_idx, const int
     }
   }
   LRP_HIP_CHECK(hipMemcpyAsync(h->idx_dev.p, h->idx_pinned, (size_t)n * (need_t ? 2 : 1) * sizeof(int), hipMemcpyHostToDevice, st));
+  LRP_HIP_CHECK(hipEventRecord(h->ev_idx, st));
   return LRP_OK;
 }
 
