@@ -163,6 +163,19 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
                        const int32_t* t_host, int32_t variant, float* R_img_dev,
                        float* R_feat_dev, float* att_dev, double* r_words_dev, void* stream);
 
+/* ---- caption generation: incremental decoding for the beam search of explainers.py:51-120.
+ * The reference re-runs the whole captioner on every partial caption at every search step; here the hypotheses'
+ * decoder state lives on the device and a search step is ONE decoder step for all of them.  The beam bookkeeping
+ * (BatchNLargest, completion rule) stays with the caller.
+ * lrp_decoder_gen_begin: B rows = image slots of the cached features (for a beam of k per image, cache every image's
+ *   features k times with lrp_set_features); zeroes the state.  Invalidates a previous lrp_decoder_forward.
+ * lrp_decoder_gen_step: step s = 0 feeds SOS; for s > 0 row r continues the hypothesis of row parent_host[r] with
+ *   tokenizer id word_host[r] appended.  logits_dev (B, V) float64 = the model's un-normalised scores for position s
+ *   (column k = tokenizer id k+1), i.e. row s of `caption_preds`. */
+int lrp_decoder_gen_begin(lrp_handle* h, int32_t B, void* stream);
+int lrp_decoder_gen_step(lrp_handle* h, int32_t B, const int32_t* parent_host, const int32_t* word_host, int32_t step,
+                         double* logits_dev, void* stream);
+
 /* ---- gradient baselines on the same caches -------------------------------------------------
  * lrp_decoder_gradient == ExplainImgCaptioning{AdaptiveAttention,GridTD}Gradient._lstm_decoder_backward(t)
  * (models/explainers.py:780-832, :1452-1532) for n (image, t) units at once: d_feat_dev (n, L, D) float32 =

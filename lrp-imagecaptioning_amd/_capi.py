@@ -54,6 +54,8 @@ SYMBOLS = {
     "lrp_op_epsilon_dense": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "lrp_op_batchnorm_lrp": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, _P, _P, C.c_int64, C.c_int32, _P]),
     "lrp_op_add_lrp": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
+    "lrp_decoder_gen_begin": (C.c_int, [_P, C.c_int32, _P]),
+    "lrp_decoder_gen_step": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
     "lrp_decoder_gradient": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "lrp_cnn_walk": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
     "lrp_op_avgpool_lrp": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -42,6 +42,8 @@ struct Decoder {
   ~Decoder() {
     if (ev_cap) { (void)hipEventSynchronize(ev_cap); (void)hipEventDestroy(ev_cap); }
     if (cap_pinned) (void)hipHostFree(cap_pinned);
+    if (ev_gen) { (void)hipEventSynchronize(ev_gen); (void)hipEventDestroy(ev_gen); }
+    if (gen_pinned) (void)hipHostFree(gen_pinned);
   }
   int B_cur = 0;
   bool have_forward = false;
@@ -309,10 +311,22 @@ struct Decoder {
     }
     LRP_HIP_CHECK(hipMemcpyAsync(cap_dev.p, cap_pinned, (size_t)B * Tm * sizeof(int), hipMemcpyHostToDevice, st));
     LRP_HIP_CHECK(hipEventRecord(ev_cap, st));
+    LRP_TRY(prepare_static(feat_dev, B, st));
+    if (kind == LRP_DEC_GRIDTD) return forward_gridtd_steps(B, Tmax, st);
+    for (int i = 0; i < Tmax; ++i) LRP_TRY(step_adaptive(i, B, st));
+    // ---- output layer for every step at once (E:421-422), float64 like the reference
+    LRP_HIP_CHECK((skinny<double, double, double>(u.as<double>(), H, Wout.as<float>(), V, bout.as<float>(),
+                                                  S_<double>("caption_preds"), V, B * Tm, H, V, 0, st)));
+    B_cur = B;
+    have_forward = true;
+    return LRP_OK;
+  }
+
+  // zeroed state + the per-image static part (E:375-388): relu(F W_if + b), its projection, mean feature, global feature
+  int prepare_static(const float* feat_dev, int B, hipStream_t st) {
     for (auto& kv : state) LRP_HIP_CHECK(hipMemsetAsync(kv.second.buf.p, 0, kv.second.buf.bytes, st));
     LRP_HIP_CHECK(hipMemsetAsync(u.p, 0, u.bytes, st));
-
-    // ---- static image part (E:375-388)
+    if (kind == LRP_DEC_GRIDTD) LRP_HIP_CHECK(hipMemsetAsync(h2u.p, 0, h2u.bytes, st));
     {
       ConvArgs ca{};
       ca.in = feat_dev; ca.NB = B * L; ca.H = 1; ca.W = 1; ca.Cin = D; ca.CinP = conv_cinp(D); ca.taps = 1;
@@ -334,12 +348,15 @@ struct Decoder {
     LRP_HIP_CHECK(hipGetLastError());
     LRP_HIP_CHECK((skinny<float, float, float>(avg.as<float>(), D, Wglob.as<float>(), E, bglob.as<float>(),
                                                glob_pre.as<float>(), E, B, D, E, 0, st)));
-    if (kind == LRP_DEC_GRIDTD) return forward_gridtd_steps(B, Tmax, st);
-    // ---- step loop (E:399-436)
+    return LRP_OK;
+  }
+
+  // one decoder step i for B rows (E:399-420): LSTM, attention / sentinel, u[b][i] = h + c_hat
+  int step_adaptive(int i, int B, hipStream_t st) {
     const int S = Tm + 1, Kd = 2 * E + H;
     float* ht = S_<float>("ht");
     float* stt = S_<float>("st");
-    for (int i = 0; i < Tmax; ++i) {
+    {
       hipLaunchKernelGGL(dec_prep_x_kernel, dim3(B), dim3(256), 0, st, emb.as<float>(), glob_pre.as<float>(), ht,
                          cap_dev.as<int>(), xh.as<float>(), S_<float>("xt"), i, Tm, E, H, V, sos);
       LRP_HIP_CHECK(hipGetLastError());
@@ -363,20 +380,84 @@ struct Decoder {
                          S_<double>("context"), S_<double>("c_hat"), u.as<double>(), i, Tm, L, H);
       LRP_HIP_CHECK(hipGetLastError());
     }
-    // ---- output layer for every step at once (E:421-422), float64 like the reference
-    LRP_HIP_CHECK((skinny<double, double, double>(u.as<double>(), H, Wout.as<float>(), V, bout.as<float>(),
-                                                  S_<double>("caption_preds"), V, B * Tm, H, V, 0, st)));
+    return LRP_OK;
+  }
+
+  // ---- incremental decoding for caption generation: the beam bookkeeping of E:51-120 stays on the host, each search
+  // step costs ONE decoder step for all live hypotheses (the reference re-runs the whole captioner per step)
+  DevBuf gen_tmp, gen_idx;
+  int* gen_pinned = nullptr;
+  hipEvent_t ev_gen = nullptr;
+  int gen_rows = 0;
+  int gen_begin(const float* feat_dev, int B, hipStream_t st) {
+    int64_t dummy = 0;
+    LRP_TRY(finalize(&dummy));
+    if (B < 1 || B > B_max) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, B_max);
+    if (!gen_pinned) {
+      LRP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&gen_pinned), (size_t)B_max * 2 * sizeof(int)));
+      LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_gen, hipEventDisableTiming));
+      LRP_TRY(gen_idx.alloc((size_t)B_max * 2 * sizeof(int), &dummy));
+      LRP_TRY(gen_tmp.alloc((size_t)B_max * H * 8, &dummy));
+    }
+    LRP_HIP_CHECK(hipMemsetAsync(cap_dev.p, 0, cap_dev.bytes, st));
+    LRP_TRY(prepare_static(feat_dev, B, st));
+    have_forward = false;               // the cached state is a search scratch, not a caption replay
     B_cur = B;
-    have_forward = true;
+    gen_rows = B;
+    return LRP_OK;
+  }
+  template <typename T>
+  int gen_reparent(const char* name, int B, int step, hipStream_t st) {
+    T* arr = S_<T>(name);
+    hipLaunchKernelGGL(gen_gather_kernel<T>, dim3(B), dim3(256), 0, st, arr, gen_tmp.as<T>(), gen_idx.as<int>(), step, Tm + 1, H);
+    hipLaunchKernelGGL(gen_scatter_kernel<T>, dim3(B), dim3(256), 0, st, arr, gen_tmp.as<T>(), step, Tm + 1, H);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+  // step s: row r continues row parent[r] with tokenizer id word[r] appended (ignored at s = 0: SOS); logits (B, V) float64
+  int gen_step(int B, const int32_t* parent_host, const int32_t* word_host, int s, double* logits_dev, hipStream_t st) {
+    if (gen_rows < 1 || have_forward) return fail(LRP_ERR_STATE, "lrp_decoder_gen_begin must run first");
+    if (B != gen_rows) return fail(LRP_ERR_INVALID, "B=%d but the search was begun with %d rows", B, gen_rows);
+    if (s < 0 || s >= Tm) return fail(LRP_ERR_RANGE, "step %d outside [0,%d)", s, Tm);
+    if (s > 0) {
+      LRP_HIP_CHECK(hipEventSynchronize(ev_gen));
+      for (int r = 0; r < B; ++r) {
+        if (parent_host[r] < 0 || parent_host[r] >= B) return fail(LRP_ERR_INVALID, "parent[%d]=%d outside [0,%d)", r, parent_host[r], B);
+        if (word_host[r] < 1 || word_host[r] > V) return fail(LRP_ERR_INVALID, "word[%d]=%d outside [1,%d]", r, word_host[r], V);
+        gen_pinned[r] = parent_host[r];
+        gen_pinned[B + r] = word_host[r];
+      }
+      LRP_HIP_CHECK(hipMemcpyAsync(gen_idx.p, gen_pinned, (size_t)2 * B * sizeof(int), hipMemcpyHostToDevice, st));
+      LRP_HIP_CHECK(hipEventRecord(ev_gen, st));
+      if (kind == LRP_DEC_ADAPTIVE) {
+        LRP_TRY(gen_reparent<float>("ht", B, s, st));
+        LRP_TRY(gen_reparent<float>("ct", B, s, st));
+      } else {
+        for (const char* nm : {"h1t", "c1t", "h2t", "c2t"}) LRP_TRY(gen_reparent<double>(nm, B, s, st));
+      }
+      hipLaunchKernelGGL(gen_set_word_kernel, dim3((B + 255) / 256), dim3(256), 0, st, cap_dev.as<int>(), gen_idx.as<int>() + B, s, Tm, B);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    LRP_TRY(kind == LRP_DEC_ADAPTIVE ? step_adaptive(s, B, st) : step_gridtd(s, B, st));
+    const double* rows = (kind == LRP_DEC_ADAPTIVE ? u.as<double>() : h2u.as<double>()) + (size_t)s * H;
+    LRP_HIP_CHECK((skinny<double, double, double>(rows, Tm * H, Wout.as<float>(), V, bout.as<float>(), logits_dev, V, B, H, V, 0, st)));
     return LRP_OK;
   }
 
   // grid-TD step loop (E:1126-1176): top-down LSTM -> attention/sentinel on h1 -> language LSTM
   int forward_gridtd_steps(int B, int Tmax, hipStream_t st) {
+    for (int i = 0; i < Tmax; ++i) LRP_TRY(step_gridtd(i, B, st));
+    // logits from h2 alone (E:1154 — the reference quirk), every step at once
+    LRP_HIP_CHECK((skinny<double, double, double>(h2u.as<double>(), H, Wout.as<float>(), V, bout.as<float>(),
+                                                  S_<double>("caption_preds"), V, B * Tm, H, V, 0, st)));
+    B_cur = B;
+    have_forward = true;
+    return LRP_OK;
+  }
+  int step_gridtd(int i, int B, hipStream_t st) {
     const int S = Tm + 1, K1 = H + 2 * E;
-    LRP_HIP_CHECK(hipMemsetAsync(h2u.p, 0, h2u.bytes, st));
     double *h1 = S_<double>("h1t"), *h2 = S_<double>("h2t"), *stt = S_<double>("st");
-    for (int i = 0; i < Tmax; ++i) {
+    {
       hipLaunchKernelGGL(gtd_prep_x1_kernel, dim3(B), dim3(256), 0, st, emb.as<float>(), glob_pre.as<float>(), h1, h2,
                          cap_dev.as<int>(), xh1d.as<double>(), S_<double>("x1t"), i, Tm, E, H, V, sos);
       LRP_HIP_CHECK(hipGetLastError());
@@ -404,11 +485,6 @@ struct Decoder {
                          h2u.as<double>(), S_<double>("o2t_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
     }
-    // logits from h2 alone (E:1154 — the reference quirk), every step at once
-    LRP_HIP_CHECK((skinny<double, double, double>(h2u.as<double>(), H, Wout.as<float>(), V, bout.as<float>(),
-                                                  S_<double>("caption_preds"), V, B * Tm, H, V, 0, st)));
-    B_cur = B;
-    have_forward = true;
     return LRP_OK;
   }
 

@@ -80,6 +80,24 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__
   }
 }
 
+// Caption generation (beam search) re-parents hypotheses between steps: row r continues the hypothesis that lived in
+// row parent[r].  Two phases (all reads, then all writes) so that a row may be both a source and a destination.
+template <typename T>
+__global__ __launch_bounds__(256) void gen_gather_kernel(const T* __restrict__ arr, T* __restrict__ tmp,
+                                                         const int* __restrict__ parent, int step, int S, int H) {
+  const int r = blockIdx.x;
+  for (int j = threadIdx.x; j < H; j += 256) tmp[(size_t)r * H + j] = arr[((size_t)parent[r] * S + step) * H + j];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gen_scatter_kernel(T* __restrict__ arr, const T* __restrict__ tmp, int step, int S, int H) {
+  const int r = blockIdx.x;
+  for (int j = threadIdx.x; j < H; j += 256) arr[((size_t)r * S + step) * H + j] = tmp[(size_t)r * H + j];
+}
+__global__ void gen_set_word_kernel(int* __restrict__ cap, const int* __restrict__ word, int step, int Tm, int B) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < B) cap[(size_t)r * Tm + step - 1] = word[r];
+}
+
 // ipre = 1 / stab(if_pre): the denominator of the image_features rule (E:654-659), once per image
 __global__ __launch_bounds__(256) void dec_ipre_kernel(const float* __restrict__ if_pre, double* __restrict__ ipre, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)

@@ -162,6 +162,18 @@ int lrp_decoder_forward(lrp_handle* h, const int32_t* captions_host, const int32
   return h->dec.forward(h->feat(), captions_host, lengths_host, B, S(stream));
 }
 
+int lrp_decoder_gen_begin(lrp_handle* h, int32_t B, void* stream) {
+  if (!h) return fail(LRP_ERR_INVALID, "null handle");
+  if (B < 1 || B > h->encoded()) return fail(LRP_ERR_STATE, "B=%d but %d images have features cached", B, h->encoded());
+  return h->dec.gen_begin(h->feat(), B, S(stream));
+}
+
+int lrp_decoder_gen_step(lrp_handle* h, int32_t B, const int32_t* parent_host, const int32_t* word_host, int32_t step,
+                         double* logits_dev, void* stream) {
+  if (!h || !logits_dev || (step > 0 && (!parent_host || !word_host))) return fail(LRP_ERR_INVALID, "null argument");
+  return h->dec.gen_step(B, parent_host, word_host, step, logits_dev, S(stream));
+}
+
 int lrp_read_state(lrp_handle* h, const char* name, void* out_dev, size_t out_bytes, void* stream) {
   if (!h || !name || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
   return h->dec.read_state(name, out_dev, out_bytes, S(stream));

@@ -200,6 +200,25 @@ class LRPEngine(object):
                                               self._stream()))
         return out
 
+    # ------------------------------------------------------------------ caption generation
+    def gen_begin(self, n_rows):
+        """Start an incremental decode over the first n_rows cached feature slots (one hypothesis per row)."""
+        _capi.check(self._lib.lrp_decoder_gen_begin(self._h, int(n_rows), self._stream()))
+        self._gen_rows = int(n_rows)
+
+    def gen_step(self, step, parent=None, word=None):
+        """One decoder step for every row; row r continues row parent[r] with tokenizer id word[r] appended
+        (step 0: SOS).  Returns the (n_rows, V) float64 logits of position `step` on the device."""
+        n = self._gen_rows
+        out = torch.empty((n, self.V), dtype=torch.float64, device=self.device)
+        if step > 0:
+            pp, ppi = _i32(parent)
+            ww, wwi = _i32(word)
+        else:
+            ppi = wwi = None
+        _capi.check(self._lib.lrp_decoder_gen_step(self._h, n, ppi, wwi, int(step), C.c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     # ------------------------------------------------------------------ gradient baselines (SURVEY 8f-3)
     WALKS = {"lrp": 0, "gradient": 1, "input_x_gradient": 2, "guided_backprop": 3}
 

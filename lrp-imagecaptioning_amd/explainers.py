@@ -181,9 +181,64 @@ class ExplainImgCaptioningAttentionModel(object):
         return out, pairs, att, rw, R
 
     def _beam_search(self, X, beam_size=3):
-        """Caption generation (E:51-120) on top of the teacher-forced decoder replay: step s
-        re-plays the current beams and reads the logits of position s.  Upstream of the LRP
-        path (captions are an input to it); provided so harnesses run end to end."""
+        """Caption generation (E:51-120).  Upstream of the LRP path (captions are an input to it); provided so harnesses
+        run end to end.  The hypotheses' decoder state stays on the device (lrp_decoder_gen_begin / _gen_step): one
+        decoder step per search step for all beams, where the reference re-runs the whole captioner on every partial
+        caption (E:71).  Beam bookkeeping as in `_beam_search_replay`."""
+        _, imgs_input = X
+        imgs_input = np.asarray(imgs_input, dtype=np.float32)
+        EOS = self._preprocessor.EOS_TOKEN_LABEL_ENCODED
+        eng = self._engine
+        if beam_size > eng.max_images:
+            return self._beam_search_replay(X, beam_size)          # not enough feature slots for one row per beam
+        results = []
+        for img in imgs_input:
+            eng.encode_images(img[None])
+            feat = eng.get_features()[:1]
+            eng.set_features(feat.expand(beam_size, -1, -1).contiguous())      # one row (feature slot) per beam
+            eng.gen_begin(beam_size)
+            beams = [([], 0.0)]                  # (word ids so far, log prob); beam k lives in row k
+            rows = [0]
+            complete = []
+            for s in range(self._max_caption_length):
+                if s == 0:
+                    logits = eng.gen_step(0)
+                else:
+                    parent = rows + [rows[0]] * (beam_size - len(rows))
+                    word = [b[0][-1] for b in beams] + [beams[0][0][-1]] * (beam_size - len(beams))
+                    logits = eng.gen_step(s, parent, word)
+                logits = logits.cpu().numpy()
+                cand = []
+                for r, (words, lp) in enumerate(beams):
+                    lg = logits[r]
+                    logp = lg - lg.max()
+                    logp = logp - np.log(np.exp(logp).sum())
+                    top = np.argpartition(logp, -beam_size)[-beam_size:]
+                    for k in top:
+                        w = int(k) + 1                      # model column -> tokenizer id (E:92)
+                        if w == EOS:
+                            complete.append((words, lp + float(logp[k])))
+                        cand.append((words + [w], lp + float(logp[k]), r))
+                cand.sort(key=lambda c: -c[1])
+                keep = [c for c in cand if c[0][-1] != EOS][:beam_size] or cand[:beam_size]
+                beams = [(c[0], c[1]) for c in keep]
+                rows = [c[2] for c in keep]
+            complete.sort(key=lambda c: -c[1])
+            beams.sort(key=lambda c: -c[1])
+            out = []
+            for i in range(beam_size):
+                if i < len(complete):
+                    out.append(complete[i][0] + [EOS])
+                elif i < len(beams):
+                    out.append(beams[i][0] + [EOS])
+            results.append(out)
+        self.caption = None
+        self._state_cache = {}
+        return results[0] if len(results) == 1 else results
+
+    def _beam_search_replay(self, X, beam_size=3):
+        """The same search on top of the teacher-forced decoder replay (every step re-plays the current beams from
+        scratch, like the reference's predict_on_batch loop): kept as the cross-check of `_beam_search`."""
         _, imgs_input = X
         imgs_input = np.asarray(imgs_input, dtype=np.float32)
         EOS, SOS = self._preprocessor.EOS_TOKEN_LABEL_ENCODED, self._preprocessor.SOS_TOKEN_LABEL_ENCODED

@@ -229,3 +229,44 @@ def test_lrp_inference_layer_gridtd():
     w2, _ = _weights(8)
     with pytest.raises(ValueError):
         LRPInferenceLayergridTD(ExplainImgCaptioningAdaptiveAttention(_spec(w2), None, None, max_caption_length=T), "mean")
+
+
+@pytest.mark.parametrize("kind", ["adaptive", "gridtd"])
+def test_incremental_beam_search_equals_replay(kind):
+    """lrp_decoder_gen_begin / _gen_step (one decoder step per search step, state re-parented on the device) against
+    the replay-based search (every step re-runs the partial captions, like the reference's predict_on_batch loop), and
+    beam 1 against greedy decoding on the oracle's forward."""
+    import lrp_imagecaptioning_amd.explainers as EX
+    from lrp_imagecaptioning_amd.synthetic import gridtd_weights
+    from oracle.decoder_ref import AdaptiveOracle, GridTDOracle
+    rs = np.random.RandomState(21)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    if kind == "adaptive":
+        from lrp_imagecaptioning_amd.synthetic import adaptive_weights
+        w.update(adaptive_weights(rs, L, D, H, H, V))
+        cls, orc = EX.ExplainImgCaptioningAdaptiveAttention, AdaptiveOracle
+    else:
+        w.update(gridtd_weights(rs, L, D, H, H, V))
+        cls, orc = EX.ExplainImgCaptioningGridTDModel, GridTDOracle
+    spec = EX.CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V, cnn_cfg=CFG,
+                               img_hw=(HW, HW))
+    X = rs.uniform(-120, 130, size=(2, HW, HW, 3)).astype(np.float32)
+    ex = cls(spec, None, None, max_caption_length=7, max_images=4)
+    for b in range(2):
+        for beam in (1, 3, 4):
+            got = ex._beam_search((None, X[b:b + 1]), beam_size=beam)
+            want = ex._beam_search_replay((None, X[b:b + 1]), beam_size=beam)
+            assert got == want, (kind, b, beam, got, want)
+        # greedy: feed the arg-max word back, on the float64/float32 oracle
+        layers = C.vgg_layers(w, CFG)
+        feat = C.forward(layers, X[b:b + 1]).astype(np.float32)
+        words = []
+        for s in range(7):
+            o = orc(w, L, D, H, H)
+            o.forward(feat, words + [1])
+            nxt = int(np.argmax(o.caption_preds[s])) + 1
+            if nxt == 1:
+                break
+            words.append(nxt)
+        g1 = ex._beam_search((None, X[b:b + 1]), beam_size=1)[0]
+        assert g1[:len(words)] == words[:len(g1) - 1] or g1 == words + [1], (g1, words)
