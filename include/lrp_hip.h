@@ -170,7 +170,8 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
  * lrp_decoder_gen_begin: B rows = image slots of the cached features (for a beam of k per image, cache every image's
  *   features k times with lrp_set_features); zeroes the state.  Invalidates a previous lrp_decoder_forward.
  * lrp_decoder_gen_step: step s = 0 feeds SOS; for s > 0 row r continues the hypothesis of row parent_host[r] with
- *   tokenizer id word_host[r] appended.  logits_dev (B, V) float64 = the model's un-normalised scores for position s
+ *   tokenizer id word_host[r] appended (parent and child must be rows of the same image: only the recurrent state is
+ *   re-parented, a row keeps its image's features).  logits_dev (B, V) float64 = the model's un-normalised scores for position s
  *   (column k = tokenizer id k+1), i.e. row s of `caption_preds`. */
 int lrp_decoder_gen_begin(lrp_handle* h, int32_t B, void* stream);
 int lrp_decoder_gen_step(lrp_handle* h, int32_t B, const int32_t* parent_host, const int32_t* word_host, int32_t step,

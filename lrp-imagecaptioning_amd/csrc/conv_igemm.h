@@ -1,10 +1,13 @@
-// conv_igemm.h — fp32 MFMA implicit-GEMM 3x3/1x1 convolution for gfx950 with
-// the LRP epilogues fused.  This one kernel family carries >95 % of the FLOPs
-// of the hot path:
-//   * encoder forward + Z+ pass           (EPI_FWD_DUAL)  — per image, cached
-//   * conv-LRP alpha1beta0 backward       (EPI_MUL / EPI_MUL_UP2 / EPI_STORE) — per token
+// conv_igemm.h — MFMA implicit-GEMM 3x3/1x1 convolution for gfx950 with the LRP epilogues fused.  This one kernel
+// family carries >95 % of the FLOPs of the hot path:
+//   * encoder forward: activation chain (EPI_BIAS / EPI_BIAS_RELU, three-way split operands, TERMS 15 + 3) and
+//     denominators Z+ (EPI_BIAS, TERMS 7); exact-fp32 variants (EPI_FWD_DUAL)             — per image, cached
+//   * conv-LRP alpha1beta0 backward (EPI_MUL / EPI_MUL_UP2 / EPI_IMG_STENCIL)              — per token
 //     RR:274-322 restructured: S_{l-1} = up2?(convT(S_l, w_l+)) * G_{l-1}
-//   * dense layers of the decoder prologue (taps = 1)
+//   * every dense product of the decoder LRP / gradient paths (taps = 1, EPI_STORE / EPI_MUL)
+// Template axes: tile (WM, WN, TM, TN), epilogue EPI, operand arithmetic PREC (exact fp32 MFMA | split-bf16),
+// HALO (3x3: A tile + halo resident in LDS for all 9 taps), BREG (N <= 64: weights in registers, no barrier per tap),
+// TERMS (which partial products of the split operands are issued).  DESIGN.md 4.1 has the measurements behind each.
 //
 // GEMM view: D[m][n] = sum_k A[m][k] * B[k][n],  m = output pixel (NHWC row),
 // n = output channel, k = (tap, input channel).  A is gathered on the fly

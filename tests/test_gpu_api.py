@@ -270,3 +270,41 @@ def test_incremental_beam_search_equals_replay(kind):
             words.append(nxt)
         g1 = ex._beam_search((None, X[b:b + 1]), beam_size=1)[0]
         assert g1[:len(words)] == words[:len(g1) - 1] or g1 == words + [1], (g1, words)
+
+
+def test_generation_api_errors():
+    """State / argument errors of the incremental decoding entry points."""
+    from lrp_imagecaptioning_amd.explainers import ExplainImgCaptioningAdaptiveAttention
+    w, rs = _weights(5)
+    ex = ExplainImgCaptioningAdaptiveAttention(_spec(w), None, None, max_caption_length=4, max_images=2)
+    eng = ex._engine
+    X = rs.uniform(-120, 130, size=(2, HW, HW, 3)).astype(np.float32)
+    eng.encode_images(X)
+    eng._gen_rows = 2
+    with pytest.raises(RuntimeError):
+        eng.gen_step(0)                                   # gen_begin has not run
+    eng.gen_begin(2)
+    lg = eng.gen_step(0)
+    assert tuple(lg.shape) == (2, V) and np.isfinite(lg.cpu().numpy()).all()
+    with pytest.raises(ValueError):
+        eng.gen_step(1, [0, 5], [3, 3])                   # parent row out of range
+    with pytest.raises(ValueError):
+        eng.gen_step(1, [0, 1], [3, V + 1])               # word id out of range
+    with pytest.raises(NotImplementedError):
+        eng.gen_step(99, [0, 1], [3, 3])                  # step beyond max_caption_len (LRP_ERR_RANGE)
+    with pytest.raises(RuntimeError):
+        eng.decoder_explain([0], [1])                     # a search scratch is not a caption replay
+    # re-parenting: both rows carry the SAME image (rows of one search share the features of their image); after
+    # different first words their states differ, and swapping the parents swaps the logits of the next step
+    feat = eng.get_features()[:1]
+    eng.set_features(feat.expand(2, -1, -1).contiguous())
+
+    def two_steps(parents):
+        eng.gen_begin(2)
+        eng.gen_step(0)
+        eng.gen_step(1, [0, 1], [7, 9])
+        return eng.gen_step(2, parents, [4, 4]).cpu().numpy()
+    a, b = two_steps([0, 1]), two_steps([1, 0])
+    assert np.abs(a[0] - a[1]).max() > 1e-6
+    np.testing.assert_allclose(a[0], b[1], rtol=1e-12)
+    np.testing.assert_allclose(a[1], b[0], rtol=1e-12)
