@@ -22,11 +22,19 @@ def build_library(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # build into a private file and rename: several ranks of one job may get here at once, and a reader must never see
+    # a half-written library
+    tmp = "%s.%d.tmp" % (LIB, os.getpid())
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB] + os.environ.get("LRP_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
+           "-o", tmp] + os.environ.get("LRP_HIPCC_FLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
-        print("[build]", " ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print("[build]", " ".join(cmd).replace(tmp, LIB), file=sys.stderr)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 
