@@ -254,6 +254,14 @@ int lrp_op_add_lrp(const float* a_dev, const float* b_dev, const float* R_dev, f
 int lrp_op_avgpool_lrp(const float* x_dev, const float* R_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
                        int32_t C, int32_t k, void* stream);
 
+/* Heat-map rendering of explain_image.py:55-60 (`heatmap(postprocess(relevance))`, innvestigate/examples/
+ * utils_imagenet.py:31-33 -> utils/visualizations.py:87-125, :57-80): per heat-map sign-preserving gamma correction
+ * (0.95 in the reference), channel sum, abs-max projection to 0..255 and a 256 x 3 colormap lookup (lut_dev, the
+ * reference uses matplotlib's 'seismic').  R_img_dev (n, npix, C) -> rgb_dev (n, npix, 3) float32.  An all-zero map
+ * (0/0 and an undefined NaN->int cast in the reference) renders as the mid-scale colour. */
+int lrp_heatmap_render(const float* R_img_dev, const float* lut_dev, float* rgb_dev, int32_t n, int32_t npix, int32_t C,
+                       float gamma, void* stream);
+
 /* Image preprocessing (models/preprocessors.py:38-53, vgg16 / vgg19 / resnet101 = keras preprocess_input 'caffe'):
  * rgb_dev (NB, H0, W0, 3) decoded uint8 RGB -> out_dev (NB, H, W, 3) float32: nearest-neighbour resize as PIL does
  * for load_img(target_size=(H, W)), RGB -> BGR, minus the ImageNet means.  The result feeds lrp_encode_images. */

@@ -59,6 +59,7 @@ SYMBOLS = {
     "lrp_decoder_gradient": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "lrp_cnn_walk": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
     "lrp_op_avgpool_lrp": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "lrp_heatmap_render": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),
     "lrp_preprocess_images": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "lrp_heatmap_scores": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "lrp_last_error": (C.c_char_p, []),

@@ -398,6 +398,15 @@ int lrp_op_avgpool_lrp(const float* x_dev, const float* R_dev, float* out_dev, i
   return LRP_OK;
 }
 
+int lrp_heatmap_render(const float* R_img_dev, const float* lut_dev, float* rgb_dev, int32_t n, int32_t npix, int32_t C,
+                       float gamma, void* stream) {
+  if (!R_img_dev || !lut_dev || !rgb_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (n < 1 || npix < 1 || C < 1 || !(gamma > 0.f)) return fail(LRP_ERR_INVALID, "n, npix, C, gamma must be positive");
+  hipLaunchKernelGGL(heatmap_render_kernel, dim3(n), dim3(256), 0, S(stream), R_img_dev, lut_dev, rgb_dev, npix, C, gamma);
+  LRP_HIP_CHECK(hipGetLastError());
+  return LRP_OK;
+}
+
 int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, int32_t H0, int32_t W0, int32_t H, int32_t W,
                           void* stream) {
   if (!rgb_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");

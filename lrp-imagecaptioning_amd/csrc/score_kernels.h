@@ -102,6 +102,54 @@ __global__ __launch_bounds__(256) void heatmap_score_kernel(const float* __restr
   if (tid == 0) scores[blockIdx.x] = s / (double)npix;
 }
 
+// Heat-map rendering of the explanation harness (innvestigate/examples/utils_imagenet.py:31-33 ->
+// utils/visualizations.py:87-125, :57-80, :36-54): per heat-map
+//   Y = sign(x) (|x| / max|x|)^gamma max|x|   (gamma = 0.95, float32 like numpy on a float32 array)
+//   t = sum_c Y;  idx = int( clip((t / max|t| + 1) / 2, 0, 1) * 255 )   (float64, truncation like astype(int))
+//   rgb = lut[idx]                              (the 256-entry colormap table, 'seismic' in the reference)
+// One workgroup per heat-map, three passes over its 600 KB (L2 resident after the first).
+__global__ __launch_bounds__(256) void heatmap_render_kernel(const float* __restrict__ Rall, const float* __restrict__ lut,
+                                                             float* __restrict__ out, int npix, int C, float gam) {
+  __shared__ float fred[4];
+  __shared__ float bc;
+  const float* R = Rall + (size_t)blockIdx.x * npix * C;
+  float* o = out + (size_t)blockIdx.x * npix * 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto block_max = [&](float v) {
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) fred[wave] = v;
+    __syncthreads();
+    if (tid == 0) bc = fmaxf(fmaxf(fred[0], fred[1]), fmaxf(fred[2], fred[3]));
+    __syncthreads();
+    return bc;
+  };
+  float mx = 0.f;
+  for (int i = tid; i < npix * C; i += 256) mx = fmaxf(mx, fabsf(R[i]));
+  const float maxamp = block_max(mx);
+  auto tsum = [&](int p) {
+    float t = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float x = R[(size_t)p * C + c] / maxamp;
+      const float y = x >= 0.f ? powf(x, gam) : -powf(-x, gam);
+      t += y * maxamp;
+    }
+    return t;
+  };
+  float mt = 0.f;
+  if (maxamp > 0.f)
+    for (int p = tid; p < npix; p += 256) mt = fmaxf(mt, fabsf(tsum(p)));
+  const float absmax = block_max(mt);
+  for (int p = tid; p < npix; p += 256) {
+    double v = maxamp > 0.f ? (double)tsum(p) : 0.0;
+    if (absmax != 0.f) v /= (double)absmax;
+    v = (v + 1.0) / 2.0;
+    v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    const int idx = (int)(v * 255.0);
+    o[(size_t)p * 3] = lut[idx * 3]; o[(size_t)p * 3 + 1] = lut[idx * 3 + 1]; o[(size_t)p * 3 + 2] = lut[idx * 3 + 2];
+  }
+}
+
 // Image preprocessing of models/preprocessors.py:38-53 for the caffe-style encoders (vgg16 / vgg19 / resnet101 all use
 // keras `preprocess_input` in 'caffe' mode): decoded RGB bytes (H0, W0, 3) -> nearest-neighbour resize to (H, W) as
 // PIL does for keras `load_img(target_size=...)` (source pixel = floor((o + 0.5) * H0 / H)), RGB -> BGR, minus the

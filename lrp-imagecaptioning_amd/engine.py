@@ -365,6 +365,27 @@ def op_avgpool_lrp(x, R, k):
     return out
 
 
+_LUT_CACHE = {}
+
+
+def heatmap_render(R_img, gamma=0.95, color_conversion=None):
+    """`heatmap(postprocess(relevance, color_conversion))` of the harness (explain_image.py:55-60) on the device:
+    R_img (n, H, W, 3) relevance tensor -> (n, H, W, 3) float32 RGB in [0, 1] (seismic colormap)."""
+    from .postprocess import _seismic
+    lib = _capi.load()
+    R = R_img.contiguous()
+    if color_conversion in ("RGBtoBGR", "BGRtoRGB"):
+        R = R.flip(-1).contiguous()              # (the channel sum does not care, the gamma maximum neither)
+    n, Hh, Ww, Cc = R.shape
+    key = str(R.device)
+    if key not in _LUT_CACHE:
+        _LUT_CACHE[key] = torch.as_tensor(np.ascontiguousarray(_seismic(np.arange(256)), dtype=np.float32)).to(R.device)
+    out = torch.empty((n, Hh, Ww, 3), dtype=torch.float32, device=R.device)
+    _capi.check(lib.lrp_heatmap_render(C.c_void_p(R.data_ptr()), C.c_void_p(_LUT_CACHE[key].data_ptr()),
+                                       C.c_void_p(out.data_ptr()), n, Hh * Ww, Cc, C.c_float(gamma), _cur_stream(R.device)))
+    return out
+
+
 def preprocess_images(rgb_u8, size=(224, 224)):
     """models/preprocessors.py:38-53 on the device: (NB, H0, W0, 3) uint8 RGB tensor -> (NB, H, W, 3) float32 BGR,
     mean-subtracted, nearest-neighbour resized like keras `load_img(target_size=size)`."""

@@ -13,6 +13,7 @@ the Keras layouts) and `weight_path` may name an `.npz` bundle of those arrays
 these classes hold no math of their own.
 """
 import numpy as np
+import torch
 
 from .engine import LRPEngine
 from .synthetic import VGG16_CFG
@@ -141,21 +142,25 @@ class ExplainImgCaptioningAttentionModel(object):
     def _r_words_from(self, row, t):
         raise NotImplementedError()
 
-    def _explain_CNN(self, X, relevance_value):
+    _batched_cnn = True      # _explain_CNN takes a stack of relevance rows (the harness then walks all words at once)
+
+    def _explain_CNN(self, X, relevance_value, as_tensor=False):
         """E:179-181: `self._CNN_explainer.analyze([X, R])`.  The reference re-runs the whole
         encoder forward on every call (AB:511); when X is the image `_forward_beam_search`
-        already encoded, the cached relevance gates are reused instead."""
+        already encoded, the cached relevance gates are reused instead.  as_tensor=True keeps
+        the (n,H,W,3) result on the device (for `engine.heatmap_render`)."""
         X = np.asarray(X, dtype=np.float32)
         R = np.asarray(relevance_value, dtype=np.float32)
         cached = getattr(self, "_img_input", None)
         if (self.caption is not None and cached is not None and X.shape[0] == 1 and X.shape == cached[:1].shape
                 and np.array_equal(X, cached[:1])):
             n = R.shape[0]
-            return self._engine.cnn_explain([0] * n, R.reshape(n, self.L, self.D)).cpu().numpy()
+            out = self._engine.cnn_explain([0] * n, R.reshape(n, self.L, self.D))
+            return out if as_tensor else out.cpu().numpy()
         out = self._CNN_explainer.analyze([X, R])        # another image: the caches now belong to it
         self.caption = None
         self._state_cache = {}
-        return out
+        return torch.as_tensor(out).to(self._engine.device) if as_tensor else out
 
     def _explain_sentence(self):
         """E:183-189, but all tokens in ONE batched launch chain."""
@@ -372,7 +377,7 @@ class _GradientMixin(object):
         dn = d.cpu().numpy()
         return [dn[i].reshape(1, g, g, self.D) for i in range(n)]
 
-    def _explain_CNN(self, X, relevance_value):
+    def _explain_CNN(self, X, relevance_value, as_tensor=False):
         """`self._CNN_explainer.analyze([X, relevance])` with the class's analyzer (E:672 / :884 / :928)."""
         X = np.asarray(X, dtype=np.float32)
         R = np.asarray(relevance_value, dtype=np.float32)
@@ -383,7 +388,8 @@ class _GradientMixin(object):
             self.caption = None
             self._state_cache = {}
         n = R.shape[0]
-        return self._engine.cnn_walk([0] * n, R.reshape(n, self.L, self.D), self._walk).cpu().numpy()
+        out = self._engine.cnn_walk([0] * n, R.reshape(n, self.L, self.D), self._walk)
+        return out if as_tensor else out.cpu().numpy()
 
     def _explain_lstm_single_word_sequence(self, t=0):
         raise NotImplementedError("the gradient engines explain through _lstm_decoder_backward")   # E:174-177 base stub
@@ -394,6 +400,7 @@ class _GradientMixin(object):
 
 class _GuidedGradcamMixin(_GradientMixin):
     _walk = "guided_backprop"
+    _batched_cnn = False     # the Grad-CAM factor is per word (E:930-937)
 
     def grad_cam(self, img_feature, grads):
         from .postprocess import grad_cam

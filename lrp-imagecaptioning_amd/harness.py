@@ -75,11 +75,19 @@ class Explainer(object):
         img_encode_relevance, attention = self._explainer._explain_sentence()
         _, img_input = X
         rel, hms = [], []
-        for i in range(len(attention)):
-            relevance = self._explainer._explain_CNN(img_input, img_encode_relevance[i])
-            hp = postprocess(relevance, self._color_conversion, False)
-            rel.append(relevance[0])
-            hms.append(heatmap(hp)[0])
+        if getattr(self._explainer, "_batched_cnn", False) and len(attention):
+            # every word of the caption in one walk of the image model, heat-maps rendered on the device
+            from .engine import heatmap_render
+            stack = np.concatenate([np.asarray(r, dtype=np.float32) for r in img_encode_relevance[:len(attention)]], axis=0)
+            dev = self._explainer._explain_CNN(img_input, stack, as_tensor=True)
+            hms = heatmap_render(dev, color_conversion=self._color_conversion).cpu().numpy()
+            rel = dev.cpu().numpy()
+        else:
+            for i in range(len(attention)):
+                relevance = self._explainer._explain_CNN(img_input, img_encode_relevance[i])
+                hp = postprocess(relevance, self._color_conversion, False)
+                rel.append(relevance[0])
+                hms.append(heatmap(hp)[0])
         res = {"captions": list(captions), "relevance": np.asarray(rel), "heatmaps": np.asarray(hms),
                "attention": np.asarray(attention), "r_words": self._explainer.r_words}
         if save_folder:

@@ -109,3 +109,20 @@ def test_preprocess_images_matches_pil(h0, w0):
         ref = np.asarray(Image.fromarray(rgb[i]).resize((224, 224), Image.NEAREST), dtype=np.float32)[..., ::-1] - VGG_BGR_MEAN
         assert out[i].shape == ref.shape
         assert np.array_equal(out[i], ref.astype(np.float32))
+
+
+def test_heatmap_render_matches_host():
+    """lrp_heatmap_render against the host restatement of utils_imagenet.heatmap (postprocess.heatmap).  The colormap
+    index is a truncation of a float32 pow chain, so single pixels may land one table entry off."""
+    from lrp_imagecaptioning_amd.engine import heatmap_render
+    from lrp_imagecaptioning_amd.postprocess import heatmap
+    rs = np.random.RandomState(0)
+    R = (rs.standard_normal((3, 56, 56, 3)) * rs.uniform(0.1, 3, size=(3, 1, 1, 1))).astype(np.float32)
+    R[2] = 0.0        # all-zero map: numpy yields 0/0 = NaN and an undefined int cast; the device renders mid-scale
+    got = heatmap_render(torch.as_tensor(R).cuda()).cpu().numpy()
+    want = np.stack([heatmap(R[i:i + 1])[0] for i in range(3)])
+    assert got.shape == want.shape == (3, 56, 56, 3)
+    d = np.abs(got[:2] - want[:2]).max(axis=-1)
+    assert (d > 0.02).mean() < 1e-3, (d > 0.02).mean()     # one LUT step of 'seismic' is <= 0.016 per channel
+    assert np.isfinite(got).all()
+    assert np.abs(got[2] - got[2, 0, 0]).max() == 0 and got[2, 0, 0].min() > 0.9      # index 127: white
