@@ -184,7 +184,7 @@ def main():
                        "reverse_walk_precision": args.precision},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:               # (rank 0 at N = 1 only: the other ranks would idle behind it)
+        if not args.no_cpu_baseline and args.cpu_sample_tokens > 0 and world == 1:               # (rank 0 at N = 1 only: the other ranks would idle behind it)
             res["cpu_baseline"] = cpu_baseline(w_host, V, T, args.cpu_sample_tokens)
         print(json.dumps(res))
     if dist:
