@@ -274,6 +274,32 @@ int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, in
 int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, int32_t npix, int32_t C, int32_t mode,
                        void* stream);
 
+/* ---- Fine-tune step of the LRP-inference training loop (train.py:573-581:
+ * `keras_model.train_on_batch(X + [lrp_weight], [y, y])` on ImgCaptioningAdaptiveAttentionLRPInferenceModel,
+ * models/model.py:1340-1374; VGG encoder + adaptive attention).  Per batch the caller runs lrp_encode_images,
+ * computes lrp_weight with the explain entry points above, then:
+ *   lrp_train_step : training-mode decoder forward on the cached features, loss 0.5 CE(y, logits[:, :-1]) +
+ *                    0.5 CE(y, (logits * lrp_weight)[:, :-1]) (M:95-103, :1370-1373), backward through the decoder and
+ *                    the encoder (all layers trainable, M:1332-1333) -> grads_dev, losses_dev = (total, head 1, head 2)
+ *   (the host all-reduces grads_dev across ranks)
+ *   lrp_train_apply: Adam(lr, clipvalue) as keras does (clip element-wise, then the moments; epsilon 1e-7) on the fp32
+ *                    master weights; the engine's operand copies are rebuilt, cached images are dropped.
+ * All parameters live in one flat fp32 buffer: lrp_train_num_params / lrp_train_param_info give name, offset and size
+ * of each slice ("<layer>_W" HWIO, "<layer>_b", then the decoder weights under their lrp_set_weight names);
+ * grads_dev has the same layout, lrp_train_flat_size floats.  cap_in_dev (B, T) int32 embedding rows (the model's
+ * `captions_input`), y_idx_dev (B, T) int32 class index of the one-hot label row or -1 for an all-zero row,
+ * lrp_weight_dev (B, T, V) float32.  Dropout masks (values 0 or 1/(1-p)) or NULL: image_features (B, L, H),
+ * global (B, E), output (B, T, H).  LSTM input / recurrent dropout is not built. */
+int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float beta2, float eps);
+int64_t lrp_train_flat_size(const lrp_handle* h);
+int32_t lrp_train_num_params(const lrp_handle* h);
+int lrp_train_param_info(const lrp_handle* h, int32_t i, const char** name, int64_t* offset, int64_t* size);
+int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const int32_t* y_idx_dev,
+                   const float* lrp_weight_dev, const float* mask_image_features_dev, const float* mask_global_dev,
+                   const float* mask_output_dev, float* grads_dev, float* losses_dev, void* stream);
+int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream);
+int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
+
 const char* lrp_last_error(void);
 int lrp_abi_version(void);
 

@@ -6,6 +6,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,9 @@ struct ConvLayer {
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
   DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
+  std::vector<float> raw_w, raw_b;   // host copies as set (HWIO / (cout,)): the fine-tune step's master weights start here
+  DevBuf Akeep;    // fine-tune step only: a_l of the layers whose output is the next conv's input (no pool after); the
+                   // LRP path turns that storage into the gate in place
   size_t act_elems() const { return (size_t)H * W * cout; }
 };
 
@@ -145,6 +149,26 @@ struct Encoder {
     return LRP_OK;
   }
 
+  // Fine-tune step: the weight gradient of layer l needs a_{l-1}; keep what the LRP caches drop.
+  bool keep_acts = false;
+  int enable_keep_acts(int64_t* total) {
+    if (keep_acts) return LRP_OK;
+    for (size_t li = 0; li + 1 < layers.size(); ++li) {
+      ConvLayer& L = layers[li];
+      if (!L.pool_after) LRP_TRY(L.Akeep.alloc((size_t)max_images * L.act_elems() * sizeof(float), total));
+    }
+    keep_acts = true;
+    return LRP_OK;
+  }
+  // input of conv li as the last encode left it (li >= 1; the image itself for li = 0)
+  const float* x1_last = nullptr;                  // input of conv 1 (the image layer's output sits in a ping-pong buffer)
+  const float* layer_input(int li) const {
+    if (li == 0) return images.as<float>();
+    if (li == 1) return x1_last;
+    const ConvLayer& P = layers[li - 1];
+    return P.pool_after ? P.P.as<float>() : P.Akeep.as<float>();
+  }
+
   int find_layer(const std::string& nm) const {
     for (size_t i = 0; i < layers.size(); ++i)
       if (layers[i].name == nm) return (int)i;
@@ -155,6 +179,7 @@ struct Encoder {
   int set_conv_weight(int li, const float* w, int64_t* total) {
     ConvLayer& L = layers[li];
     const size_t nW = (size_t)9 * L.cin * L.cout;
+    if (w != L.raw_w.data()) L.raw_w.assign(w, w + nW);
     std::vector<float> wp(nW), wn(nW);
     for (size_t i = 0; i < nW; ++i) { wp[i] = w[i] >= 0.f ? w[i] : 0.f; wn[i] = w[i] < 0.f ? w[i] : 0.f; }
     std::vector<float> pk;
@@ -249,6 +274,7 @@ struct Encoder {
 
   int set_conv_bias(int li, const float* b, int64_t* total) {
     ConvLayer& L = layers[li];
+    if (b != L.raw_b.data()) L.raw_b.assign(b, b + L.cout);
     LRP_TRY(L.bias.alloc((size_t)L.cout * sizeof(float), total));
     LRP_HIP_CHECK(hipMemcpy(L.bias.p, b, (size_t)L.cout * sizeof(float), hipMemcpyHostToDevice));
     L.have_b = true;
@@ -284,6 +310,8 @@ struct Encoder {
     for (const ConvLayer& L : layers)
       if (L.cout & 7) mixed = false;
     const bool overlap = mixed && side && overlap_enabled() && layers.size() > 1;
+    if (keep_acts && !overlap)
+      return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step needs the overlapped encode (default precision mode, widths % 8 == 0)");
     std::vector<const float*> xin(layers.size() + 1, nullptr);   // overlapped path: input of every conv
     for (size_t li = 0; li < layers.size(); ++li) {
       ConvLayer& L = layers[li];
@@ -293,7 +321,7 @@ struct Encoder {
         // activation chain only: a_l = relu(conv(x_l) + b) exact fp32, parked in the storage of its future gate
         ca.in = xin[li]; ca.NB = B; ca.H = L.H; ca.W = L.W; ca.Cin = L.cin; ca.CinP = conv_cinp(L.cin); ca.taps = 9;
         ca.bias = L.bias.as<float>(); ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout;
-        float* a_out = top ? feat.as<float>() : L.G.as<float>();
+        float* a_out = top ? feat.as<float>() : (keep_acts && !L.pool_after) ? L.Akeep.as<float>() : L.G.as<float>();
         ca.out = a_out;
         if (fwd_x6() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
           // fp32-grade product on the bf16 matrix cores: three-way split operands, two passes (see conv_igemm.h TERMS)
@@ -364,6 +392,7 @@ struct Encoder {
         float* t = x; x = a; a = t;                   // next input = a_l
       }
       xin[li + 1] = x;
+      if (li == 0) x1_last = x;
       if (mixed && !overlap) {                        // split8 copy of the next conv's input
         const size_t n8 = (size_t)B * layers[li + 1].H * layers[li + 1].W * layers[li + 1].cin / 8;
         hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, x, bufXs.as<float>(), n8);
@@ -392,7 +421,8 @@ struct Encoder {
           hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, side, L.G.as<float>(), bufZ.as<float>(),
                              (float*)nullptr, L.G.as<float>(), B, L.H, L.W, L.cout);
         else
-          hipLaunchKernelGGL(gate_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, side, reinterpret_cast<const f32x4*>(L.G.as<float>()),
+          hipLaunchKernelGGL(gate_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, side,
+                             reinterpret_cast<const f32x4*>(keep_acts ? L.Akeep.as<float>() : L.G.as<float>()),
                              reinterpret_cast<const f32x4*>(bufZ.as<float>()), L.G.as<f32x4>(), n / 4);
         LRP_HIP_CHECK(hipGetLastError());
       }
@@ -409,7 +439,10 @@ struct Encoder {
   // walk: 0 = LRP (LRPSequentialPresetA); gradient baselines (gradient_based.py:101-265) on the same caches:
   //   1 = Gradient, 2 = InputTimesGradient, 3 = GuidedBackprop — backward-data convs with the full w, the LRP gate
   //   used as the ReLU/arg-max mask, exact fp32.
-  int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st, int walk = 0) {
+  // layer_hook (fine-tune step): called with (li, dZ_li) — the gradient at the pre-activation of conv li, n x H x W x cout —
+  // before that layer's backward-data conv is launched; the image layer itself is then skipped (R_img_dev may be null).
+  int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st, int walk = 0,
+              const std::function<int(int, const float*)>* layer_hook = nullptr) {
     if (n < 1 || n > max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, max_tokens);
     if (walk < 0 || walk > 3) return fail(LRP_ERR_INVALID, "unknown walk %d", walk);
     if (encoded < 1 || features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before the CNN explain");
@@ -441,6 +474,10 @@ struct Encoder {
     }
     for (int li = (int)layers.size() - 1; li >= 0; --li) {
       const ConvLayer& L = layers[li];
+      if (layer_hook) {
+        LRP_TRY((*layer_hook)(li, S));
+        if (li == 0) return LRP_OK;
+      }
       ConvArgs ca{};
       ca.in = S; ca.NB = n; ca.H = L.H; ca.W = L.W; ca.Cin = L.cout; ca.CinP = conv_cinp(L.cout); ca.taps = 9;
       ca.wpk = walk != 0 ? L.w_bwd_full.as<float>() : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();

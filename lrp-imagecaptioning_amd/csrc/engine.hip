@@ -15,6 +15,7 @@
 #include "resnet_encoder.h"
 #include "rules_kernels.h"
 #include "score_kernels.h"
+#include "trainer.h"
 
 namespace lrp {
 std::string& last_error_ref() {
@@ -32,6 +33,7 @@ struct lrp_handle {
   ResNetEncoder rn;        // ResNet bottleneck encoder (LRP_ENC_RESNET)
   bool resnet = false;
   Decoder dec;
+  Trainer trainer;         // fine-tune step (lrp_train_*), VGG + adaptive attention
   float* feat() { return resnet ? rn.feat.as<float>() : enc.feat.as<float>(); }
   int& encoded() { return resnet ? rn.encoded : enc.encoded; }
   bool& features_only() { return resnet ? rn.features_only : enc.features_only; }
@@ -414,6 +416,48 @@ int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, in
   hipLaunchKernelGGL(preprocess_caffe_kernel, dim3(stream_grid((size_t)NB * H * W)), dim3(256), 0, S(stream), rgb_dev, out_dev,
                      NB, H0, W0, H, W);
   LRP_HIP_CHECK(hipGetLastError());
+  return LRP_OK;
+}
+
+// ---- fine-tune step, trainer.h
+int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float beta2, float eps) {
+  if (!h) return fail(LRP_ERR_INVALID, "null handle");
+  if (h->resnet) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step is built for the VGG encoder");
+  if (!(lr > 0.f) || clipvalue < 0.f || !(eps > 0.f)) return fail(LRP_ERR_INVALID, "lr, eps must be positive, clipvalue >= 0");
+  LRP_HIP_CHECK(hipSetDevice(h->cfg.device));
+  return h->trainer.begin(h->enc, h->dec, h->cfg, lr, clipvalue, beta1, beta2, eps, &h->ws_bytes);
+}
+
+int64_t lrp_train_flat_size(const lrp_handle* h) { return h && h->trainer.ready ? (int64_t)h->trainer.n_total : 0; }
+int32_t lrp_train_num_params(const lrp_handle* h) { return h && h->trainer.ready ? (int32_t)h->trainer.params.size() : 0; }
+
+int lrp_train_param_info(const lrp_handle* h, int32_t i, const char** name, int64_t* offset, int64_t* size) {
+  if (!h || !h->trainer.ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
+  if (i < 0 || i >= (int32_t)h->trainer.params.size()) return fail(LRP_ERR_INVALID, "parameter index %d out of range", i);
+  const TrainParam& p = h->trainer.params[i];
+  if (name) *name = p.name.c_str();
+  if (offset) *offset = (int64_t)p.off;
+  if (size) *size = (int64_t)p.n;
+  return LRP_OK;
+}
+
+int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const int32_t* y_idx_dev,
+                   const float* lrp_weight_dev, const float* mask_image_features_dev, const float* mask_global_dev,
+                   const float* mask_output_dev, float* grads_dev, float* losses_dev, void* stream) {
+  if (!h || !cap_in_dev || !y_idx_dev || !lrp_weight_dev || !grads_dev) return fail(LRP_ERR_INVALID, "null argument");
+  return h->trainer.step(h->enc, h->feat(), B, T, cap_in_dev, y_idx_dev, lrp_weight_dev, mask_image_features_dev, mask_global_dev,
+                         mask_output_dev, grads_dev, losses_dev, S(stream));
+}
+
+int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream) {
+  if (!h || !grads_dev) return fail(LRP_ERR_INVALID, "null argument");
+  return h->trainer.apply(h->enc, h->dec, grads_dev, nullptr, S(stream));
+}
+
+int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream) {
+  if (!h || !flat_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (!h->trainer.ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
+  LRP_HIP_CHECK(hipMemcpyAsync(flat_dev, h->trainer.master.p, h->trainer.n_total * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
   return LRP_OK;
 }
 

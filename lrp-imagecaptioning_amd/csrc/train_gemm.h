@@ -1,0 +1,242 @@
+// Dense fp32 products of the fine-tune step (train.py:573-581, models/model.py:1340-1374) on the fp32
+// matrix cores: C (+)= op(A) . op(B), row-major operands with leading dimensions, any M / N / K.
+//
+//   TN  C = A^T B   weight gradients  dW = X^T dY, K = rows of the batch (B*T, B*L or B*H*W pixels) — both operands
+//                   are read as they lie in memory (k-major rows); split over K with a deterministic second pass.
+//                   With `gather` the rows of A are the pixels of an NHWC activation shifted by one 3x3 tap (zero
+//                   outside the image): the weight gradient of a 'same' convolution, one launch per tap.
+//   NN  C = A B     forward products X W          NT  C = A B^T   backward-data products dY W^T
+//
+// v_mfma_f32_32x32x2_f32: lane l feeds A[m = l & 31][k = l >> 5] and B[k = l >> 5][n = l & 31] — one scalar per lane
+// from a k-major LDS tile, consecutive lanes on consecutive banks.  Tile 128 x 128 x 16, 4 waves of 64 x 64, register
+// prefetch of the next k-slab while the current one is multiplied.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lrp {
+
+struct SgemmArgs {
+  const float* A; const float* B; float* C;
+  int M, N; long K;
+  long lda, ldb, ldc;
+  int transA, transB;      // op(A)[m][k] = transA ? A[k*lda + m] : A[m*lda + k];  op(B)[k][n] = transB ? B[n*ldb + k] : B[k*ldb + n]
+  int accumulate;          // C += result
+  int ksplit; long kchunk; // blockIdx.z = slice of K; partials go to ws[slice][M][N] when ksplit > 1
+  float* ws;
+  int gather, gH, gW, dy, dx;   // transA only: row r = (n*gH + y)*gW + x reads row r + dy*gW + dx, zero outside the image
+  int vecA, vecB;          // 16 B loads allowed (alignment checked on the host)
+};
+
+constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 16, SG_LD = 132;
+
+typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
+
+// stage one operand tile (16 k x 128 cols) into LDS [k][col]; kmajor: memory rows are k
+template <bool KMAJOR>
+__device__ __forceinline__ void sg_fetch(const float* __restrict__ P, long ld, int rows_mn, long k_end, int mn0, long k0, int tid,
+                                         bool vec, const SgemmArgs& a, bool is_a, float (&r)[2][4]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q;
+    if constexpr (KMAJOR) {
+      const int kr = idx >> 5, c4 = idx & 31;
+      const long k = k0 + kr;
+      const int col = mn0 + 4 * c4;
+      long src = k;
+      bool ok = k < k_end;
+      if (is_a && a.gather && ok) {
+        const int x = (int)(k % a.gW), y = (int)((k / a.gW) % a.gH);
+        ok = (unsigned)(y + a.dy) < (unsigned)a.gH && (unsigned)(x + a.dx) < (unsigned)a.gW;
+        src = k + (long)a.dy * a.gW + a.dx;
+      }
+      if (ok && vec && col + 3 < rows_mn) {
+        const float4 v = *reinterpret_cast<const float4*>(P + src * ld + col);
+        r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[q][j] = (ok && col + j < rows_mn) ? P[src * ld + col + j] : 0.f;
+      }
+    } else {
+      const int row = idx >> 2, c4 = idx & 3;
+      const int mn = mn0 + row;
+      const long k = k0 + 4 * c4;
+      const bool ok = mn < rows_mn;
+      if (ok && vec && k + 3 < k_end) {
+        const float4 v = *reinterpret_cast<const float4*>(P + (long)mn * ld + k);
+        r[q][0] = v.x; r[q][1] = v.y; r[q][2] = v.z; r[q][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[q][j] = (ok && k + j < k_end) ? P[(long)mn * ld + k + j] : 0.f;
+      }
+    }
+  }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void sg_put(float* __restrict__ S, int tid, const float (&r)[2][4]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int idx = tid + 256 * q;
+    if constexpr (KMAJOR) {
+      const int kr = idx >> 5, c4 = idx & 31;
+      *reinterpret_cast<float4*>(S + kr * SG_LD + 4 * c4) = make_float4(r[q][0], r[q][1], r[q][2], r[q][3]);
+    } else {
+      const int row = idx >> 2, c4 = idx & 3;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) S[(4 * c4 + j) * SG_LD + row] = r[q][j];
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __shared__ float As[2][SG_BK * SG_LD];
+  __shared__ float Bs[2][SG_BK * SG_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * SG_BM, n0 = blockIdx.x * SG_BN;
+  const long kb = (long)blockIdx.z * a.kchunk;
+  const long ke = kb + a.kchunk < a.K ? kb + a.kchunk : a.K;
+  sg_f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ra[2][4], rb[2][4];
+  const long nst = (ke - kb + SG_BK - 1) / SG_BK;
+  if (nst > 0) {
+    sg_fetch<TA>(a.A, a.lda, a.M, ke, m0, kb, tid, a.vecA != 0, a, true, ra);
+    sg_fetch<!TB>(a.B, a.ldb, a.N, ke, n0, kb, tid, a.vecB != 0, a, false, rb);
+    sg_put<TA>(As[0], tid, ra);
+    sg_put<!TB>(Bs[0], tid, rb);
+  }
+  __syncthreads();
+  for (long s = 0; s < nst; ++s) {
+    const int cur = (int)(s & 1);
+    const bool more = s + 1 < nst;
+    if (more) {
+      sg_fetch<TA>(a.A, a.lda, a.M, ke, m0, kb + (s + 1) * SG_BK, tid, a.vecA != 0, a, true, ra);
+      sg_fetch<!TB>(a.B, a.ldb, a.N, ke, n0, kb + (s + 1) * SG_BK, tid, a.vecB != 0, a, false, rb);
+    }
+    const float* Ac = As[cur] + (lane >> 5) * SG_LD + wm * 64 + (lane & 31);
+    const float* Bc = Bs[cur] + (lane >> 5) * SG_LD + wn * 64 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < SG_BK / 2; ++kk) {
+      const float a0 = Ac[2 * kk * SG_LD], a1 = Ac[2 * kk * SG_LD + 32];
+      const float b0 = Bc[2 * kk * SG_LD], b1 = Bc[2 * kk * SG_LD + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      sg_put<TA>(As[cur ^ 1], tid, ra);
+      sg_put<!TB>(Bs[cur ^ 1], tid, rb);
+    }
+    __syncthreads();
+  }
+  float* C = a.ksplit > 1 ? a.ws + (size_t)blockIdx.z * a.M * a.N : a.C;
+  const long ldc = a.ksplit > 1 ? a.N : a.ldc;
+  const bool accum = a.ksplit > 1 ? false : a.accumulate != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col < a.N) {
+          float* p = C + (long)row * ldc + col;
+          *p = accum ? *p + acc[i][j][r] : acc[i][j][r];
+        }
+      }
+    }
+#endif
+}
+
+// C[m][n] (+)= sum_s ws[s][m][n], slices added in index order
+__global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
+                                                           long ldc, int ksplit, int accumulate) {
+  const size_t mn = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += ws[(size_t)k * mn + i];
+    float* p = C + (long)(i / N) * ldc + (i % N);
+    *p = accumulate ? *p + s : s;
+  }
+}
+
+inline bool sg_aligned(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
+
+// ws / ws_floats: workspace for the K split (may be null: no split).  Target ~2 blocks per CU.
+inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st) {
+  if (a.M < 1 || a.N < 1 || a.K < 1) return hipErrorInvalidValue;
+  a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
+  a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
+  const int gx = (a.N + SG_BN - 1) / SG_BN, gy = (a.M + SG_BM - 1) / SG_BM;
+  int ks = 1;
+  const long steps = (a.K + SG_BK - 1) / SG_BK;
+  if (ws && (long)gx * gy < 512 && steps >= 64) {
+    ks = (int)((1024 + (long)gx * gy - 1) / ((long)gx * gy));
+    const long max_by_k = steps / 32 > 0 ? steps / 32 : 1;        // at least 32 slabs per slice
+    if (ks > max_by_k) ks = (int)max_by_k;
+    const size_t per = (size_t)a.M * a.N;
+    if ((size_t)ks * per > ws_floats) ks = (int)(ws_floats / per);
+    if (ks < 1) ks = 1;
+  }
+  long chunk = ((steps + ks - 1) / ks) * SG_BK;
+  ks = (int)((a.K + chunk - 1) / chunk);
+  a.ksplit = ks; a.kchunk = chunk; a.ws = ws;
+  dim3 grid(gx, gy, ks);
+  if (a.transA && !a.transB) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, a);
+  else if (!a.transA && !a.transB) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, st, a);
+  else if (!a.transA && a.transB) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, st, a);
+  else return hipErrorInvalidValue;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (ks > 1) {
+    const size_t mn = (size_t)a.M * a.N;
+    const unsigned blocks = (unsigned)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sgemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, a.C, a.M, a.N, a.ldc, ks, a.accumulate);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+// column sums of a (rows x N) matrix: out[n] (+)= sum_r X[r][n]; two deterministic passes through `part` (chunks x N)
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long ld, long rows, int N, long rows_per,
+                                                          float* __restrict__ part) {
+  const long r0 = (long)blockIdx.x * rows_per;
+  const long r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += X[r * ld + n];
+    part[(size_t)blockIdx.x * N + n] = s;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out,
+                                                           int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N + n];
+  out[n] = accumulate ? out[n] + s : s;
+}
+inline hipError_t colsum(const float* X, long ld, long rows, int N, float* out, int accumulate, float* ws, size_t ws_floats,
+                         hipStream_t st) {
+  long chunks = (rows + 255) / 256;
+  if (chunks > 2048) chunks = 2048;
+  if ((size_t)chunks * N > ws_floats) chunks = (long)(ws_floats / N);
+  if (chunks < 1) return hipErrorInvalidValue;
+  const long per = (rows + chunks - 1) / chunks;
+  chunks = (rows + per - 1) / per;
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)chunks), dim3(256), 0, st, X, ld, rows, N, per, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, (int)chunks, N, out, accumulate);
+  return hipGetLastError();
+}
+
+}  // namespace lrp

@@ -1,0 +1,322 @@
+// Point-wise / attention kernels of the fine-tune step of the adaptive-attention captioner.
+// Forward graph: models/model.py:1340-1368 (build) + :573-600 (ExternalAttentionRNNWrapperLocalAttentionV3.step);
+// loss :95-103 with loss_weights [0.5, 0.5] (:1370-1373).  Everything is fp32, time-major (t, b) rows.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lrp {
+
+__device__ __forceinline__ float tr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float tr_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over a 256-thread block, result broadcast to every thread (red: 4 floats of LDS + 1)
+__device__ __forceinline__ float tr_block_sum(float v, float* red) {
+  v = tr_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float s = red[0] + red[1] + red[2] + red[3];
+  return s;
+}
+__device__ __forceinline__ float tr_block_max(float v, float* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// x[r][n] = relu(x[r][n] + b[n]) * mask[r][n]   (Dense(relu) -> Dropout, M:1346-1352)
+__global__ __launch_bounds__(256) void tr_bias_relu_mask_kernel(float* __restrict__ x, const float* __restrict__ b,
+                                                                const float* __restrict__ mask, size_t rows, int N) {
+  const size_t n = rows * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = fmaxf(x[i] + b[i % N], 0.f);
+    if (mask) v *= mask[i];
+    x[i] = v;
+  }
+}
+// d[i] = d[i] * mask[i] * [y[i] > 0]   (back through Dropout and ReLU; y = the masked activation)
+__global__ __launch_bounds__(256) void tr_relu_mask_bwd_kernel(float* __restrict__ d, const float* __restrict__ y,
+                                                               const float* __restrict__ mask, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float v = y[i] > 0.f ? d[i] : 0.f;
+    if (mask) v *= mask[i];
+    d[i] = v;
+  }
+}
+// favg[b][d] = mean_i feat[b][i][d]   (Lambda K.mean(axis=1), M:1343-1344)
+__global__ __launch_bounds__(256) void tr_mean_rows_kernel(const float* __restrict__ feat, float* __restrict__ favg, int L, int D) {
+  const int b = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float s = 0.f;
+    for (int i = 0; i < L; ++i) s += feat[((size_t)b * L + i) * D + d];
+    favg[(size_t)b * D + d] = s / (float)L;
+  }
+}
+// dfeat[b][i][d] += dfavg[b][d] / L
+__global__ __launch_bounds__(256) void tr_mean_rows_bwd_kernel(float* __restrict__ dfeat, const float* __restrict__ dfavg, int L, int D,
+                                                               size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t b = i / ((size_t)L * D);
+    dfeat[i] += dfavg[b * D + i % D] / (float)L;
+  }
+}
+// X[t][b] = [embedding[cap_in[b][t]] | glob[b]]   (M:581 input_x)
+__global__ __launch_bounds__(256) void tr_build_x_kernel(const float* __restrict__ emb, const float* __restrict__ glob,
+                                                         const int* __restrict__ cap_in, float* __restrict__ X, int B, int T, int E) {
+  const int t = blockIdx.x / B, b = blockIdx.x % B;
+  const int row = cap_in[b * T + t];
+  float* x = X + (size_t)blockIdx.x * 2 * E;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    x[e] = emb[(size_t)row * E + e];
+    x[E + e] = glob[(size_t)b * E + e];
+  }
+}
+// LSTM cell + sentinel of one step (keras LSTMCell.call, gate order i f c o; M:582-584).  Z row = [z_i z_f z_g z_o | u]
+// before the bias; G row = activated gates, C / Hs / TC (= tanh c) / SU (= sigmoid u) / S rows of this step.
+__global__ __launch_bounds__(256) void tr_cell_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
+                                                          const float* __restrict__ Cprev, float* __restrict__ G, float* __restrict__ C,
+                                                          float* __restrict__ Hs, float* __restrict__ TC, float* __restrict__ SU,
+                                                          float* __restrict__ S, int B, int H) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * H; idx += gridDim.x * 256) {
+    const int b = idx / H, h = idx % H;
+    const float* z = Z + (size_t)b * 5 * H;
+    const float i = tr_sigmoid(z[h] + bias[h]), f = tr_sigmoid(z[H + h] + bias[H + h]);
+    const float g = tanhf(z[2 * H + h] + bias[2 * H + h]), o = tr_sigmoid(z[3 * H + h] + bias[3 * H + h]);
+    const float c = f * (Cprev ? Cprev[idx] : 0.f) + i * g;
+    const float tc = tanhf(c), su = tr_sigmoid(z[4 * H + h]);
+    float* gg = G + (size_t)b * 4 * H;
+    gg[h] = i; gg[H + h] = f; gg[2 * H + h] = g; gg[3 * H + h] = o;
+    C[idx] = c; Hs[idx] = o * tc; TC[idx] = tc; SU[idx] = su; S[idx] = tc * su;
+  }
+}
+// Adaptive attention of one step, one workgroup per caption (M:586-599).  OUTm = (h + c_hat) * mask_out.
+__global__ __launch_bounds__(256) void tr_attention_fwd_kernel(const float* __restrict__ proj, const float* __restrict__ Vf,
+                                                               const float* __restrict__ HW, const float* __restrict__ SW,
+                                                               const float* __restrict__ v, const float* __restrict__ Hs,
+                                                               const float* __restrict__ S, const float* __restrict__ mask_out,
+                                                               float* __restrict__ ALPHA, float* __restrict__ BETA, float* __restrict__ CTX,
+                                                               float* __restrict__ OUTm, int L, int H, int T, int t) {
+  extern __shared__ float sm[];                 // e[L] | red[8]
+  float* e = sm;
+  float* red = sm + L;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* hw = HW + (size_t)b * H;
+  for (int i = wave; i < L; i += 4) {
+    const float* p = proj + ((size_t)b * L + i) * H;
+    float s = 0.f;
+    for (int h = lane; h < H; h += 64) s += tanhf(p[h] + hw[h]) * v[h];
+    s = tr_wave_sum(s);
+    if (lane == 0) e[i] = s;
+  }
+  float zs = 0.f;
+  for (int h = tid; h < H; h += 256) zs += tanhf(SW[(size_t)b * H + h] + hw[h]) * v[h];
+  zs = tr_block_sum(zs, red);                   // (also publishes e[])
+  float mx = -INFINITY;
+  for (int i = tid; i < L; i += 256) mx = fmaxf(mx, e[i]);
+  mx = tr_block_max(mx, red);
+  float se = 0.f;
+  for (int i = tid; i < L; i += 256) se += expf(e[i] - mx);
+  se = tr_block_sum(se, red);
+  const float mx2 = fmaxf(mx, zs);
+  const float den2 = se * expf(mx - mx2) + expf(zs - mx2);
+  const float beta = expf(zs - mx2) / den2;
+  __syncthreads();
+  for (int i = tid; i < L; i += 256) {
+    const float a = expf(e[i] - mx) / se;
+    e[i] = a;
+    ALPHA[(size_t)b * L + i] = a;
+  }
+  if (tid == 0) BETA[b] = beta;
+  __syncthreads();
+  for (int h = tid; h < H; h += 256) {
+    float c = 0.f;
+    for (int i = 0; i < L; ++i) c += e[i] * Vf[((size_t)b * L + i) * H + h];
+    const size_t o = (size_t)b * H + h;
+    CTX[o] = c;
+    float out = Hs[o] + beta * S[o] + (1.f - beta) * c;
+    if (mask_out) out *= mask_out[((size_t)b * T + t) * H + h];
+    OUTm[o] = out;
+  }
+}
+// Two-headed loss (M:95-103, :1364-1373) of one (t, b) row, in place: Z row (logits before the bias) -> d loss / d logits.
+// part[row] = (CE head 1, CE head 2).  Rows of the last time step and rows without a label give zero.
+__global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, const float* __restrict__ bout, const float* __restrict__ lw,
+                                                      const int* __restrict__ y_idx, float* __restrict__ part, int B, int T, int V,
+                                                      float scale) {
+  __shared__ float red[4];
+  const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
+  float* z = Z + (size_t)row * V;
+  const int y = y_idx[b * T + t];
+  if (t == T - 1 || y < 0) {
+    for (int k = tid; k < V; k += 256) z[k] = 0.f;
+    if (tid == 0) { part[2 * row] = 0.f; part[2 * row + 1] = 0.f; }
+    return;
+  }
+  const float* w = lw + ((size_t)b * T + t) * V;
+  float m1 = -INFINITY, m2 = -INFINITY;
+  for (int k = tid; k < V; k += 256) {
+    const float x = z[k] + bout[k];
+    m1 = fmaxf(m1, x); m2 = fmaxf(m2, x * w[k]);
+  }
+  m1 = tr_block_max(m1, red);
+  m2 = tr_block_max(m2, red);
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = tid; k < V; k += 256) {
+    const float x = z[k] + bout[k];
+    s1 += expf(x - m1); s2 += expf(x * w[k] - m2);
+  }
+  s1 = tr_block_sum(s1, red);
+  s2 = tr_block_sum(s2, red);
+  const float zy = z[y] + bout[y];
+  __syncthreads();
+  if (tid == 0) {
+    part[2 * row] = -(zy - m1 - logf(s1));
+    part[2 * row + 1] = -(zy * w[y] - m2 - logf(s2));
+  }
+  for (int k = tid; k < V; k += 256) {
+    const float x = z[k] + bout[k];
+    const float d = k == y ? 1.f : 0.f;
+    z[k] = scale * (0.5f * (expf(x - m1) / s1 - d) + 0.5f * w[k] * (expf(x * w[k] - m2) / s2 - d));
+  }
+}
+// losses[0..2] = (0.5 l1 + 0.5 l2, l1, l2), rows summed in index order
+__global__ void tr_loss_final_kernel(const float* __restrict__ part, int rows, float scale, float* __restrict__ losses) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, c = 0.0;
+  for (int r = 0; r < rows; ++r) { a += part[2 * r]; c += part[2 * r + 1]; }
+  losses[1] = (float)(a * scale); losses[2] = (float)(c * scale);
+  losses[0] = 0.5f * losses[1] + 0.5f * losses[2];
+}
+
+// Backward of tr_attention_fwd_kernel for one step.  In: dOUTm row of the step, carry dH.  Out: dHtot = dH + dout,
+// dS = beta dout, DZS (d of the sentinel score pre-tanh row), DHW (d of h Wg); accumulated over the steps per caption:
+// dProj (B, L, H), dVf (B, L, H), dVacc (B, H) (the attention vector's gradient, summed over captions afterwards).
+__global__ __launch_bounds__(256) void tr_attention_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ Vf,
+                                                               const float* __restrict__ HW, const float* __restrict__ SW,
+                                                               const float* __restrict__ v, const float* __restrict__ S,
+                                                               const float* __restrict__ CTX, const float* __restrict__ ALPHA,
+                                                               const float* __restrict__ BETA, const float* __restrict__ dOUTm,
+                                                               const float* __restrict__ mask_out, const float* __restrict__ dH,
+                                                               float* __restrict__ dHtot, float* __restrict__ dS, float* __restrict__ DZS,
+                                                               float* __restrict__ DHW, float* __restrict__ dProj, float* __restrict__ dVf,
+                                                               float* __restrict__ dVacc, int L, int H, int T, int t) {
+  extern __shared__ float sm[];                 // de[L] | alpha[L] | dctx[H] | red[8]
+  float* de = sm;
+  float* al = sm + L;
+  float* dctx = sm + 2 * L;
+  float* red = sm + 2 * L + H;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float beta = BETA[b];
+  const float* hw = HW + (size_t)b * H;
+  float dbeta = 0.f;
+  for (int h = tid; h < H; h += 256) {
+    const size_t o = (size_t)b * H + h;
+    float d = dOUTm[o];
+    if (mask_out) d *= mask_out[((size_t)b * T + t) * H + h];
+    dHtot[o] = (dH ? dH[o] : 0.f) + d;
+    dS[o] = beta * d;
+    dctx[h] = (1.f - beta) * d;
+    dbeta += d * (S[o] - CTX[o]);
+  }
+  for (int i = tid; i < L; i += 256) al[i] = ALPHA[(size_t)b * L + i];
+  dbeta = tr_block_sum(dbeta, red);             // (publishes dctx / al)
+  for (int i = wave; i < L; i += 4) {
+    const float* vf = Vf + ((size_t)b * L + i) * H;
+    float s = 0.f;
+    for (int h = lane; h < H; h += 64) s += dctx[h] * vf[h];
+    s = tr_wave_sum(s);
+    if (lane == 0) de[i] = s;                   // d alpha_i for now
+  }
+  __syncthreads();
+  float dot = 0.f;
+  for (int i = tid; i < L; i += 256) dot += al[i] * de[i];
+  dot = tr_block_sum(dot, red);
+  for (int i = tid; i < L; i += 256) de[i] = al[i] * (de[i] - dot) - beta * (1.f - beta) * al[i] * dbeta;
+  const float dzs = beta * (1.f - beta) * dbeta;
+  __syncthreads();
+  for (int h = tid; h < H; h += 256) {
+    const float vh = v[h], hwh = hw[h], dc = dctx[h];
+    float dhw = 0.f, dv = 0.f;
+    for (int i = 0; i < L; ++i) {
+      const size_t o = ((size_t)b * L + i) * H + h;
+      const float A = tanhf(proj[o] + hwh);
+      const float dA = de[i] * vh * (1.f - A * A);
+      dProj[o] += dA;
+      dVf[o] += al[i] * dc;
+      dhw += dA;
+      dv += de[i] * A;
+    }
+    const size_t o = (size_t)b * H + h;
+    const float As = tanhf(SW[o] + hwh);
+    const float dz = dzs * vh * (1.f - As * As);
+    DZS[o] = dz;
+    DHW[o] = dhw + dz;
+    dVacc[o] += dv + dzs * As;
+  }
+}
+// Backward of tr_cell_fwd_kernel: dHtot, dS, carry dC -> DZ row [d z_i, d z_f, d z_g, d z_o | d u], carry dC (in place).
+__global__ __launch_bounds__(256) void tr_cell_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Cprev,
+                                                          const float* __restrict__ TC, const float* __restrict__ SU,
+                                                          const float* __restrict__ dHtot, const float* __restrict__ dS,
+                                                          float* __restrict__ dC, float* __restrict__ DZ, int B, int H) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * H; idx += gridDim.x * 256) {
+    const int b = idx / H, h = idx % H;
+    const float* gg = G + (size_t)b * 4 * H;
+    const float i = gg[h], f = gg[H + h], g = gg[2 * H + h], o = gg[3 * H + h];
+    const float tc = TC[idx], su = SU[idx], ds = dS[idx], dh = dHtot[idx];
+    const float dct = dC[idx] + (ds * su + dh * o) * (1.f - tc * tc);
+    float* dz = DZ + (size_t)b * 5 * H;
+    dz[h] = dct * g * i * (1.f - i);
+    dz[H + h] = dct * (Cprev ? Cprev[idx] : 0.f) * f * (1.f - f);
+    dz[2 * H + h] = dct * i * (1.f - g * g);
+    dz[3 * H + h] = dh * tc * o * (1.f - o);
+    dz[4 * H + h] = ds * tc * su * (1.f - su);
+    dC[idx] = dct * f;
+  }
+}
+// dglob[b][e] = sum_t dX[t][b][E + e]
+__global__ __launch_bounds__(256) void tr_dglob_kernel(const float* __restrict__ dX, float* __restrict__ dglob, int B, int T, int E) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * E; idx += gridDim.x * 256) {
+    const int b = idx / E, e = idx % E;
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += dX[((size_t)t * B + b) * 2 * E + E + e];
+    dglob[idx] = s;
+  }
+}
+// Embedding gradient: dEmb[row] = sum of the dX word halves of every (t, b) that read that row, in (t, b) order
+// (one workgroup per (t, b); the first reader of a row sums for all of them — no atomics, run-to-run identical).
+__global__ __launch_bounds__(256) void tr_embedding_bwd_kernel(const float* __restrict__ dX, const int* __restrict__ cap_in,
+                                                               float* __restrict__ dEmb, int B, int T, int E) {
+  const int me = blockIdx.x, n = B * T;
+  const int row = cap_in[(me % B) * T + me / B];
+  for (int j = 0; j < me; ++j)
+    if (cap_in[(j % B) * T + j / B] == row) return;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float s = 0.f;
+    for (int j = me; j < n; ++j)
+      if (cap_in[(j % B) * T + j / B] == row) s += dX[(size_t)j * 2 * E + e];
+    dEmb[(size_t)row * E + e] = s;
+  }
+}
+// keras Adam with clipvalue (optimizers.py: clip, moments, update); lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) from the host
+__global__ __launch_bounds__(256) void tr_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, size_t n, float lr_t, float clip, float b1, float b2,
+                                                      float eps) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float gi = g[i];
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+}  // namespace lrp

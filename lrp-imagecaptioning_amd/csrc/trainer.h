@@ -1,0 +1,306 @@
+// Fine-tune step of the LRP-inference training loop (reference: train.py:573-581,
+// `keras_model.train_on_batch(X + [lrp_weight], [y, y])` on the model of models/model.py:1340-1374).
+//
+// What the reference does per batch: predict (forward), LRPInferenceLayerAdaptive.call (the hot path of this library),
+// then a second, training-mode forward + backward + Adam through the whole captioner incl. the VGG16 encoder.  Here
+// the encoder forward is the one `lrp_encode_images` already ran for the explanation (the encoder has no
+// training-mode layers): its ReLU masks / arg-max routes are the cached LRP gates, its activations are kept
+// (`Encoder::keep_acts`).  The step itself:
+//   decoder forward with the given dropout masks (train_kernels.h) -> two-headed loss -> decoder backward (hand-written
+//   BPTT, weight gradients as K = batch-rows products after the scan) -> d features -> encoder backward = the
+//   Gradient walk of the explainer (exact fp32 backward-data convs) with one weight-gradient product per layer and tap
+//   hooked in (train_gemm.h, gather form) -> flat gradient buffer (caller's; all-reduced by the host over RCCL) -> Adam.
+// Parameters live in ONE flat fp32 master buffer in `param order` (conv W, b per layer, then the decoder weights in
+// Decoder::adaptive order); gradients and Adam moments use the same offsets.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "decoder.h"
+#include "encoder.h"
+#include "train_gemm.h"
+#include "train_kernels.h"
+
+namespace lrp {
+
+struct TrainParam {
+  std::string name;
+  size_t off = 0, n = 0;
+  std::vector<int64_t> shape;
+};
+
+struct Trainer {
+  bool ready = false;
+  int Bm = 0, Tm = 0, L = 0, D = 0, H = 0, E = 0, V = 0;
+  std::vector<TrainParam> params;
+  size_t n_total = 0;
+  DevBuf master, mom, vel;
+  std::vector<float> host;                     // mirror of master for re-packing the engine's operand copies
+  float lr = 0.f, clip = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
+  int64_t iter = 0;
+  // forward state (time-major rows (t, b))
+  DevBuf Vf, favg, glob, proj, Xall, Z, Gt, Cst, Hst, TC, SU, Sst, HW, SW, ALPHA, BETA, CTX, OUTm, logits, part, losses;
+  // backward state
+  DevBuf dOUTm, dHtot, dS, dH, dC, DZ, DZS, DHW, dProj, dVf, dVacc, dX, dglob, dfavg, dF, ws, ident;
+  size_t ws_floats = 0;
+  bool stepped = false;
+
+  const TrainParam* find(const std::string& nm) const {
+    for (const TrainParam& p : params)
+      if (p.name == nm) return &p;
+    return nullptr;
+  }
+  float* W(const char* nm) const { return master.as<float>() + find(nm)->off; }
+  size_t off(const char* nm) const { return find(nm)->off; }
+
+  int begin(Encoder& enc, Decoder& dec, const lrp_config& c, float lr_, float clip_, float b1_, float b2_, float eps_,
+            int64_t* total) {
+    if (dec.kind != LRP_DEC_ADAPTIVE) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step is built for the adaptive-attention captioner");
+    if (c.E != c.H) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step needs E == H");
+    LRP_TRY(enc.check_ready());
+    Bm = c.max_images; Tm = c.max_caption_len; L = c.L; D = c.D; H = c.H; E = c.E; V = c.V;
+    if (Bm > c.max_tokens) return fail(LRP_ERR_INVALID, "fine-tune step: max_tokens (%d) must be >= max_images (%d)", c.max_tokens, Bm);
+    params.clear();
+    n_total = 0;
+    auto add = [&](const std::string& nm, std::vector<int64_t> shape) {
+      TrainParam p;
+      p.name = nm; p.shape = shape; p.n = 1;
+      for (int64_t s : shape) p.n *= (size_t)s;
+      p.off = n_total;
+      n_total += (p.n + 3) / 4 * 4;                                 // 16 B aligned slices
+      params.push_back(p);
+    };
+    for (const ConvLayer& Ly : enc.layers) {
+      add(Ly.name + "_W", {3, 3, Ly.cin, Ly.cout});
+      add(Ly.name + "_b", {Ly.cout});
+    }
+    add("image_features_W", {D, H}); add("image_features_b", {H});
+    add("global_W", {D, E}); add("global_b", {E});
+    add("embedding", {V, E});
+    add("lstm_Wi", {2 * E, 4 * H}); add("lstm_Wh", {H, 4 * H}); add("lstm_b", {4 * H});
+    add("Wv", {H, H}); add("Wg", {H, H}); add("V", {H, 1}); add("Wx", {2 * E, H}); add("Wh", {H, H}); add("Ws", {H, H});
+    add("output_W", {H, V}); add("output_b", {V});
+    host.assign(n_total, 0.f);
+    size_t pi = 0;
+    for (const ConvLayer& Ly : enc.layers) {
+      if (Ly.raw_w.size() != params[pi].n || Ly.raw_b.size() != params[pi + 1].n)
+        return fail(LRP_ERR_STATE, "encoder weights of '%s' are not set", Ly.name.c_str());
+      std::copy(Ly.raw_w.begin(), Ly.raw_w.end(), host.begin() + params[pi].off);
+      std::copy(Ly.raw_b.begin(), Ly.raw_b.end(), host.begin() + params[pi + 1].off);
+      pi += 2;
+    }
+    for (; pi < params.size(); ++pi) {
+      auto it = dec.raw.find(params[pi].name);
+      if (it == dec.raw.end() || it->second.size() != params[pi].n)
+        return fail(LRP_ERR_STATE, "decoder weight '%s' is not set (or has the wrong size)", params[pi].name.c_str());
+      std::copy(it->second.begin(), it->second.end(), host.begin() + params[pi].off);
+    }
+    LRP_TRY(master.alloc(n_total * 4, total)); LRP_TRY(mom.alloc(n_total * 4, total)); LRP_TRY(vel.alloc(n_total * 4, total));
+    LRP_HIP_CHECK(hipMemcpy(master.p, host.data(), n_total * 4, hipMemcpyHostToDevice));
+    LRP_HIP_CHECK(hipMemset(mom.p, 0, n_total * 4));
+    LRP_HIP_CHECK(hipMemset(vel.p, 0, n_total * 4));
+    lr = lr_; clip = clip_; b1 = b1_; b2 = b2_; eps = eps_; iter = 0;
+    const size_t B = Bm, T = Tm, TB = B * T;
+    LRP_TRY(Vf.alloc(B * L * H * 4, total)); LRP_TRY(favg.alloc(B * D * 4, total)); LRP_TRY(glob.alloc(B * E * 4, total));
+    LRP_TRY(proj.alloc(B * L * H * 4, total)); LRP_TRY(Xall.alloc(TB * 2 * E * 4, total)); LRP_TRY(Z.alloc(TB * 5 * H * 4, total));
+    LRP_TRY(Gt.alloc(TB * 4 * H * 4, total));
+    for (DevBuf* d : {&Cst, &Hst, &TC, &SU, &Sst, &HW, &SW, &CTX, &OUTm, &dOUTm, &DZS, &DHW}) LRP_TRY(d->alloc(TB * H * 4, total));
+    LRP_TRY(ALPHA.alloc(TB * L * 4, total)); LRP_TRY(BETA.alloc(TB * 4, total));
+    LRP_TRY(logits.alloc(TB * V * 4, total)); LRP_TRY(part.alloc(TB * 2 * 4, total)); LRP_TRY(losses.alloc(16, total));
+    for (DevBuf* d : {&dHtot, &dS, &dH, &dC, &dVacc}) LRP_TRY(d->alloc(B * H * 4, total));
+    LRP_TRY(DZ.alloc(TB * 5 * H * 4, total)); LRP_TRY(dProj.alloc(B * L * H * 4, total)); LRP_TRY(dVf.alloc(B * L * H * 4, total));
+    LRP_TRY(dX.alloc(TB * 2 * E * 4, total)); LRP_TRY(dglob.alloc(B * E * 4, total)); LRP_TRY(dfavg.alloc(B * D * 4, total));
+    LRP_TRY(dF.alloc(B * L * D * 4, total));
+    ws_floats = (size_t)16 << 20;
+    LRP_TRY(ws.alloc(ws_floats * 4, total));
+    std::vector<int> id(Bm);
+    for (int i = 0; i < Bm; ++i) id[i] = i;
+    LRP_TRY(ident.alloc(Bm * sizeof(int), total));
+    LRP_HIP_CHECK(hipMemcpy(ident.p, id.data(), Bm * sizeof(int), hipMemcpyHostToDevice));
+    LRP_TRY(enc.enable_keep_acts(total));
+    ready = true;
+    stepped = false;
+    return LRP_OK;
+  }
+
+  int mm(bool ta, bool tb, int M, int N, long K, const float* A, long lda, const float* Bp, long ldb, float* C, long ldc, bool acc,
+         hipStream_t st) {
+    SgemmArgs a{};
+    a.A = A; a.B = Bp; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.transA = ta; a.transB = tb; a.accumulate = acc;
+    LRP_HIP_CHECK(sgemm(a, ws.as<float>(), ws_floats, st));
+    return LRP_OK;
+  }
+  static unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 4096); }
+
+  // One step: gradients of 0.5 CE(y, logits) + 0.5 CE(y, logits * lrp_weight) for the B images last encoded.
+  // cap_in (B, T) embedding rows, y_idx (B, T) class index or -1, lrp_weight (B, T, V); masks null = no dropout:
+  // m_if (B, L, H), m_glob (B, E), m_out (B, T, H).  grads_dev: n_total floats (caller's).  losses_dev: 3 floats.
+  int step(Encoder& enc, const float* feat, int B, int T, const int* cap_in, const int* y_idx, const float* lrp_weight,
+           const float* m_if, const float* m_glob, const float* m_out, float* grads, float* losses_dev, hipStream_t st) {
+    if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
+    if (B < 1 || B > Bm || T < 2 || T > Tm) return fail(LRP_ERR_INVALID, "B=%d / T=%d outside [1,%d] / [2,%d]", B, T, Bm, Tm);
+    if (enc.encoded < B || enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run (after lrp_train_begin) on the batch first");
+    for (size_t li = 0; li + 1 < enc.layers.size(); ++li)
+      if (!enc.layers[li].pool_after && !enc.layers[li].Akeep.p) return fail(LRP_ERR_STATE, "activations were not kept");
+    const size_t TB = (size_t)T * B, BH = (size_t)B * H;
+    float *vf = Vf.as<float>(), *pj = proj.as<float>(), *x = Xall.as<float>(), *z = Z.as<float>();
+    auto g = [&](const char* nm) { return grads + off(nm); };
+    // ---------------- forward
+    LRP_TRY(mm(false, false, B * L, H, D, feat, D, W("image_features_W"), H, vf, H, false, st));
+    hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, vf, W("image_features_b"), m_if,
+                       (size_t)B * L, H);
+    hipLaunchKernelGGL(tr_mean_rows_kernel, dim3(B), dim3(256), 0, st, feat, favg.as<float>(), L, D);
+    LRP_TRY(mm(false, false, B, E, D, favg.as<float>(), D, W("global_W"), E, glob.as<float>(), E, false, st));
+    hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, glob.as<float>(), W("global_b"), m_glob,
+                       (size_t)B, E);
+    LRP_TRY(mm(false, false, B * L, H, H, vf, H, W("Wv"), H, pj, H, false, st));
+    hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), cap_in, x, B, T, E);
+    LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("lstm_Wi"), 4 * H, z, 5 * H, false, st));
+    LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("Wx"), H, z + 4 * H, 5 * H, false, st));
+    const size_t att_fwd_lds = (size_t)(L + 8) * 4, att_bwd_lds = (size_t)(2 * L + H + 8) * 4;
+    for (int t = 0; t < T; ++t) {
+      float* zt = z + (size_t)t * B * 5 * H;
+      const float* hp = t > 0 ? Hst.as<float>() + (size_t)(t - 1) * BH : nullptr;
+      if (t > 0) {
+        LRP_TRY(mm(false, false, B, 4 * H, H, hp, H, W("lstm_Wh"), 4 * H, zt, 5 * H, true, st));
+        LRP_TRY(mm(false, false, B, H, H, hp, H, W("Wh"), H, zt + 4 * H, 5 * H, true, st));
+      }
+      hipLaunchKernelGGL(tr_cell_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, zt, W("lstm_b"),
+                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, Gt.as<float>() + (size_t)t * B * 4 * H,
+                         Cst.as<float>() + t * BH, Hst.as<float>() + t * BH, TC.as<float>() + t * BH, SU.as<float>() + t * BH,
+                         Sst.as<float>() + t * BH, B, H);
+      LRP_TRY(mm(false, false, B, H, H, Hst.as<float>() + t * BH, H, W("Wg"), H, HW.as<float>() + t * BH, H, false, st));
+      LRP_TRY(mm(false, false, B, H, H, Sst.as<float>() + t * BH, H, W("Ws"), H, SW.as<float>() + t * BH, H, false, st));
+      hipLaunchKernelGGL(tr_attention_fwd_kernel, dim3(B), dim3(256), att_fwd_lds, st, pj, vf, HW.as<float>() + t * BH,
+                         SW.as<float>() + t * BH, W("V"), Hst.as<float>() + t * BH, Sst.as<float>() + t * BH, m_out,
+                         ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, CTX.as<float>() + t * BH,
+                         OUTm.as<float>() + t * BH, L, H, T, t);
+    }
+    LRP_HIP_CHECK(hipGetLastError());
+    float* lg = logits.as<float>();
+    LRP_TRY(mm(false, false, (int)TB, V, H, OUTm.as<float>(), H, W("output_W"), V, lg, V, false, st));
+    const float scale = 1.f / (float)((size_t)B * (T - 1));
+    hipLaunchKernelGGL(tr_loss_kernel, dim3((unsigned)TB), dim3(256), 0, st, lg, W("output_b"), lrp_weight, y_idx, part.as<float>(), B, T, V,
+                       scale);
+    hipLaunchKernelGGL(tr_loss_final_kernel, dim3(1), dim3(64), 0, st, part.as<float>(), (int)TB, scale, losses.as<float>());
+    LRP_HIP_CHECK(hipGetLastError());
+    if (losses_dev) LRP_HIP_CHECK(hipMemcpyAsync(losses_dev, losses.p, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // ---------------- backward: output layer
+    float* wsf = ws.as<float>();
+    LRP_TRY(mm(true, false, H, V, (long)TB, OUTm.as<float>(), H, lg, V, g("output_W"), V, false, st));
+    LRP_HIP_CHECK(colsum(lg, V, (long)TB, V, g("output_b"), 0, wsf, ws_floats, st));
+    LRP_TRY(mm(false, true, (int)TB, H, V, lg, V, W("output_W"), V, dOUTm.as<float>(), H, false, st));
+    LRP_HIP_CHECK(hipMemsetAsync(dProj.p, 0, (size_t)B * L * H * 4, st));
+    LRP_HIP_CHECK(hipMemsetAsync(dVf.p, 0, (size_t)B * L * H * 4, st));
+    LRP_HIP_CHECK(hipMemsetAsync(dVacc.p, 0, BH * 4, st));
+    LRP_HIP_CHECK(hipMemsetAsync(dC.p, 0, BH * 4, st));
+    float* dz = DZ.as<float>();
+    for (int t = T - 1; t >= 0; --t) {
+      hipLaunchKernelGGL(tr_attention_bwd_kernel, dim3(B), dim3(256), att_bwd_lds, st, pj, vf, HW.as<float>() + t * BH,
+                         SW.as<float>() + t * BH, W("V"), Sst.as<float>() + t * BH, CTX.as<float>() + t * BH,
+                         ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, dOUTm.as<float>() + t * BH, m_out,
+                         t == T - 1 ? (const float*)nullptr : dH.as<float>(), dHtot.as<float>(), dS.as<float>(),
+                         DZS.as<float>() + t * BH, DHW.as<float>() + t * BH, dProj.as<float>(), dVf.as<float>(), dVacc.as<float>(), L, H,
+                         T, t);
+      LRP_TRY(mm(false, true, B, H, H, DZS.as<float>() + t * BH, H, W("Ws"), H, dS.as<float>(), H, true, st));
+      LRP_TRY(mm(false, true, B, H, H, DHW.as<float>() + t * BH, H, W("Wg"), H, dHtot.as<float>(), H, true, st));
+      float* dzt = dz + (size_t)t * B * 5 * H;
+      hipLaunchKernelGGL(tr_cell_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, Gt.as<float>() + (size_t)t * B * 4 * H,
+                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, TC.as<float>() + t * BH,
+                         SU.as<float>() + t * BH, dHtot.as<float>(), dS.as<float>(), dC.as<float>(), dzt, B, H);
+      if (t > 0) {
+        LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("lstm_Wh"), 4 * H, dH.as<float>(), H, false, st));
+        LRP_TRY(mm(false, true, B, H, H, dzt + 4 * H, 5 * H, W("Wh"), H, dH.as<float>(), H, true, st));
+      }
+    }
+    LRP_HIP_CHECK(hipGetLastError());
+    // ---------------- weight gradients of the recurrent part, K = (t, b) rows
+    float* dx = dX.as<float>();
+    LRP_TRY(mm(false, true, (int)TB, 2 * E, 4 * H, dz, 5 * H, W("lstm_Wi"), 4 * H, dx, 2 * E, false, st));
+    LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + 4 * H, 5 * H, W("Wx"), H, dx, 2 * E, true, st));
+    LRP_TRY(mm(true, false, 2 * E, 4 * H, (long)TB, x, 2 * E, dz, 5 * H, g("lstm_Wi"), 4 * H, false, st));
+    LRP_TRY(mm(true, false, 2 * E, H, (long)TB, x, 2 * E, dz + 4 * H, 5 * H, g("Wx"), H, false, st));
+    const long Kr = (long)(T - 1) * B;
+    LRP_TRY(mm(true, false, H, 4 * H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H, 5 * H, g("lstm_Wh"), 4 * H, false, st));
+    LRP_TRY(mm(true, false, H, H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H + 4 * H, 5 * H, g("Wh"), H, false, st));
+    LRP_HIP_CHECK(colsum(dz, 5 * H, (long)TB, 4 * H, g("lstm_b"), 0, wsf, ws_floats, st));
+    LRP_TRY(mm(true, false, H, H, (long)TB, Hst.as<float>(), H, DHW.as<float>(), H, g("Wg"), H, false, st));
+    LRP_TRY(mm(true, false, H, H, (long)TB, Sst.as<float>(), H, DZS.as<float>(), H, g("Ws"), H, false, st));
+    LRP_HIP_CHECK(colsum(dVacc.as<float>(), H, B, H, g("V"), 0, wsf, ws_floats, st));
+    LRP_TRY(mm(true, false, H, H, (long)B * L, vf, H, dProj.as<float>(), H, g("Wv"), H, false, st));
+    LRP_TRY(mm(false, true, B * L, H, H, dProj.as<float>(), H, W("Wv"), H, dVf.as<float>(), H, true, st));
+    LRP_HIP_CHECK(hipMemsetAsync(g("embedding"), 0, (size_t)V * E * 4, st));
+    hipLaunchKernelGGL(tr_embedding_bwd_kernel, dim3((unsigned)TB), dim3(256), 0, st, dx, cap_in, g("embedding"), B, T, E);
+    // global feature branch
+    hipLaunchKernelGGL(tr_dglob_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, dx, dglob.as<float>(), B, T, E);
+    hipLaunchKernelGGL(tr_relu_mask_bwd_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, dglob.as<float>(), glob.as<float>(), m_glob,
+                       (size_t)B * E);
+    LRP_TRY(mm(true, false, D, E, B, favg.as<float>(), D, dglob.as<float>(), E, g("global_W"), E, false, st));
+    LRP_HIP_CHECK(colsum(dglob.as<float>(), E, B, E, g("global_b"), 0, wsf, ws_floats, st));
+    LRP_TRY(mm(false, true, B, D, E, dglob.as<float>(), E, W("global_W"), E, dfavg.as<float>(), D, false, st));
+    // image_features branch
+    hipLaunchKernelGGL(tr_relu_mask_bwd_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, dVf.as<float>(), vf, m_if,
+                       (size_t)B * L * H);
+    LRP_TRY(mm(true, false, D, H, (long)B * L, feat, D, dVf.as<float>(), H, g("image_features_W"), H, false, st));
+    LRP_HIP_CHECK(colsum(dVf.as<float>(), H, (long)B * L, H, g("image_features_b"), 0, wsf, ws_floats, st));
+    LRP_TRY(mm(false, true, B * L, D, H, dVf.as<float>(), H, W("image_features_W"), H, dF.as<float>(), D, false, st));
+    hipLaunchKernelGGL(tr_mean_rows_bwd_kernel, dim3(grid_for((size_t)B * L * D)), dim3(256), 0, st, dF.as<float>(), dfavg.as<float>(), L, D,
+                       (size_t)B * L * D);
+    LRP_HIP_CHECK(hipGetLastError());
+    // ---------------- encoder: Gradient walk + one weight-gradient product per layer and tap
+    std::function<int(int, const float*)> hook = [&](int li, const float* dZ) -> int {
+      const ConvLayer& Ly = enc.layers[li];
+      const long K = (long)B * Ly.H * Ly.W;
+      float* gw = grads + params[2 * li].off;
+      for (int t = 0; t < 9; ++t) {
+        SgemmArgs a{};
+        a.A = enc.layer_input(li); a.lda = Ly.cin; a.B = dZ; a.ldb = Ly.cout; a.C = gw + (size_t)t * Ly.cin * Ly.cout; a.ldc = Ly.cout;
+        a.M = Ly.cin; a.N = Ly.cout; a.K = K; a.transA = 1; a.transB = 0;
+        a.gather = 1; a.gH = Ly.H; a.gW = Ly.W; a.dy = t / 3 - 1; a.dx = t % 3 - 1;
+        LRP_HIP_CHECK(sgemm(a, wsf, ws_floats, st));
+      }
+      LRP_HIP_CHECK(colsum(dZ, Ly.cout, K, Ly.cout, grads + params[2 * li + 1].off, 0, wsf, ws_floats, st));
+      return LRP_OK;
+    };
+    LRP_TRY(enc.explain(B, ident.as<int>(), dF.as<float>(), nullptr, st, 1, &hook));
+    stepped = true;
+    return LRP_OK;
+  }
+
+  // keras Adam(lr, clipvalue) on the master weights, then the engine's operand copies are rebuilt from them
+  int apply(Encoder& enc, Decoder& dec, const float* grads, int64_t* total, hipStream_t st) {
+    if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
+    ++iter;
+    const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)b2, (double)iter)) / (1.0 - std::pow((double)b1, (double)iter));
+    hipLaunchKernelGGL(tr_adam_kernel, dim3(grid_for(n_total)), dim3(256), 0, st, master.as<float>(), grads, mom.as<float>(),
+                       vel.as<float>(), n_total, (float)lr_t, clip, b1, b2, eps);
+    LRP_HIP_CHECK(hipGetLastError());
+    return sync_engine(enc, dec, total, st);
+  }
+
+  int sync_engine(Encoder& enc, Decoder& dec, int64_t* total, hipStream_t st) {
+    LRP_HIP_CHECK(hipMemcpyAsync(host.data(), master.p, n_total * 4, hipMemcpyDeviceToHost, st));
+    LRP_HIP_CHECK(hipStreamSynchronize(st));
+    if (enc.gates_pending) {                       // the side stream may still read the operand copies we replace
+      LRP_HIP_CHECK(hipEventSynchronize(enc.ev_gates));
+      enc.gates_pending = false;
+    }
+    size_t pi = 0;
+    for (size_t li = 0; li < enc.layers.size(); ++li, pi += 2) {
+      LRP_TRY(enc.set_conv_weight((int)li, host.data() + params[pi].off, total));
+      LRP_TRY(enc.set_conv_bias((int)li, host.data() + params[pi + 1].off, total));
+    }
+    for (; pi < params.size(); ++pi)
+      LRP_TRY(dec.set_weight(params[pi].name, host.data() + params[pi].off, (int)params[pi].shape.size(), params[pi].shape.data(), total));
+    enc.encoded = 0;                               // caches belong to the old weights
+    return LRP_OK;
+  }
+};
+
+}  // namespace lrp

@@ -200,6 +200,65 @@ class LRPEngine(object):
                                               self._stream()))
         return out
 
+    # ------------------------------------------------------------------ fine-tune step
+    def train_begin(self, lr=2e-4, clipvalue=0.01, beta1=0.9, beta2=0.999, eps=1e-7):
+        """Adam(lr, clipvalue) as `ImgCaptioningAdaptiveAttentionLRPInferenceModel.build` compiles it (M:1370);
+        returns the layout of the flat parameter / gradient buffers: {name: (offset, size)}."""
+        _capi.check(self._lib.lrp_train_begin(self._h, C.c_float(lr), C.c_float(clipvalue), C.c_float(beta1), C.c_float(beta2),
+                                              C.c_float(eps)))
+        self.train_flat_size = int(self._lib.lrp_train_flat_size(self._h))
+        self.train_layout = {}
+        for i in range(int(self._lib.lrp_train_num_params(self._h))):
+            nm, off, n = C.c_char_p(), C.c_int64(), C.c_int64()
+            _capi.check(self._lib.lrp_train_param_info(self._h, i, C.byref(nm), C.byref(off), C.byref(n)))
+            self.train_layout[nm.value.decode()] = (int(off.value), int(n.value))
+        self.n_images = 0
+        return self.train_layout
+
+    def train_step(self, cap_in, y_idx, lrp_weight, masks=None, grads=None):
+        """Gradients of the two-headed loss for the images last encoded.  cap_in / y_idx (B, T) ints (y -1 = no label),
+        lrp_weight (B, T, V).  masks: dict with optional 'image_features' (B, L, H), 'global' (B, E), 'output' (B, T, H).
+        Returns (grads flat float32 device tensor, losses (3,) device tensor = total, head 1, head 2)."""
+        masks = masks or {}
+        ci = self._dev(cap_in, torch.int32)
+        yi = self._dev(y_idx, torch.int32)
+        B, T = ci.shape
+        lw = self._dev(lrp_weight).reshape(B, T, self.V)
+        if tuple(yi.shape) != (B, T):
+            raise ValueError("y_idx must have the shape of cap_in")
+        def m(key, shape):
+            v = masks.get(key)
+            if v is None:
+                return None
+            v = self._dev(v)
+            if tuple(v.shape) != shape:
+                raise ValueError("mask '%s' must be %s" % (key, shape))
+            return v
+        mi, mg, mo = m("image_features", (B, self.L, self.H)), m("global", (B, self.E)), m("output", (B, T, self.H))
+        for k in masks:
+            if k not in ("image_features", "global", "output") and masks[k] is not None:
+                raise NotImplementedError("dropout mask '%s' is not supported by the fine-tune step" % k)
+        if grads is None:
+            grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
+        losses = torch.empty(3, dtype=torch.float32, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(grads), p(losses),
+                                             self._stream()))
+        return grads, losses
+
+    def train_apply(self, grads):
+        """Adam update of the master weights from the (all-reduced) flat gradient; cached images are dropped."""
+        _capi.check(self._lib.lrp_train_apply(self._h, C.c_void_p(grads.data_ptr()), self._stream()))
+        self.n_images = 0
+        self.captions = None
+
+    def train_weights(self):
+        """Master weights as {name: float32 ndarray} (checkpointing / tests)."""
+        flat = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
+        _capi.check(self._lib.lrp_train_get_master(self._h, C.c_void_p(flat.data_ptr()), self._stream()))
+        f = flat.cpu().numpy()
+        return {k: f[o:o + n].copy() for k, (o, n) in self.train_layout.items()}
+
     # ------------------------------------------------------------------ caption generation (SURVEY 8f-4)
     def gen_begin(self, n_rows):
         """Start an incremental decode over the first n_rows cached feature slots (one hypothesis per row)."""

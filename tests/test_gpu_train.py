@@ -1,0 +1,87 @@
+"""Fine-tune step against oracle/train_ref.py (torch float64 autograd) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from lrp_imagecaptioning_amd.synthetic import adaptive_weights, vgg_weights
+
+pytestmark = pytest.mark.gpu
+
+CFG = [("c1", 3, 8, True), ("c2", 8, 16, True), ("c3", 16, 16, False), ("c4", 16, 16, False)]
+HW, L, D, H, V = 16, 16, 16, 16, 40
+
+
+def rel_l1(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64).reshape(b.shape) - b).sum() / max(np.abs(b).sum(), 1e-30))
+
+
+def _case(seed=0, B=3, Tn=5):
+    rs = np.random.RandomState(seed)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update(adaptive_weights(rs, L, D, H, H, V))
+    X = (rs.uniform(0, 255, size=(B, HW, HW, 3)) - 110).astype(np.float32) / 64
+    caps = [[int(c) for c in rs.randint(3, V + 1, size=Tn - 1)] + [1] for _ in range(B)]
+    cap_in = np.array([[2 - 1] + [c - 1 for c in cap[:-1]] for cap in caps], dtype=np.int32)
+    y = np.array([[c - 1 for c in cap] for cap in caps], dtype=np.int32)
+    y[1, -2:] = -1
+    cap_in[2, 3] = cap_in[0, 1]                                       # a repeated embedding row
+    lw = (1 + rs.uniform(0, 1, size=(B, Tn, V)) * (rs.uniform(size=(B, Tn, V)) < 0.2)).astype(np.float32)
+    p = 0.5
+    mk = lambda *s: ((rs.uniform(size=s) >= p) / (1 - p)).astype(np.float32)
+    masks = {"image_features": mk(B, L, H), "global": mk(B, H), "output": mk(B, Tn, H)}
+    return w, X, cap_in, y, lw, masks
+
+
+def _engine(w, B):
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    eng = LRPEngine(decoder="adaptive", cnn_cfg=CFG, img_hw=(HW, HW), L=L, D=D, H=H, E=H, V=V, max_images=4, max_tokens=8,
+                    max_caption_len=6)
+    eng.set_weights(w)
+    return eng
+
+
+@pytest.mark.parametrize("with_masks", [False, True])
+def test_gradients_match_oracle(with_masks):
+    from oracle import train_ref as T
+    w, X, cap_in, y, lw, masks = _case()
+    if not with_masks:
+        masks = None
+    eng = _engine(w, len(X))
+    layout = eng.train_begin(lr=1e-3, clipvalue=0.01)
+    assert set(layout) == set(T.param_names(CFG))
+    eng.encode_images(X)
+    grads, losses = eng.train_step(cap_in, y, lw, masks)
+    total, l1, l2, g, _ = T.loss_and_grads(w, CFG, X, cap_in, y, lw, masks)
+    np.testing.assert_allclose(losses.cpu().numpy(), [total, l1, l2], rtol=2e-5)
+    gf = grads.cpu().numpy()
+    worst = {}
+    for name, (off, n) in layout.items():
+        worst[name] = rel_l1(gf[off:off + n], g[name])
+    bad = {k: v for k, v in worst.items() if not v < 2e-4}
+    assert not bad, bad
+
+
+def test_adam_step_matches_oracle_and_engine_follows():
+    from oracle import train_ref as T
+    w, X, cap_in, y, lw, masks = _case(3)
+    eng = _engine(w, len(X))
+    layout = eng.train_begin(lr=1e-3, clipvalue=0.01)
+    eng.encode_images(X)
+    grads, _ = eng.train_step(cap_in, y, lw, masks)
+    eng.train_apply(grads)
+    new = eng.train_weights()
+    _, _, _, g, _ = T.loss_and_grads(w, CFG, X, cap_in, y, lw, masks)
+    for name in layout:
+        p1, _, _ = T.adam_clipvalue_step(np.asarray(w[name], np.float64).ravel(), g[name].ravel(), 0.0, 0.0, 1, 1e-3, 0.01)
+        # Adam's first step is lr * sign(g) wherever |g| >> eps: compare where the oracle gradient is not tiny
+        big = np.abs(g[name].ravel()) > 1e-5
+        np.testing.assert_allclose(new[name][big], p1[big], rtol=0, atol=2e-6)
+    # the explanation path now runs on the updated weights
+    from oracle import cnn_lrp_ref as Cn
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(len(X), -1, D)
+    ref = Cn.forward(Cn.vgg_layers({k: new[k].reshape(np.shape(w[k])) for k in w}, CFG), X).reshape(len(X), -1, D)
+    assert rel_l1(feat, ref) < 1e-5
+    with pytest.raises(ValueError):
+        eng.train_step(cap_in[:, :1], y[:, :1], lw[:, :1])           # T < 2
