@@ -280,7 +280,8 @@ int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, in
  * computes lrp_weight with the explain entry points above, then:
  *   lrp_train_step : training-mode decoder forward on the cached features, loss 0.5 CE(y, logits[:, :-1]) +
  *                    0.5 CE(y, (logits * lrp_weight)[:, :-1]) (M:95-103, :1370-1373), backward through the decoder and
- *                    the encoder (all layers trainable, M:1332-1333) -> grads_dev, losses_dev = (total, head 1, head 2)
+ *                    the encoder (all layers trainable, M:1332-1333) -> grads_dev, losses_dev (5 floats) = what train_on_batch
+ *                    returns: total, loss head 1, loss head 2, accuracy head 1, accuracy head 2 (M:105-124)
  *   (the host all-reduces grads_dev across ranks)
  *   lrp_train_apply: Adam(lr, clipvalue) as keras does (clip element-wise, then the moments; epsilon 1e-7) on the fp32
  *                    master weights; the engine's operand copies are rebuilt, cached images are dropped.

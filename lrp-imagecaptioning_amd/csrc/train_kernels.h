@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void tr_attention_fwd_kernel(const float* __re
   }
 }
 // Two-headed loss (M:95-103, :1364-1373) of one (t, b) row, in place: Z row (logits before the bias) -> d loss / d logits.
-// part[row] = (CE head 1, CE head 2).  Rows of the last time step and rows without a label give zero.
+// part[row] = (CE head 1, CE head 2, hit head 1, hit head 2, labelled) — hit = the label is the arg-max (M:105-124).
+// Rows of the last time step and rows without a label give zero.
 __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, const float* __restrict__ bout, const float* __restrict__ lw,
                                                       const int* __restrict__ y_idx, float* __restrict__ part, int B, int T, int V,
                                                       float scale) {
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, con
   const int y = y_idx[b * T + t];
   if (t == T - 1 || y < 0) {
     for (int k = tid; k < V; k += 256) z[k] = 0.f;
-    if (tid == 0) { part[2 * row] = 0.f; part[2 * row + 1] = 0.f; }
+    if (tid < 5) part[5 * row + tid] = 0.f;
     return;
   }
   const float* w = lw + ((size_t)b * T + t) * V;
@@ -177,8 +178,11 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, con
   const float zy = z[y] + bout[y];
   __syncthreads();
   if (tid == 0) {
-    part[2 * row] = -(zy - m1 - logf(s1));
-    part[2 * row + 1] = -(zy * w[y] - m2 - logf(s2));
+    part[5 * row] = -(zy - m1 - logf(s1));
+    part[5 * row + 1] = -(zy * w[y] - m2 - logf(s2));
+    part[5 * row + 2] = zy >= m1 ? 1.f : 0.f;
+    part[5 * row + 3] = zy * w[y] >= m2 ? 1.f : 0.f;
+    part[5 * row + 4] = 1.f;
   }
   for (int k = tid; k < V; k += 256) {
     const float x = z[k] + bout[k];
@@ -186,13 +190,18 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, con
     z[k] = scale * (0.5f * (expf(x - m1) / s1 - d) + 0.5f * w[k] * (expf(x * w[k] - m2) / s2 - d));
   }
 }
-// losses[0..2] = (0.5 l1 + 0.5 l2, l1, l2), rows summed in index order
+// losses[0..4] = (0.5 l1 + 0.5 l2, l1, l2, accuracy head 1, accuracy head 2) — what train_on_batch returns
+// (train.py:578-579); rows summed in index order
 __global__ void tr_loss_final_kernel(const float* __restrict__ part, int rows, float scale, float* __restrict__ losses) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double a = 0.0, c = 0.0;
-  for (int r = 0; r < rows; ++r) { a += part[2 * r]; c += part[2 * r + 1]; }
+  double a = 0.0, c = 0.0, h1 = 0.0, h2 = 0.0, n = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    a += part[5 * r]; c += part[5 * r + 1]; h1 += part[5 * r + 2]; h2 += part[5 * r + 3]; n += part[5 * r + 4];
+  }
   losses[1] = (float)(a * scale); losses[2] = (float)(c * scale);
   losses[0] = 0.5f * losses[1] + 0.5f * losses[2];
+  losses[3] = n > 0.0 ? (float)(h1 / n) : 0.f;
+  losses[4] = n > 0.0 ? (float)(h2 / n) : 0.f;
 }
 
 // Backward of tr_attention_fwd_kernel for one step.  In: dOUTm row of the step, carry dH.  Out: dHtot = dH + dout,

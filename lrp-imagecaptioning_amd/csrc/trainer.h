@@ -111,7 +111,7 @@ struct Trainer {
     LRP_TRY(Gt.alloc(TB * 4 * H * 4, total));
     for (DevBuf* d : {&Cst, &Hst, &TC, &SU, &Sst, &HW, &SW, &CTX, &OUTm, &dOUTm, &DZS, &DHW}) LRP_TRY(d->alloc(TB * H * 4, total));
     LRP_TRY(ALPHA.alloc(TB * L * 4, total)); LRP_TRY(BETA.alloc(TB * 4, total));
-    LRP_TRY(logits.alloc(TB * V * 4, total)); LRP_TRY(part.alloc(TB * 2 * 4, total)); LRP_TRY(losses.alloc(16, total));
+    LRP_TRY(logits.alloc(TB * V * 4, total)); LRP_TRY(part.alloc(TB * 5 * 4, total)); LRP_TRY(losses.alloc(32, total));
     for (DevBuf* d : {&dHtot, &dS, &dH, &dC, &dVacc}) LRP_TRY(d->alloc(B * H * 4, total));
     LRP_TRY(DZ.alloc(TB * 5 * H * 4, total)); LRP_TRY(dProj.alloc(B * L * H * 4, total)); LRP_TRY(dVf.alloc(B * L * H * 4, total));
     LRP_TRY(dX.alloc(TB * 2 * E * 4, total)); LRP_TRY(dglob.alloc(B * E * 4, total)); LRP_TRY(dfavg.alloc(B * D * 4, total));
@@ -140,7 +140,7 @@ struct Trainer {
 
   // One step: gradients of 0.5 CE(y, logits) + 0.5 CE(y, logits * lrp_weight) for the B images last encoded.
   // cap_in (B, T) embedding rows, y_idx (B, T) class index or -1, lrp_weight (B, T, V); masks null = no dropout:
-  // m_if (B, L, H), m_glob (B, E), m_out (B, T, H).  grads_dev: n_total floats (caller's).  losses_dev: 3 floats.
+  // m_if (B, L, H), m_glob (B, E), m_out (B, T, H).  grads_dev: n_total floats (caller's).  losses_dev: 5 floats.
   int step(Encoder& enc, const float* feat, int B, int T, const int* cap_in, const int* y_idx, const float* lrp_weight,
            const float* m_if, const float* m_glob, const float* m_out, float* grads, float* losses_dev, hipStream_t st) {
     if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
@@ -190,7 +190,7 @@ struct Trainer {
                        scale);
     hipLaunchKernelGGL(tr_loss_final_kernel, dim3(1), dim3(64), 0, st, part.as<float>(), (int)TB, scale, losses.as<float>());
     LRP_HIP_CHECK(hipGetLastError());
-    if (losses_dev) LRP_HIP_CHECK(hipMemcpyAsync(losses_dev, losses.p, 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (losses_dev) LRP_HIP_CHECK(hipMemcpyAsync(losses_dev, losses.p, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
     // ---------------- backward: output layer
     float* wsf = ws.as<float>();
     LRP_TRY(mm(true, false, H, V, (long)TB, OUTm.as<float>(), H, lg, V, g("output_W"), V, false, st));

@@ -218,7 +218,8 @@ class LRPEngine(object):
     def train_step(self, cap_in, y_idx, lrp_weight, masks=None, grads=None):
         """Gradients of the two-headed loss for the images last encoded.  cap_in / y_idx (B, T) ints (y -1 = no label),
         lrp_weight (B, T, V).  masks: dict with optional 'image_features' (B, L, H), 'global' (B, E), 'output' (B, T, H).
-        Returns (grads flat float32 device tensor, losses (3,) device tensor = total, head 1, head 2)."""
+        Returns (grads flat float32 device tensor, losses (5,) device tensor = total, loss head 1, loss head 2,
+        accuracy head 1, accuracy head 2: the list `train_on_batch` returns)."""
         masks = masks or {}
         ci = self._dev(cap_in, torch.int32)
         yi = self._dev(y_idx, torch.int32)
@@ -240,7 +241,7 @@ class LRPEngine(object):
                 raise NotImplementedError("dropout mask '%s' is not supported by the fine-tune step" % k)
         if grads is None:
             grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
-        losses = torch.empty(3, dtype=torch.float32, device=self.device)
+        losses = torch.empty(5, dtype=torch.float32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(grads), p(losses),
                                              self._stream()))

@@ -46,3 +46,21 @@ def broadcast_weights(weights_rank0, shapes, device_index, dist, src=0):
         flat = torch.empty(total, dtype=torch.float32, device=dev)
     dist.broadcast(flat, src=src)
     return unflatten_bundle(flat, shapes)
+
+
+def average_gradients(flat_grads, losses=None, group=None):
+    """Data-parallel fine-tune step: every rank holds the flat gradient of ITS shard's mean loss; with
+    equal shards the global-batch gradient is the mean over ranks.  One all-reduce over the whole flat buffer (a single
+    ~125 MB bucket for VGG16 + decoder: on xGMI rings few large transfers beat many small ones), in place."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grads, losses
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat_grads, losses
+    dist.all_reduce(flat_grads, group=group)
+    flat_grads /= world
+    if losses is not None:
+        dist.all_reduce(losses, group=group)
+        losses /= world
+    return flat_grads, losses

@@ -55,3 +55,49 @@ def test_broadcast_and_sharding_world2():
     assert s0["block1_conv1_W"] == (3, 3, 3, 8)
     assert (lo0, hi0, lo1, hi1) == (0, 5, 5, 10)       # contiguous, disjoint, complete
     assert t0 == t1 == 1.5                             # MAX over ranks
+
+
+def _train_worker(rank, world, port, q):
+    """Data-parallel fine-tune step: each rank differentiates its half of the batch (oracle arithmetic stands in for the
+    HIP step), `average_gradients` makes them the full-batch gradient."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lrp_imagecaptioning_amd.parallel import average_gradients
+    from lrp_imagecaptioning_amd.synthetic import adaptive_weights, vgg_weights
+    from oracle import train_ref as T
+    cfg = [("c1", 3, 8, True), ("c2", 8, 8, False)]
+    HW, L, D, H, V, B, Tn = 8, 16, 8, 8, 12, 4, 4
+    rs = np.random.RandomState(5)
+    w = vgg_weights(rs, cfg, bias_std=0.3)
+    w.update(adaptive_weights(rs, L, D, H, H, V))
+    X = rs.uniform(-2, 2, size=(B, HW, HW, 3)).astype(np.float32)
+    cap_in = rs.randint(0, V, size=(B, Tn))
+    y = rs.randint(0, V, size=(B, Tn))
+    lw = 1 + rs.uniform(0, 1, size=(B, Tn, V))
+    names = T.param_names(cfg)
+    flat = lambda g: torch.from_numpy(np.concatenate([g[k].ravel() for k in names]))
+    lo, hi = shard_range(B, world, rank)
+    tot, l1, l2, g, _ = T.loss_and_grads(w, cfg, X[lo:hi], cap_in[lo:hi], y[lo:hi], lw[lo:hi])
+    mine, losses = average_gradients(flat(g), torch.tensor([tot, l1, l2], dtype=torch.float64))
+    full = T.loss_and_grads(w, cfg, X, cap_in, y, lw)
+    err = float((mine - flat(full[3])).abs().sum() / flat(full[3]).abs().sum())
+    q.put((rank, err, float(losses[0]), full[0], float(mine.double().sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_average_world2_equals_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, loss, full_loss, _ in res:
+        assert err < 1e-12 and abs(loss - full_loss) < 1e-12
+    assert res[0][4] == res[1][4]                      # both ranks step with the same gradient
