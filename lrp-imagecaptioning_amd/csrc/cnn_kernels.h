@@ -142,6 +142,40 @@ __global__ __launch_bounds__(256) void split3_copy_kernel(const float* __restric
   }
 }
 
+// Device twins of the host weight packers (conv_igemm.h pack_conv_fwd / pack_conv_bwd / pack_frag64) for the fine-tune
+// step, whose weights change on the device every iteration.  dst [rows_total][taps * CP], zero padded.
+//   bwd = 0: row = output channel, k = tap * CP + ci       (dual: rows [Cout, 2 Cout) hold w+ of row - Cout)
+//   bwd = 1: row = input channel,  k = tap' * CP + co with the taps flipped (transposed conv as a conv)
+__global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restrict__ w, float* __restrict__ dst, int bwd, int Cin,
+                                                            int Cout, int CP, int rows_total, int dual, int pos_only) {
+  const int K = 9 * CP;
+  const size_t total = (size_t)rows_total * K;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    int row = (int)(i / K);
+    const int k = (int)(i % K), t = k / CP, c = k % CP;
+    bool pos = pos_only != 0;
+    float v = 0.f;
+    if (!bwd) {
+      if (dual && row >= Cout) { row -= Cout; pos = true; }
+      if (row < Cout && c < Cin) v = w[((size_t)t * Cin + c) * Cout + row];
+    } else {
+      if (row < Cin && c < Cout) v = w[((size_t)(8 - t) * Cin + row) * Cout + c];
+    }
+    dst[i] = (pos && !(v >= 0.f)) ? 0.f : v;
+  }
+}
+// split8-packed [64][K] -> fragment-major copy for the weights-in-registers kernel (pack_frag64)
+__global__ __launch_bounds__(256) void pack_frag64_dev_kernel(const float* __restrict__ src, float* __restrict__ dst, int CP) {
+  const int K = 9 * CP, cpt = CP / 32;
+  const size_t total = (size_t)cpt * 9 * 4 * 2 * 64;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int n = (int)(i & 63), hh = (int)((i >> 6) & 1), q = (int)((i >> 7) & 3);
+    const int kc = (int)(i >> 9), cc = kc / 9, t = kc % 9;
+    const int c = 4 * (q >> 1) + 2 * hh + (q & 1);
+    *reinterpret_cast<f32x4*>(dst + i * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)n * K + t * CP + cc * 32 + c * 4);
+  }
+}
+
 // Head of the reverse walk (KG:898-900): S_top = R_feat / safe(Z_top[img])
 __global__ __launch_bounds__(256) void top_divide_kernel(const f32x4* __restrict__ R, const f32x4* __restrict__ Ztop,
                                                          const int* __restrict__ row2img, f32x4* __restrict__ S,

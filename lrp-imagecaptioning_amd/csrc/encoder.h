@@ -272,6 +272,40 @@ struct Encoder {
     return LRP_OK;
   }
 
+  // Same operand copies as set_conv_weight, rebuilt in place from device weights (fine-tune step; li >= 1, buffers exist).
+  // tmp: scratch of at least conv_npad(cout) * 9 * conv_cinp(cin) floats.
+  int repack_conv_from_device(int li, const float* w_dev, const float* b_dev, float* tmp, hipStream_t st) {
+    ConvLayer& L = layers[li];
+    if (li < 1 || !L.have_w || !L.have_b) return fail(LRP_ERR_STATE, "layer %d has no operand copies to rebuild", li);
+    const int CPi = conv_cinp(L.cin), CPo = conv_cinp(L.cout);
+    const int Np2 = conv_npad(2 * L.cout), Npa = conv_npad(L.cout), Npb = conv_npad(L.cin);
+    auto pack = [&](float* dst, int bwd, int rows, int dual, int pos) {
+      const size_t tot = (size_t)rows * 9 * (bwd ? CPo : CPi);
+      hipLaunchKernelGGL(pack_conv_dev_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, w_dev, dst, bwd, L.cin, L.cout,
+                         bwd ? CPo : CPi, rows, dual, pos);
+    };
+    auto split = [&](const float* src, float* dst, size_t n) {
+      hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, st, src, dst, n / 8);
+    };
+    const size_t nf = (size_t)Npa * 9 * CPi, nb = (size_t)Npb * 9 * CPo;
+    pack(L.w_fwd.as<float>(), 0, Np2, 1, 0);
+    pack(L.w_fwd_a.as<float>(), 0, Npa, 0, 0);
+    pack(tmp, 0, Npa, 0, 1);
+    split(tmp, L.w_fwd_zs.as<float>(), nf);
+    hipLaunchKernelGGL(split3_copy_kernel, dim3(stream_grid(nf / 8)), dim3(256), 0, st, L.w_fwd_a.as<float>(), L.w_fwd_as.as<float>(),
+                       L.w_fwd_al.as<float>(), nf / 8);
+    pack(L.w_bwd.as<float>(), 1, Npb, 0, 1);
+    split(L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb);
+    if (L.w_bwd_frag.p)
+      hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_s.as<float>(),
+                         L.w_bwd_frag.as<float>(), CPo);
+    pack(L.w_bwd_full.as<float>(), 1, Npb, 0, 0);
+    LRP_HIP_CHECK(hipGetLastError());
+    LRP_HIP_CHECK(hipMemcpyAsync(L.bias.p, b_dev, (size_t)L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    L.raw_w.clear(); L.raw_b.clear();               // stale from here on (the trainer's master buffer is the truth)
+    return LRP_OK;
+  }
+
   int set_conv_bias(int li, const float* b, int64_t* total) {
     ConvLayer& L = layers[li];
     if (b != L.raw_b.data()) L.raw_b.assign(b, b + L.cout);

@@ -25,6 +25,7 @@ struct SgemmArgs {
   int ksplit; long kchunk; // blockIdx.z = slice of K; partials go to ws[slice][M][N] when ksplit > 1
   float* ws;
   int gather, gH, gW, dy, dx;   // transA only: row r = (n*gH + y)*gW + x reads row r + dy*gW + dx, zero outside the image
+  int taps; long tapC;          // gather with taps = 9: blockIdx.z / ksplit = tap (dy, dx from it), C advances by tapC per tap
   int vecA, vecB;          // 16 B loads allowed (alignment checked on the host)
 };
 
@@ -46,7 +47,8 @@ __device__ __forceinline__ void sg_fetch(const float* __restrict__ P, long ld, i
       long src = k;
       bool ok = k < k_end;
       if (is_a && a.gather && ok) {
-        const int x = (int)(k % a.gW), y = (int)((k / a.gW) % a.gH);
+        const unsigned ku = (unsigned)k, rowi = ku / (unsigned)a.gW;      // (pixel counts stay far below 2^31)
+        const int x = (int)(ku - rowi * (unsigned)a.gW), y = (int)(rowi % (unsigned)a.gH);
         ok = (unsigned)(y + a.dy) < (unsigned)a.gH && (unsigned)(x + a.dx) < (unsigned)a.gW;
         src = k + (long)a.dy * a.gW + a.dx;
       }
@@ -95,7 +97,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
   __shared__ float Bs[2][SG_BK * SG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * SG_BM, n0 = blockIdx.x * SG_BN;
-  const long kb = (long)blockIdx.z * a.kchunk;
+  const int tap = a.taps > 1 ? (int)blockIdx.z / a.ksplit : 0, slice = a.taps > 1 ? (int)blockIdx.z % a.ksplit : (int)blockIdx.z;
+  if (a.taps > 1) { a.dy = tap / 3 - 1; a.dx = tap % 3 - 1; }
+  const long kb = (long)slice * a.kchunk;
   const long ke = kb + a.kchunk < a.K ? kb + a.kchunk : a.K;
   sg_f32x16 acc[2][2];
 #pragma unroll
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
     }
     __syncthreads();
   }
-  float* C = a.ksplit > 1 ? a.ws + (size_t)blockIdx.z * a.M * a.N : a.C;
+  float* C = a.ksplit > 1 ? a.ws + (size_t)blockIdx.z * a.M * a.N : a.C + (size_t)tap * a.tapC;
   const long ldc = a.ksplit > 1 ? a.N : a.ldc;
   const bool accum = a.ksplit > 1 ? false : a.accumulate != 0;
 #pragma unroll
@@ -158,14 +162,16 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
 #endif
 }
 
-// C[m][n] (+)= sum_s ws[s][m][n], slices added in index order
+// C[tap][m][n] (+)= sum_s ws[tap][s][m][n], slices added in index order
 __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
-                                                           long ldc, int ksplit, int accumulate) {
-  const size_t mn = (size_t)M * N;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn; i += (size_t)gridDim.x * 256) {
+                                                           long ldc, int ksplit, int accumulate, int taps, long tapC) {
+  const size_t mn = (size_t)M * N, all = mn * taps;
+  for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < all; j += (size_t)gridDim.x * 256) {
+    const size_t tap = j / mn, i = j - tap * mn;
+    const float* w = ws + tap * ksplit * mn + i;
     float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += ws[(size_t)k * mn + i];
-    float* p = C + (long)(i / N) * ldc + (i % N);
+    for (int k = 0; k < ksplit; ++k) s += w[(size_t)k * mn];
+    float* p = C + tap * tapC + (long)(i / N) * ldc + (i % N);
     *p = accumulate ? *p + s : s;
   }
 }
@@ -179,19 +185,24 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
   const int gx = (a.N + SG_BN - 1) / SG_BN, gy = (a.M + SG_BM - 1) / SG_BM;
   int ks = 1;
+  const int taps = a.gather && a.taps > 1 ? a.taps : 1;
+  a.taps = taps;
   const long steps = (a.K + SG_BK - 1) / SG_BK;
-  if (ws && (long)gx * gy < 512 && steps >= 64) {
-    ks = (int)((1024 + (long)gx * gy - 1) / ((long)gx * gy));
+  const long tiles = (long)gx * gy * taps;
+  if (ws && tiles < 512 && steps >= 64) {
+    ks = (int)((768 + tiles - 1) / tiles);                        // ~3 workgroups per CU in flight
     const long max_by_k = steps / 32 > 0 ? steps / 32 : 1;        // at least 32 slabs per slice
     if (ks > max_by_k) ks = (int)max_by_k;
-    const size_t per = (size_t)a.M * a.N;
+    const size_t per = (size_t)a.M * a.N * taps;
     if ((size_t)ks * per > ws_floats) ks = (int)(ws_floats / per);
     if (ks < 1) ks = 1;
   }
+  if (taps > 1 && ks < 2) ks = 2;                                 // (the tap-folded launch always goes through the partials)
   long chunk = ((steps + ks - 1) / ks) * SG_BK;
   ks = (int)((a.K + chunk - 1) / chunk);
+  if (taps > 1 && (ks < 2 || !ws || (size_t)ks * a.M * a.N * taps > ws_floats)) return hipErrorInvalidValue;
   a.ksplit = ks; a.kchunk = chunk; a.ws = ws;
-  dim3 grid(gx, gy, ks);
+  dim3 grid(gx, gy, ks * taps);
   if (a.transA && !a.transB) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, a);
   else if (!a.transA && !a.transB) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, st, a);
   else if (!a.transA && a.transB) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, st, a);
@@ -199,9 +210,10 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (ks > 1) {
-    const size_t mn = (size_t)a.M * a.N;
-    const unsigned blocks = (unsigned)((mn + 255) / 256 < 2048 ? (mn + 255) / 256 : 2048);
-    hipLaunchKernelGGL(sgemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, a.C, a.M, a.N, a.ldc, ks, a.accumulate);
+    const size_t mn = (size_t)a.M * a.N * taps;
+    const unsigned blocks = (unsigned)((mn + 255) / 256 < 4096 ? (mn + 255) / 256 : 4096);
+    hipLaunchKernelGGL(sgemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, a.C, a.M, a.N, a.ldc, ks, a.accumulate, taps,
+                       a.tapC);
     e = hipGetLastError();
   }
   return e;
@@ -210,21 +222,35 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
 // column sums of a (rows x N) matrix: out[n] (+)= sum_r X[r][n]; two deterministic passes through `part` (chunks x N)
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, long ld, long rows, int N, long rows_per,
                                                           float* __restrict__ part) {
+  __shared__ float red[256];
   const long r0 = (long)blockIdx.x * rows_per;
   const long r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
-  for (int n = threadIdx.x; n < N; n += 256) {
+  // columns in passes of up to 256; with fewer columns the spare threads take interleaved rows
+  const int cw = N < 256 ? N : 256, lanes = 256 / cw, tid = threadIdx.x;
+  for (int n0 = 0; n0 < N; n0 += cw) {
+    const int c = tid % cw, rl = tid / cw, n = n0 + c;
     float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += X[r * ld + n];
-    part[(size_t)blockIdx.x * N + n] = s;
+    if (rl < lanes && n < N)
+      for (long r = r0 + rl; r < r1; r += lanes) s += X[r * ld + n];
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+      for (int j = 1; j < lanes; ++j) s += red[j * cw + c];
+      part[(size_t)blockIdx.x * N + n] = s;
+    }
+    __syncthreads();
   }
 }
+// one wave per column: lanes take interleaved chunks, fixed-order tree over the lanes
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int chunks, int N, float* __restrict__ out,
                                                            int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   float s = 0.f;
-  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N + n];
-  out[n] = accumulate ? out[n] + s : s;
+  for (int c = lane; c < chunks; c += 64) s += part[(size_t)c * N + n];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) out[n] = accumulate ? out[n] + s : s;
 }
 inline hipError_t colsum(const float* X, long ld, long rows, int N, float* out, int accumulate, float* ws, size_t ws_floats,
                          hipStream_t st) {
@@ -235,7 +261,7 @@ inline hipError_t colsum(const float* X, long ld, long rows, int N, float* out, 
   const long per = (rows + chunks - 1) / chunks;
   chunks = (rows + per - 1) / per;
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned)chunks), dim3(256), 0, st, X, ld, rows, N, per, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws, (int)chunks, N, out, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 3) / 4), dim3(256), 0, st, ws, (int)chunks, N, out, accumulate);
   return hipGetLastError();
 }
 

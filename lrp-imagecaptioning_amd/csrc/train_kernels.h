@@ -96,48 +96,60 @@ __global__ __launch_bounds__(256) void tr_cell_fwd_kernel(const float* __restric
     C[idx] = c; Hs[idx] = o * tc; TC[idx] = tc; SU[idx] = su; S[idx] = tc * su;
   }
 }
-// Adaptive attention of one step, one workgroup per caption (M:586-599).  OUTm = (h + c_hat) * mask_out.
-__global__ __launch_bounds__(256) void tr_attention_fwd_kernel(const float* __restrict__ proj, const float* __restrict__ Vf,
-                                                               const float* __restrict__ HW, const float* __restrict__ SW,
-                                                               const float* __restrict__ v, const float* __restrict__ Hs,
-                                                               const float* __restrict__ S, const float* __restrict__ mask_out,
-                                                               float* __restrict__ ALPHA, float* __restrict__ BETA, float* __restrict__ CTX,
-                                                               float* __restrict__ OUTm, int L, int H, int T, int t) {
-  extern __shared__ float sm[];                 // e[L] | red[8]
+// Adaptive attention of one step (M:586-599), two launches:
+//   scores: one wave per (caption, position): e_i = v . tanh(proj_i + h Wg)                         grid (B, ceil(L/4))
+//   mix   : one workgroup per (caption, 64 hidden units): soft-max over the positions, sentinel gate beta, context,
+//           OUTm = (h + c_hat) * mask_out.  The L-sized soft-max and the H-sized sentinel score are recomputed by every
+//           workgroup of a caption (cheap) so that no third launch is needed.                       grid (B, H/64)
+__global__ __launch_bounds__(256) void tr_att_scores_kernel(const float* __restrict__ proj, const float* __restrict__ HW,
+                                                            const float* __restrict__ v, float* __restrict__ Esc, int L, int H) {
+  const int b = blockIdx.x, i = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= L) return;
+  const float* p = proj + ((size_t)b * L + i) * H;
+  const float* hw = HW + (size_t)b * H;
+  float s = 0.f;
+  for (int h = lane; h < H; h += 64) s += tanhf(p[h] + hw[h]) * v[h];
+  s = tr_wave_sum(s);
+  if (lane == 0) Esc[(size_t)b * L + i] = s;
+}
+__global__ __launch_bounds__(256) void tr_att_mix_kernel(const float* __restrict__ Esc, const float* __restrict__ Vf,
+                                                         const float* __restrict__ HW, const float* __restrict__ SW,
+                                                         const float* __restrict__ v, const float* __restrict__ Hs,
+                                                         const float* __restrict__ S, const float* __restrict__ mask_out,
+                                                         float* __restrict__ ALPHA, float* __restrict__ BETA, float* __restrict__ CTX,
+                                                         float* __restrict__ OUTm, int L, int H, int T, int t) {
+  extern __shared__ float sm[];                 // e[L] | red[8] | part[256]
   float* e = sm;
   float* red = sm + L;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* part = sm + L + 8;
+  const int b = blockIdx.x, h0 = blockIdx.y * 64, tid = threadIdx.x;
   const float* hw = HW + (size_t)b * H;
-  for (int i = wave; i < L; i += 4) {
-    const float* p = proj + ((size_t)b * L + i) * H;
-    float s = 0.f;
-    for (int h = lane; h < H; h += 64) s += tanhf(p[h] + hw[h]) * v[h];
-    s = tr_wave_sum(s);
-    if (lane == 0) e[i] = s;
-  }
   float zs = 0.f;
   for (int h = tid; h < H; h += 256) zs += tanhf(SW[(size_t)b * H + h] + hw[h]) * v[h];
-  zs = tr_block_sum(zs, red);                   // (also publishes e[])
+  zs = tr_block_sum(zs, red);
   float mx = -INFINITY;
-  for (int i = tid; i < L; i += 256) mx = fmaxf(mx, e[i]);
+  for (int i = tid; i < L; i += 256) { e[i] = Esc[(size_t)b * L + i]; mx = fmaxf(mx, e[i]); }
   mx = tr_block_max(mx, red);
   float se = 0.f;
   for (int i = tid; i < L; i += 256) se += expf(e[i] - mx);
   se = tr_block_sum(se, red);
   const float mx2 = fmaxf(mx, zs);
-  const float den2 = se * expf(mx - mx2) + expf(zs - mx2);
-  const float beta = expf(zs - mx2) / den2;
-  __syncthreads();
+  const float beta = expf(zs - mx2) / (se * expf(mx - mx2) + expf(zs - mx2));
   for (int i = tid; i < L; i += 256) {
     const float a = expf(e[i] - mx) / se;
     e[i] = a;
-    ALPHA[(size_t)b * L + i] = a;
+    if (blockIdx.y == 0) ALPHA[(size_t)b * L + i] = a;
   }
-  if (tid == 0) BETA[b] = beta;
+  if (blockIdx.y == 0 && tid == 0) BETA[b] = beta;
   __syncthreads();
-  for (int h = tid; h < H; h += 256) {
-    float c = 0.f;
-    for (int i = 0; i < L; ++i) c += e[i] * Vf[((size_t)b * L + i) * H + h];
+  const int hl = tid & 63, q = tid >> 6, h = h0 + hl;
+  float c = 0.f;
+  if (h < H)
+    for (int i = q; i < L; i += 4) c += e[i] * Vf[((size_t)b * L + i) * H + h];
+  part[tid] = c;
+  __syncthreads();
+  if (q == 0 && h < H) {
+    c = part[hl] + part[64 + hl] + part[128 + hl] + part[192 + hl];
     const size_t o = (size_t)b * H + h;
     CTX[o] = c;
     float out = Hs[o] + beta * S[o] + (1.f - beta) * c;
@@ -204,26 +216,20 @@ __global__ void tr_loss_final_kernel(const float* __restrict__ part, int rows, f
   losses[4] = n > 0.0 ? (float)(h2 / n) : 0.f;
 }
 
-// Backward of tr_attention_fwd_kernel for one step.  In: dOUTm row of the step, carry dH.  Out: dHtot = dH + dout,
-// dS = beta dout, DZS (d of the sentinel score pre-tanh row), DHW (d of h Wg); accumulated over the steps per caption:
-// dProj (B, L, H), dVf (B, L, H), dVacc (B, H) (the attention vector's gradient, summed over captions afterwards).
-__global__ __launch_bounds__(256) void tr_attention_bwd_kernel(const float* __restrict__ proj, const float* __restrict__ Vf,
-                                                               const float* __restrict__ HW, const float* __restrict__ SW,
-                                                               const float* __restrict__ v, const float* __restrict__ S,
-                                                               const float* __restrict__ CTX, const float* __restrict__ ALPHA,
-                                                               const float* __restrict__ BETA, const float* __restrict__ dOUTm,
-                                                               const float* __restrict__ mask_out, const float* __restrict__ dH,
-                                                               float* __restrict__ dHtot, float* __restrict__ dS, float* __restrict__ DZS,
-                                                               float* __restrict__ DHW, float* __restrict__ dProj, float* __restrict__ dVf,
-                                                               float* __restrict__ dVacc, int L, int H, int T, int t) {
-  extern __shared__ float sm[];                 // de[L] | alpha[L] | dctx[H] | red[8]
-  float* de = sm;
-  float* al = sm + L;
-  float* dctx = sm + 2 * L;
-  float* red = sm + 2 * L + H;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Backward of the attention step, three launches.  In: dOUTm row of the step, carry dH.
+//   head (grid B): dHtot = dH + dout, dS = beta dout, dCtx = (1 - beta) dout, dBeta = dout . (s - ctx)
+//   dalpha (grid (B, ceil(L/4))): DA_i = dCtx . Vf_i, one wave per position
+//   main (grid (B, H/64)): scores' gradient de_i (soft-max over L and the sentinel soft-max, recomputed per workgroup),
+//        then for its 64 hidden units: dProj += de_i v (1 - A^2), dVf += alpha_i dCtx, DHW (d of h Wg), DZS (d of the
+//        sentinel score's pre-tanh row), dVacc (the attention vector's gradient, per caption).
+__global__ __launch_bounds__(256) void tr_att_bwd_head_kernel(const float* __restrict__ S, const float* __restrict__ CTX,
+                                                              const float* __restrict__ BETA, const float* __restrict__ dOUTm,
+                                                              const float* __restrict__ mask_out, const float* __restrict__ dH,
+                                                              float* __restrict__ dHtot, float* __restrict__ dS, float* __restrict__ dCtx,
+                                                              float* __restrict__ dBeta, int H, int T, int t) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float beta = BETA[b];
-  const float* hw = HW + (size_t)b * H;
   float dbeta = 0.f;
   for (int h = tid; h < H; h += 256) {
     const size_t o = (size_t)b * H + h;
@@ -231,29 +237,52 @@ __global__ __launch_bounds__(256) void tr_attention_bwd_kernel(const float* __re
     if (mask_out) d *= mask_out[((size_t)b * T + t) * H + h];
     dHtot[o] = (dH ? dH[o] : 0.f) + d;
     dS[o] = beta * d;
-    dctx[h] = (1.f - beta) * d;
+    dCtx[o] = (1.f - beta) * d;
     dbeta += d * (S[o] - CTX[o]);
   }
-  for (int i = tid; i < L; i += 256) al[i] = ALPHA[(size_t)b * L + i];
-  dbeta = tr_block_sum(dbeta, red);             // (publishes dctx / al)
-  for (int i = wave; i < L; i += 4) {
-    const float* vf = Vf + ((size_t)b * L + i) * H;
-    float s = 0.f;
-    for (int h = lane; h < H; h += 64) s += dctx[h] * vf[h];
-    s = tr_wave_sum(s);
-    if (lane == 0) de[i] = s;                   // d alpha_i for now
-  }
-  __syncthreads();
+  dbeta = tr_block_sum(dbeta, red);
+  if (tid == 0) dBeta[b] = dbeta;
+}
+__global__ __launch_bounds__(256) void tr_att_bwd_dalpha_kernel(const float* __restrict__ Vf, const float* __restrict__ dCtx,
+                                                                float* __restrict__ DA, int L, int H) {
+  const int b = blockIdx.x, i = blockIdx.y * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (i >= L) return;
+  const float* vf = Vf + ((size_t)b * L + i) * H;
+  const float* dc = dCtx + (size_t)b * H;
+  float s = 0.f;
+  for (int h = lane; h < H; h += 64) s += dc[h] * vf[h];
+  s = tr_wave_sum(s);
+  if (lane == 0) DA[(size_t)b * L + i] = s;
+}
+__global__ __launch_bounds__(256) void tr_att_bwd_main_kernel(const float* __restrict__ proj, const float* __restrict__ HW,
+                                                              const float* __restrict__ SW, const float* __restrict__ v,
+                                                              const float* __restrict__ ALPHA, const float* __restrict__ BETA,
+                                                              const float* __restrict__ DA, const float* __restrict__ dBeta,
+                                                              const float* __restrict__ dCtx, float* __restrict__ DZS,
+                                                              float* __restrict__ DHW, float* __restrict__ dProj, float* __restrict__ dVf,
+                                                              float* __restrict__ dVacc, int L, int H) {
+  extern __shared__ float sm[];                 // de[L] | alpha[L] | red[8] | part[512]
+  float* de = sm;
+  float* al = sm + L;
+  float* red = sm + 2 * L;
+  float* part = sm + 2 * L + 8;
+  const int b = blockIdx.x, h0 = blockIdx.y * 64, tid = threadIdx.x;
+  const float beta = BETA[b], dbeta = dBeta[b];
   float dot = 0.f;
-  for (int i = tid; i < L; i += 256) dot += al[i] * de[i];
+  for (int i = tid; i < L; i += 256) {
+    al[i] = ALPHA[(size_t)b * L + i];
+    de[i] = DA[(size_t)b * L + i];
+    dot += al[i] * de[i];
+  }
   dot = tr_block_sum(dot, red);
   for (int i = tid; i < L; i += 256) de[i] = al[i] * (de[i] - dot) - beta * (1.f - beta) * al[i] * dbeta;
   const float dzs = beta * (1.f - beta) * dbeta;
   __syncthreads();
-  for (int h = tid; h < H; h += 256) {
-    const float vh = v[h], hwh = hw[h], dc = dctx[h];
-    float dhw = 0.f, dv = 0.f;
-    for (int i = 0; i < L; ++i) {
+  const int hl = tid & 63, q = tid >> 6, h = h0 + hl;
+  float dhw = 0.f, dv = 0.f;
+  if (h < H) {
+    const float vh = v[h], hwh = HW[(size_t)b * H + h], dc = dCtx[(size_t)b * H + h];
+    for (int i = q; i < L; i += 4) {
       const size_t o = ((size_t)b * L + i) * H + h;
       const float A = tanhf(proj[o] + hwh);
       const float dA = de[i] * vh * (1.f - A * A);
@@ -262,8 +291,16 @@ __global__ __launch_bounds__(256) void tr_attention_bwd_kernel(const float* __re
       dhw += dA;
       dv += de[i] * A;
     }
+  }
+  part[tid] = dhw;
+  part[256 + tid] = dv;
+  __syncthreads();
+  if (q == 0 && h < H) {
+    dhw = part[hl] + part[64 + hl] + part[128 + hl] + part[192 + hl];
+    dv = part[256 + hl] + part[320 + hl] + part[384 + hl] + part[448 + hl];
     const size_t o = (size_t)b * H + h;
-    const float As = tanhf(SW[o] + hwh);
+    const float vh = v[h];
+    const float As = tanhf(SW[o] + HW[o]);
     const float dz = dzs * vh * (1.f - As * As);
     DZS[o] = dz;
     DHW[o] = dhw + dz;

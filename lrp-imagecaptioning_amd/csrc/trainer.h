@@ -40,12 +40,15 @@ struct Trainer {
   std::vector<TrainParam> params;
   size_t n_total = 0;
   DevBuf master, mom, vel;
-  std::vector<float> host;                     // mirror of master for re-packing the engine's operand copies
+  std::vector<float> host;                     // staging of the initial weights
+  float* host_pinned = nullptr;                // pinned mirror of the slices that are re-packed on the host
+  ~Trainer() { if (host_pinned) (void)hipHostFree(host_pinned); }
   float lr = 0.f, clip = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
   int64_t iter = 0;
   // forward state (time-major rows (t, b))
   DevBuf Vf, favg, glob, proj, Xall, Z, Gt, Cst, Hst, TC, SU, Sst, HW, SW, ALPHA, BETA, CTX, OUTm, logits, part, losses;
   // backward state
+  DevBuf Esc, dCtx, dBeta;                     // attention scores / d alpha of the current step, per-step scratch
   DevBuf dOUTm, dHtot, dS, dH, dC, DZ, DZS, DHW, dProj, dVf, dVacc, dX, dglob, dfavg, dF, ws, ident;
   size_t ws_floats = 0;
   bool stepped = false;
@@ -61,6 +64,7 @@ struct Trainer {
   int begin(Encoder& enc, Decoder& dec, const lrp_config& c, float lr_, float clip_, float b1_, float b2_, float eps_,
             int64_t* total) {
     if (dec.kind != LRP_DEC_ADAPTIVE) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step is built for the adaptive-attention captioner");
+    if (ready) return fail(LRP_ERR_STATE, "lrp_train_begin was already called on this handle");
     if (c.E != c.H) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step needs E == H");
     LRP_TRY(enc.check_ready());
     Bm = c.max_images; Tm = c.max_caption_len; L = c.L; D = c.D; H = c.H; E = c.E; V = c.V;
@@ -100,6 +104,8 @@ struct Trainer {
         return fail(LRP_ERR_STATE, "decoder weight '%s' is not set (or has the wrong size)", params[pi].name.c_str());
       std::copy(it->second.begin(), it->second.end(), host.begin() + params[pi].off);
     }
+    if (host_pinned) { (void)hipHostFree(host_pinned); host_pinned = nullptr; }
+    if (hipHostMalloc(reinterpret_cast<void**>(&host_pinned), n_total * 4) != hipSuccess) return fail(LRP_ERR_NOMEM, "hipHostMalloc failed");
     LRP_TRY(master.alloc(n_total * 4, total)); LRP_TRY(mom.alloc(n_total * 4, total)); LRP_TRY(vel.alloc(n_total * 4, total));
     LRP_HIP_CHECK(hipMemcpy(master.p, host.data(), n_total * 4, hipMemcpyHostToDevice));
     LRP_HIP_CHECK(hipMemset(mom.p, 0, n_total * 4));
@@ -112,7 +118,8 @@ struct Trainer {
     for (DevBuf* d : {&Cst, &Hst, &TC, &SU, &Sst, &HW, &SW, &CTX, &OUTm, &dOUTm, &DZS, &DHW}) LRP_TRY(d->alloc(TB * H * 4, total));
     LRP_TRY(ALPHA.alloc(TB * L * 4, total)); LRP_TRY(BETA.alloc(TB * 4, total));
     LRP_TRY(logits.alloc(TB * V * 4, total)); LRP_TRY(part.alloc(TB * 5 * 4, total)); LRP_TRY(losses.alloc(32, total));
-    for (DevBuf* d : {&dHtot, &dS, &dH, &dC, &dVacc}) LRP_TRY(d->alloc(B * H * 4, total));
+    for (DevBuf* d : {&dHtot, &dS, &dH, &dC, &dVacc, &dCtx}) LRP_TRY(d->alloc(B * H * 4, total));
+    LRP_TRY(Esc.alloc(B * L * 4, total)); LRP_TRY(dBeta.alloc(B * 4, total));
     LRP_TRY(DZ.alloc(TB * 5 * H * 4, total)); LRP_TRY(dProj.alloc(B * L * H * 4, total)); LRP_TRY(dVf.alloc(B * L * H * 4, total));
     LRP_TRY(dX.alloc(TB * 2 * E * 4, total)); LRP_TRY(dglob.alloc(B * E * 4, total)); LRP_TRY(dfavg.alloc(B * D * 4, total));
     LRP_TRY(dF.alloc(B * L * D * 4, total));
@@ -163,7 +170,7 @@ struct Trainer {
     hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), cap_in, x, B, T, E);
     LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("lstm_Wi"), 4 * H, z, 5 * H, false, st));
     LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("Wx"), H, z + 4 * H, 5 * H, false, st));
-    const size_t att_fwd_lds = (size_t)(L + 8) * 4, att_bwd_lds = (size_t)(2 * L + H + 8) * 4;
+    const size_t att_fwd_lds = (size_t)(L + 8 + 256) * 4, att_bwd_lds = (size_t)(2 * L + 8 + 512) * 4;
     for (int t = 0; t < T; ++t) {
       float* zt = z + (size_t)t * B * 5 * H;
       const float* hp = t > 0 ? Hst.as<float>() + (size_t)(t - 1) * BH : nullptr;
@@ -177,9 +184,11 @@ struct Trainer {
                          Sst.as<float>() + t * BH, B, H);
       LRP_TRY(mm(false, false, B, H, H, Hst.as<float>() + t * BH, H, W("Wg"), H, HW.as<float>() + t * BH, H, false, st));
       LRP_TRY(mm(false, false, B, H, H, Sst.as<float>() + t * BH, H, W("Ws"), H, SW.as<float>() + t * BH, H, false, st));
-      hipLaunchKernelGGL(tr_attention_fwd_kernel, dim3(B), dim3(256), att_fwd_lds, st, pj, vf, HW.as<float>() + t * BH,
-                         SW.as<float>() + t * BH, W("V"), Hst.as<float>() + t * BH, Sst.as<float>() + t * BH, m_out,
-                         ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, CTX.as<float>() + t * BH,
+      hipLaunchKernelGGL(tr_att_scores_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, pj, HW.as<float>() + t * BH, W("V"),
+                         Esc.as<float>(), L, H);
+      hipLaunchKernelGGL(tr_att_mix_kernel, dim3(B, (H + 63) / 64), dim3(256), att_fwd_lds, st, Esc.as<float>(), vf,
+                         HW.as<float>() + t * BH, SW.as<float>() + t * BH, W("V"), Hst.as<float>() + t * BH, Sst.as<float>() + t * BH,
+                         m_out, ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, CTX.as<float>() + t * BH,
                          OUTm.as<float>() + t * BH, L, H, T, t);
     }
     LRP_HIP_CHECK(hipGetLastError());
@@ -202,12 +211,15 @@ struct Trainer {
     LRP_HIP_CHECK(hipMemsetAsync(dC.p, 0, BH * 4, st));
     float* dz = DZ.as<float>();
     for (int t = T - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(tr_attention_bwd_kernel, dim3(B), dim3(256), att_bwd_lds, st, pj, vf, HW.as<float>() + t * BH,
-                         SW.as<float>() + t * BH, W("V"), Sst.as<float>() + t * BH, CTX.as<float>() + t * BH,
-                         ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, dOUTm.as<float>() + t * BH, m_out,
-                         t == T - 1 ? (const float*)nullptr : dH.as<float>(), dHtot.as<float>(), dS.as<float>(),
-                         DZS.as<float>() + t * BH, DHW.as<float>() + t * BH, dProj.as<float>(), dVf.as<float>(), dVacc.as<float>(), L, H,
-                         T, t);
+      hipLaunchKernelGGL(tr_att_bwd_head_kernel, dim3(B), dim3(256), 0, st, Sst.as<float>() + t * BH, CTX.as<float>() + t * BH,
+                         BETA.as<float>() + (size_t)t * B, dOUTm.as<float>() + t * BH, m_out,
+                         t == T - 1 ? (const float*)nullptr : dH.as<float>(), dHtot.as<float>(), dS.as<float>(), dCtx.as<float>(),
+                         dBeta.as<float>(), H, T, t);
+      hipLaunchKernelGGL(tr_att_bwd_dalpha_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, vf, dCtx.as<float>(), Esc.as<float>(), L, H);
+      hipLaunchKernelGGL(tr_att_bwd_main_kernel, dim3(B, (H + 63) / 64), dim3(256), att_bwd_lds, st, pj, HW.as<float>() + t * BH,
+                         SW.as<float>() + t * BH, W("V"), ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B,
+                         Esc.as<float>(), dBeta.as<float>(), dCtx.as<float>(), DZS.as<float>() + t * BH, DHW.as<float>() + t * BH,
+                         dProj.as<float>(), dVf.as<float>(), dVacc.as<float>(), L, H);
       LRP_TRY(mm(false, true, B, H, H, DZS.as<float>() + t * BH, H, W("Ws"), H, dS.as<float>(), H, true, st));
       LRP_TRY(mm(false, true, B, H, H, DHW.as<float>() + t * BH, H, W("Wg"), H, dHtot.as<float>(), H, true, st));
       float* dzt = dz + (size_t)t * B * 5 * H;
@@ -258,11 +270,11 @@ struct Trainer {
       const ConvLayer& Ly = enc.layers[li];
       const long K = (long)B * Ly.H * Ly.W;
       float* gw = grads + params[2 * li].off;
-      for (int t = 0; t < 9; ++t) {
-        SgemmArgs a{};
-        a.A = enc.layer_input(li); a.lda = Ly.cin; a.B = dZ; a.ldb = Ly.cout; a.C = gw + (size_t)t * Ly.cin * Ly.cout; a.ldc = Ly.cout;
+      {
+        SgemmArgs a{};                              // all nine taps in one launch (blockIdx.z = tap x K slice)
+        a.A = enc.layer_input(li); a.lda = Ly.cin; a.B = dZ; a.ldb = Ly.cout; a.C = gw; a.ldc = Ly.cout;
         a.M = Ly.cin; a.N = Ly.cout; a.K = K; a.transA = 1; a.transB = 0;
-        a.gather = 1; a.gH = Ly.H; a.gW = Ly.W; a.dy = t / 3 - 1; a.dx = t % 3 - 1;
+        a.gather = 1; a.gH = Ly.H; a.gW = Ly.W; a.taps = 9; a.tapC = (long)Ly.cin * Ly.cout;
         LRP_HIP_CHECK(sgemm(a, wsf, ws_floats, st));
       }
       LRP_HIP_CHECK(colsum(dZ, Ly.cout, K, Ly.cout, grads + params[2 * li + 1].off, 0, wsf, ws_floats, st));
@@ -284,20 +296,24 @@ struct Trainer {
     return sync_engine(enc, dec, total, st);
   }
 
+  // Encoder operand copies are rebuilt on the device (cnn_kernels.h pack_*_dev); the image layer (1.7 K weights) and
+  // the decoder's derived matrices still go through their host packers.
   int sync_engine(Encoder& enc, Decoder& dec, int64_t* total, hipStream_t st) {
-    LRP_HIP_CHECK(hipMemcpyAsync(host.data(), master.p, n_total * 4, hipMemcpyDeviceToHost, st));
-    LRP_HIP_CHECK(hipStreamSynchronize(st));
     if (enc.gates_pending) {                       // the side stream may still read the operand copies we replace
-      LRP_HIP_CHECK(hipEventSynchronize(enc.ev_gates));
+      LRP_HIP_CHECK(hipStreamWaitEvent(st, enc.ev_gates, 0));
       enc.gates_pending = false;
     }
-    size_t pi = 0;
-    for (size_t li = 0; li < enc.layers.size(); ++li, pi += 2) {
-      LRP_TRY(enc.set_conv_weight((int)li, host.data() + params[pi].off, total));
-      LRP_TRY(enc.set_conv_bias((int)li, host.data() + params[pi + 1].off, total));
-    }
-    for (; pi < params.size(); ++pi)
-      LRP_TRY(dec.set_weight(params[pi].name, host.data() + params[pi].off, (int)params[pi].shape.size(), params[pi].shape.data(), total));
+    for (size_t li = 1; li < enc.layers.size(); ++li)
+      LRP_TRY(enc.repack_conv_from_device((int)li, master.as<float>() + params[2 * li].off, master.as<float>() + params[2 * li + 1].off,
+                                          ws.as<float>(), st));
+    const size_t dec0 = params[2 * enc.layers.size()].off, l0 = params[2].off;     // [0, l0): image layer; [dec0, n): decoder
+    LRP_HIP_CHECK(hipMemcpyAsync(host_pinned, master.p, l0 * 4, hipMemcpyDeviceToHost, st));
+    LRP_HIP_CHECK(hipMemcpyAsync(host_pinned + dec0, master.as<float>() + dec0, (n_total - dec0) * 4, hipMemcpyDeviceToHost, st));
+    LRP_HIP_CHECK(hipStreamSynchronize(st));
+    LRP_TRY(enc.set_conv_weight(0, host_pinned + params[0].off, total));
+    LRP_TRY(enc.set_conv_bias(0, host_pinned + params[1].off, total));
+    for (size_t pi = 2 * enc.layers.size(); pi < params.size(); ++pi)
+      LRP_TRY(dec.set_weight(params[pi].name, host_pinned + params[pi].off, (int)params[pi].shape.size(), params[pi].shape.data(), total));
     enc.encoded = 0;                               // caches belong to the old weights
     return LRP_OK;
   }

@@ -32,7 +32,8 @@ class LRPInferenceLayerAdaptive(object):
             out.append(i)
         return out
 
-    def call(self, inputs):
+    def call(self, inputs, images_encoded=False):
+        """images_encoded: the engine already holds these images (the fine-tune loop encodes once per batch)."""
         assert len(inputs) == 3
         _, img_inputs, y_preds = inputs
         y_preds = np.asarray(y_preds)
@@ -55,7 +56,8 @@ class LRPInferenceLayerAdaptive(object):
                     pairs.append((b, i, int(cap[i])))
         out = np.zeros(y_preds.shape, dtype=np.float64)
         if pairs:
-            eng.encode_images(img_inputs)
+            if not (images_encoded and eng.n_images == B):
+                eng.encode_images(img_inputs)
             eng.decoder_forward(caps)
             for lo in range(0, len(pairs), eng.max_tokens):
                 chunk = pairs[lo:lo + eng.max_tokens]

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 on ONE GPU's share: the LRP-inference fine-tune step (train.py:571-580) of the VGG16 +
+adaptive-attention captioner — predict, lrp_weight for every word of every predicted caption, gradients, Adam.
+The config quotes batch=64 on 8 GPUs = 8 images per GPU; B=32 (the reference's config.batch_size) is timed as well.
+Prints the phases; not the headline bench."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    import torch
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention
+    from lrp_imagecaptioning_amd.synthetic import adaptive_weights, images, vgg_weights
+    from lrp_imagecaptioning_amd.training import TrainingLRPInferenceAdaptive
+    B, T, V = int(os.environ.get("B", 8)), int(os.environ.get("T", 21)), 10000
+    rs = np.random.RandomState(0)
+    w = vgg_weights(rs)
+    w.update(adaptive_weights(rs, 196, 512, 512, 512, V))
+    spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512, vocab_size=V)
+    ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=T - 1, max_images=B)
+    tr = TrainingLRPInferenceAdaptive(ex, learning_rate=2e-4, clipvalue=0.01, drop_rate=0.5)
+    eng = ex._engine
+    X = torch.as_tensor(images(rs, B)).cuda()
+    cap_in = np.concatenate([np.full((B, 1), 1), rs.randint(2, V, size=(B, T - 1))], axis=1).astype(np.int32)
+    y = rs.randint(0, V, size=(B, T)).astype(np.int32)
+
+    def timed(fn):
+        torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return (time.perf_counter() - t) * 1e3, r
+    tr.train_on_batch([cap_in, X], y)                                   # warm-up
+    t_pred, y_pred = timed(lambda: tr.predict_on_batch([cap_in, X]))
+    yp = y_pred.cpu().numpy()
+    t_lrp, lw = timed(lambda: tr._lrp_layer.call([cap_in, X, yp]))
+    n_maps = int((lw != 1).sum())
+    lw_dev = torch.as_tensor(lw, dtype=torch.float32).cuda()
+    masks = tr._masks(B, T)
+    t_step, (g, losses) = timed(lambda: eng.train_step(cap_in, y, lw_dev, masks, grads=tr._grads))
+    t_apply, _ = timed(lambda: eng.train_apply(g))
+    n = 3
+    t_all, _ = timed(lambda: [tr.train_on_batch([cap_in, X], y) for _ in range(n)])
+    print("config5 (fine-tune step, VGG16 + adaptive, B=%d, T=%d, %d heat-maps): %.1f ms/iteration; predict %.1f, lrp_weight %.1f, "
+          "gradients %.1f, Adam + operand rebuild %.1f ms; losses %s; workspace %.1f GB" % (
+              B, T, n_maps, t_all / n, t_pred, t_lrp, t_step, t_apply, [round(float(v), 4) for v in losses.cpu()],
+              eng.workspace_bytes / 1e9))
+    assert torch.isfinite(g).all()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,12 @@ def test_adam_step_matches_oracle_and_engine_follows():
     feat = eng.get_features().cpu().numpy().reshape(len(X), -1, D)
     ref = Cn.forward(Cn.vgg_layers({k: new[k].reshape(np.shape(w[k])) for k in w}, CFG), X).reshape(len(X), -1, D)
     assert rel_l1(feat, ref) < 1e-5
+    # ... including the LRP operand copies rebuilt on the device (split / fragment-major forms)
+    wn = {k: new[k].reshape(np.shape(w[k])) for k in w}
+    R = np.abs(np.random.RandomState(0).standard_normal((1, L, D))).astype(np.float32) * feat[:1]
+    got = eng.cnn_explain([0], R).cpu().numpy()
+    want = Cn.analyze(Cn.vgg_layers(wn, CFG), X[:1], R.reshape(1, 4, 4, D))
+    assert rel_l1(got, want) < 1e-4
     with pytest.raises(ValueError):
         eng.train_step(cap_in[:, :1], y[:, :1], lw[:, :1])           # T < 2
 
