@@ -29,19 +29,20 @@ struct SgemmArgs {
   int vecA, vecB;          // 16 B loads allowed (alignment checked on the host)
 };
 
-constexpr int SG_BM = 128, SG_BN = 128, SG_BK = 16, SG_LD = 132;
+constexpr int SG_BK = 16;
+constexpr int sg_ld(int bmn) { return bmn + 4; }       // LDS row stride (floats): keeps 16 B alignment, spreads the transposing writes
 
 typedef float sg_f32x16 __attribute__((ext_vector_type(16)));
 
-// stage one operand tile (16 k x 128 cols) into LDS [k][col]; kmajor: memory rows are k
-template <bool KMAJOR>
+// stage one operand tile (16 k x BMN cols) into LDS [k][col]; kmajor: memory rows are k
+template <bool KMAJOR, int BMN>
 __device__ __forceinline__ void sg_fetch(const float* __restrict__ P, long ld, int rows_mn, long k_end, int mn0, long k0, int tid,
-                                         bool vec, const SgemmArgs& a, bool is_a, float (&r)[2][4]) {
+                                         bool vec, const SgemmArgs& a, bool is_a, float (&r)[BMN / 64][4]) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < BMN / 64; ++q) {
     const int idx = tid + 256 * q;
     if constexpr (KMAJOR) {
-      const int kr = idx >> 5, c4 = idx & 31;
+      const int kr = idx / (BMN / 4), c4 = idx % (BMN / 4);
       const long k = k0 + kr;
       const int col = mn0 + 4 * c4;
       long src = k;
@@ -74,70 +75,76 @@ __device__ __forceinline__ void sg_fetch(const float* __restrict__ P, long ld, i
     }
   }
 }
-template <bool KMAJOR>
-__device__ __forceinline__ void sg_put(float* __restrict__ S, int tid, const float (&r)[2][4]) {
+template <bool KMAJOR, int BMN>
+__device__ __forceinline__ void sg_put(float* __restrict__ S, int tid, const float (&r)[BMN / 64][4]) {
+  constexpr int LD = sg_ld(BMN);
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
+  for (int q = 0; q < BMN / 64; ++q) {
     const int idx = tid + 256 * q;
     if constexpr (KMAJOR) {
-      const int kr = idx >> 5, c4 = idx & 31;
-      *reinterpret_cast<float4*>(S + kr * SG_LD + 4 * c4) = make_float4(r[q][0], r[q][1], r[q][2], r[q][3]);
+      const int kr = idx / (BMN / 4), c4 = idx % (BMN / 4);
+      *reinterpret_cast<float4*>(S + kr * LD + 4 * c4) = make_float4(r[q][0], r[q][1], r[q][2], r[q][3]);
     } else {
       const int row = idx >> 2, c4 = idx & 3;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) S[(4 * c4 + j) * SG_LD + row] = r[q][j];
+      for (int j = 0; j < 4; ++j) S[(4 * c4 + j) * LD + row] = r[q][j];
     }
   }
 }
 
-template <bool TA, bool TB>
+// TM x TN 32x32 MFMA tiles per wave, 2 x 2 waves: block tile (64 TM) x (64 TN)
+template <bool TA, bool TB, int TM, int TN>
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  __shared__ float As[2][SG_BK * SG_LD];
-  __shared__ float Bs[2][SG_BK * SG_LD];
+  constexpr int BM = 64 * TM, BN = 64 * TN, LDA = sg_ld(BM), LDB = sg_ld(BN);
+  __shared__ float As[2][SG_BK * LDA];
+  __shared__ float Bs[2][SG_BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * SG_BM, n0 = blockIdx.x * SG_BN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int tap = a.taps > 1 ? (int)blockIdx.z / a.ksplit : 0, slice = a.taps > 1 ? (int)blockIdx.z % a.ksplit : (int)blockIdx.z;
   if (a.taps > 1) { a.dy = tap / 3 - 1; a.dx = tap % 3 - 1; }
   const long kb = (long)slice * a.kchunk;
   const long ke = kb + a.kchunk < a.K ? kb + a.kchunk : a.K;
-  sg_f32x16 acc[2][2];
+  sg_f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float ra[2][4], rb[2][4];
+  float ra[TM][4], rb[TN][4];
   const long nst = (ke - kb + SG_BK - 1) / SG_BK;
   if (nst > 0) {
-    sg_fetch<TA>(a.A, a.lda, a.M, ke, m0, kb, tid, a.vecA != 0, a, true, ra);
-    sg_fetch<!TB>(a.B, a.ldb, a.N, ke, n0, kb, tid, a.vecB != 0, a, false, rb);
-    sg_put<TA>(As[0], tid, ra);
-    sg_put<!TB>(Bs[0], tid, rb);
+    sg_fetch<TA, BM>(a.A, a.lda, a.M, ke, m0, kb, tid, a.vecA != 0, a, true, ra);
+    sg_fetch<!TB, BN>(a.B, a.ldb, a.N, ke, n0, kb, tid, a.vecB != 0, a, false, rb);
+    sg_put<TA, BM>(As[0], tid, ra);
+    sg_put<!TB, BN>(Bs[0], tid, rb);
   }
   __syncthreads();
   for (long s = 0; s < nst; ++s) {
     const int cur = (int)(s & 1);
     const bool more = s + 1 < nst;
     if (more) {
-      sg_fetch<TA>(a.A, a.lda, a.M, ke, m0, kb + (s + 1) * SG_BK, tid, a.vecA != 0, a, true, ra);
-      sg_fetch<!TB>(a.B, a.ldb, a.N, ke, n0, kb + (s + 1) * SG_BK, tid, a.vecB != 0, a, false, rb);
+      sg_fetch<TA, BM>(a.A, a.lda, a.M, ke, m0, kb + (s + 1) * SG_BK, tid, a.vecA != 0, a, true, ra);
+      sg_fetch<!TB, BN>(a.B, a.ldb, a.N, ke, n0, kb + (s + 1) * SG_BK, tid, a.vecB != 0, a, false, rb);
     }
-    const float* Ac = As[cur] + (lane >> 5) * SG_LD + wm * 64 + (lane & 31);
-    const float* Bc = Bs[cur] + (lane >> 5) * SG_LD + wn * 64 + (lane & 31);
+    const float* Ac = As[cur] + (lane >> 5) * LDA + wm * 32 * TM + (lane & 31);
+    const float* Bc = Bs[cur] + (lane >> 5) * LDB + wn * 32 * TN + (lane & 31);
 #pragma unroll
     for (int kk = 0; kk < SG_BK / 2; ++kk) {
-      const float a0 = Ac[2 * kk * SG_LD], a1 = Ac[2 * kk * SG_LD + 32];
-      const float b0 = Bc[2 * kk * SG_LD], b1 = Bc[2 * kk * SG_LD + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = Ac[2 * kk * LDA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bc[2 * kk * LDB + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      sg_put<TA>(As[cur ^ 1], tid, ra);
-      sg_put<!TB>(Bs[cur ^ 1], tid, rb);
+      sg_put<TA, BM>(As[cur ^ 1], tid, ra);
+      sg_put<!TB, BN>(Bs[cur ^ 1], tid, rb);
     }
     __syncthreads();
   }
@@ -145,14 +152,14 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
   const long ldc = a.ksplit > 1 ? a.N : a.ldc;
   const bool accum = a.ksplit > 1 ? false : a.accumulate != 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row >= a.M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (col < a.N) {
           float* p = C + (long)row * ldc + col;
           *p = accum ? *p + acc[i][j][r] : acc[i][j][r];
@@ -178,20 +185,31 @@ __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restri
 
 inline bool sg_aligned(const void* p, long ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 3) == 0; }
 
-// ws / ws_floats: workspace for the K split (may be null: no split).  Target ~2 blocks per CU.
+template <bool TA, bool TB>
+inline void sgemm_launch_tile(int tm, int tn, dim3 grid, hipStream_t st, const SgemmArgs& a) {
+  if (tm == 1 && tn == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 1, 1>), grid, dim3(256), 0, st, a);
+  else if (tm == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 1, 2>), grid, dim3(256), 0, st, a);
+  else if (tn == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 2, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((sgemm_kernel<TA, TB, 2, 2>), grid, dim3(256), 0, st, a);
+}
+
+// ws / ws_floats: workspace for the K split (may be null: no split).  Tile 64 or 128 per side by the extent; the K
+// split fills the chip when the tiles alone do not (weight gradients: few tiles, K = millions of pixels; the
+// per-step products of the scan: 32 rows, a handful of tiles).
 inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st) {
   if (a.M < 1 || a.N < 1 || a.K < 1) return hipErrorInvalidValue;
   a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
   a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
-  const int gx = (a.N + SG_BN - 1) / SG_BN, gy = (a.M + SG_BM - 1) / SG_BM;
+  const int tm = a.M <= 64 ? 1 : 2, tn = a.N <= 64 ? 1 : 2;
+  const int gx = (a.N + 64 * tn - 1) / (64 * tn), gy = (a.M + 64 * tm - 1) / (64 * tm);
   int ks = 1;
   const int taps = a.gather && a.taps > 1 ? a.taps : 1;
   a.taps = taps;
   const long steps = (a.K + SG_BK - 1) / SG_BK;
   const long tiles = (long)gx * gy * taps;
-  if (ws && tiles < 512 && steps >= 64) {
+  if (ws && tiles < 384 && steps >= 16) {
     ks = (int)((768 + tiles - 1) / tiles);                        // ~3 workgroups per CU in flight
-    const long max_by_k = steps / 32 > 0 ? steps / 32 : 1;        // at least 32 slabs per slice
+    const long max_by_k = steps / 8 > 0 ? steps / 8 : 1;          // at least 8 slabs per slice
     if (ks > max_by_k) ks = (int)max_by_k;
     const size_t per = (size_t)a.M * a.N * taps;
     if ((size_t)ks * per > ws_floats) ks = (int)(ws_floats / per);
@@ -203,9 +221,9 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   if (taps > 1 && (ks < 2 || !ws || (size_t)ks * a.M * a.N * taps > ws_floats)) return hipErrorInvalidValue;
   a.ksplit = ks; a.kchunk = chunk; a.ws = ws;
   dim3 grid(gx, gy, ks * taps);
-  if (a.transA && !a.transB) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, a);
-  else if (!a.transA && !a.transB) hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, st, a);
-  else if (!a.transA && a.transB) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, st, a);
+  if (a.transA && !a.transB) sgemm_launch_tile<true, false>(tm, tn, grid, st, a);
+  else if (!a.transA && !a.transB) sgemm_launch_tile<false, false>(tm, tn, grid, st, a);
+  else if (!a.transA && a.transB) sgemm_launch_tile<false, true>(tm, tn, grid, st, a);
   else return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
@@ -225,13 +243,19 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
   __shared__ float red[256];
   const long r0 = (long)blockIdx.x * rows_per;
   const long r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
-  // columns in passes of up to 256; with fewer columns the spare threads take interleaved rows
+  // columns in passes of up to 256; with fewer columns the spare threads take interleaved rows (4 loads in flight each)
   const int cw = N < 256 ? N : 256, lanes = 256 / cw, tid = threadIdx.x;
   for (int n0 = 0; n0 < N; n0 += cw) {
     const int c = tid % cw, rl = tid / cw, n = n0 + c;
-    float s = 0.f;
-    if (rl < lanes && n < N)
-      for (long r = r0 + rl; r < r1; r += lanes) s += X[r * ld + n];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (rl < lanes && n < N) {
+      long r = r0 + rl;
+      for (; r + 3L * lanes < r1; r += 4L * lanes) {
+        s0 += X[r * ld + n]; s1 += X[(r + lanes) * ld + n]; s2 += X[(r + 2L * lanes) * ld + n]; s3 += X[(r + 3L * lanes) * ld + n];
+      }
+      for (; r < r1; r += lanes) s0 += X[r * ld + n];
+    }
+    float s = (s0 + s1) + (s2 + s3);
     red[tid] = s;
     __syncthreads();
     if (rl == 0 && n < N) {

@@ -120,3 +120,38 @@ def test_training_loop_class():
     assert any(np.abs(w1[k] - np.asarray(w[k]).ravel()).max() > 0 for k in ("c1_W", "lstm_Wi", "output_W"))
     losses = [first[0]] + [tr.train_on_batch([cap_in, X], y)[0] for _ in range(12)]
     assert losses[-1] < losses[0], losses                                  # same batch over and over: the loss goes down
+
+
+def test_gradients_match_oracle_midsize():
+    """Widths that are not multiples of the 64 / 128 GEMM tiles, enough rows for the K split, a vocabulary wider than a tile."""
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    from oracle import train_ref as T
+    cfg = [("c1", 3, 24, False), ("c2", 24, 72, True), ("c3", 72, 136, True), ("c4", 136, 136, False)]
+    hw, Lm, Dm, Hm, Vm, B, Tn = 28, 49, 136, 136, 300, 5, 6
+    rs = np.random.RandomState(11)
+    w = vgg_weights(rs, cfg, bias_std=0.2)
+    w.update(adaptive_weights(rs, Lm, Dm, Hm, Hm, Vm))
+    X = (rs.uniform(0, 255, size=(B, hw, hw, 3)) - 110).astype(np.float32) / 64
+    cap_in = np.concatenate([np.full((B, 1), 1), rs.randint(2, Vm, size=(B, Tn - 1))], axis=1).astype(np.int32)
+    y = rs.randint(0, Vm, size=(B, Tn)).astype(np.int32)
+    y[0, 3:] = -1
+    lw = (1 + rs.uniform(0, 1, size=(B, Tn, Vm)) * (rs.uniform(size=(B, Tn, Vm)) < 0.1)).astype(np.float32)
+    mk = lambda *s: ((rs.uniform(size=s) >= 0.5) * 2.0).astype(np.float32)
+    masks = {"image_features": mk(B, Lm, Hm), "global": mk(B, Hm), "output": mk(B, Tn, Hm)}
+    eng = LRPEngine(decoder="adaptive", cnn_cfg=cfg, img_hw=(hw, hw), L=Lm, D=Dm, H=Hm, E=Hm, V=Vm, max_images=B, max_tokens=8,
+                    max_caption_len=Tn)
+    eng.set_weights(w)
+    layout = eng.train_begin()
+    eng.encode_images(X)
+    grads, losses = eng.train_step(cap_in, y, lw, masks)
+    total, l1, l2, g, _ = T.loss_and_grads(w, cfg, X, cap_in, y, lw, masks)
+    np.testing.assert_allclose(losses.cpu().numpy()[:3], [total, l1, l2], rtol=5e-5)
+    gf = grads.cpu().numpy()
+    bad = {}
+    for name, (off, n) in layout.items():
+        e = rel_l1(gf[off:off + n], g[name])
+        if not e < 3e-4:
+            bad[name] = e
+    assert not bad, bad
+    g2, _ = eng.train_step(cap_in, y, lw, masks)
+    assert torch.equal(grads, g2)                       # no atomics anywhere: run-to-run identical
