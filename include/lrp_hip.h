@@ -290,14 +290,17 @@ int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, in
  * grads_dev has the same layout, lrp_train_flat_size floats.  cap_in_dev (B, T) int32 embedding rows (the model's
  * `captions_input`), y_idx_dev (B, T) int32 class index of the one-hot label row or -1 for an all-zero row,
  * lrp_weight_dev (B, T, V) float32.  Dropout masks (values 0 or 1/(1-p)) or NULL: image_features (B, L, H),
- * global (B, E), output (B, T, H).  LSTM input / recurrent dropout is not built. */
+ * global (B, E), output (B, T, H); LSTM-cell dropout (keras `dropout` / `recurrent_dropout`, one mask per gate i f c o
+ * and per step because the wrapper calls the cell inside the K.rnn loop, M:582): lstm_in (T, 4, B, 2E),
+ * lstm_rec (T, 4, B, H). */
 int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float beta2, float eps);
 int64_t lrp_train_flat_size(const lrp_handle* h);
 int32_t lrp_train_num_params(const lrp_handle* h);
 int lrp_train_param_info(const lrp_handle* h, int32_t i, const char** name, int64_t* offset, int64_t* size);
 int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const int32_t* y_idx_dev,
                    const float* lrp_weight_dev, const float* mask_image_features_dev, const float* mask_global_dev,
-                   const float* mask_output_dev, float* grads_dev, float* losses_dev, void* stream);
+                   const float* mask_output_dev, const float* mask_lstm_in_dev, const float* mask_lstm_rec_dev, float* grads_dev,
+                   float* losses_dev, void* stream);
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream);
 int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
 

@@ -78,6 +78,35 @@ __global__ __launch_bounds__(256) void tr_build_x_kernel(const float* __restrict
     x[E + e] = glob[(size_t)b * E + e];
   }
 }
+// LSTM-cell dropout (keras LSTMCell.call, implementation 1: one mask per gate on the inputs and on h; the wrapper calls
+// the cell inside the K.rnn loop, M:582, so masks are per step): out[g][r][:] = x[r][:] * mask[t(r)][g][b(r)][:] for the
+// rows r = (t, b) of `x` (rows x W); mask layout (T, 4, B, W) with t0 = first step of x.
+__global__ __launch_bounds__(256) void tr_gate_masks_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                            float* __restrict__ out, int rows, int B, int W, int t0, size_t gate_stride) {
+  const size_t n = (size_t)rows * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / W;
+    const int w = (int)(i % W), t = t0 + (int)(r / B), b = (int)(r % B);
+    const float v = x[i];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[g * gate_stride + i] = v * mask[(((size_t)t * 4 + g) * B + b) * W + w];
+  }
+}
+// d[r][:] (+)= sum_g part[g][r][:] * mask[t(r)][g][b(r)][:]   (back through the four per-gate masks)
+__global__ __launch_bounds__(256) void tr_gate_masks_bwd_kernel(const float* __restrict__ part, const float* __restrict__ mask,
+                                                                float* __restrict__ d, int rows, int B, int W, int t0,
+                                                                size_t gate_stride) {
+  const size_t n = (size_t)rows * W;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / W;
+    const int w = (int)(i % W), t = t0 + (int)(r / B), b = (int)(r % B);
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s += part[g * gate_stride + i] * mask[(((size_t)t * 4 + g) * B + b) * W + w];
+    d[i] = s;
+  }
+}
+
 // LSTM cell + sentinel of one step (keras LSTMCell.call, gate order i f c o; M:582-584).  Z row = [z_i z_f z_g z_o | u]
 // before the bias; G row = activated gates, C / Hs / TC (= tanh c) / SU (= sigmoid u) / S rows of this step.
 __global__ __launch_bounds__(256) void tr_cell_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias,

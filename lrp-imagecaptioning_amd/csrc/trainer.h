@@ -48,6 +48,7 @@ struct Trainer {
   // forward state (time-major rows (t, b))
   DevBuf Vf, favg, glob, proj, Xall, Z, Gt, Cst, Hst, TC, SU, Sst, HW, SW, ALPHA, BETA, CTX, OUTm, logits, part, losses;
   // backward state
+  DevBuf X4, H4, P4;                           // LSTM-cell dropout: per-gate masked inputs (4, T, B, 2E) / states (4, T, B, H), partials
   DevBuf Esc, dCtx, dBeta;                     // attention scores / d alpha of the current step, per-step scratch
   DevBuf dOUTm, dHtot, dS, dH, dC, DZ, DZS, DHW, dProj, dVf, dVacc, dX, dglob, dfavg, dF, ws, ident;
   size_t ws_floats = 0;
@@ -148,14 +149,21 @@ struct Trainer {
   // One step: gradients of 0.5 CE(y, logits) + 0.5 CE(y, logits * lrp_weight) for the B images last encoded.
   // cap_in (B, T) embedding rows, y_idx (B, T) class index or -1, lrp_weight (B, T, V); masks null = no dropout:
   // m_if (B, L, H), m_glob (B, E), m_out (B, T, H).  grads_dev: n_total floats (caller's).  losses_dev: 5 floats.
+  // LSTM-cell dropout (keras `dropout` / `recurrent_dropout`): m_lin (T, 4, B, 2E), m_lrec (T, 4, B, H), gate order i f c o.
   int step(Encoder& enc, const float* feat, int B, int T, const int* cap_in, const int* y_idx, const float* lrp_weight,
-           const float* m_if, const float* m_glob, const float* m_out, float* grads, float* losses_dev, hipStream_t st) {
+           const float* m_if, const float* m_glob, const float* m_out, const float* m_lin, const float* m_lrec, float* grads,
+           float* losses_dev, int64_t* total, hipStream_t st) {
     if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
     if (B < 1 || B > Bm || T < 2 || T > Tm) return fail(LRP_ERR_INVALID, "B=%d / T=%d outside [1,%d] / [2,%d]", B, T, Bm, Tm);
     if (enc.encoded < B || enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run (after lrp_train_begin) on the batch first");
     for (size_t li = 0; li + 1 < enc.layers.size(); ++li)
       if (!enc.layers[li].pool_after && !enc.layers[li].Akeep.p) return fail(LRP_ERR_STATE, "activations were not kept");
     const size_t TB = (size_t)T * B, BH = (size_t)B * H;
+    if ((m_lin || m_lrec) && !X4.p) {                 // allocated on first use
+      const size_t cap = (size_t)Bm * Tm;
+      LRP_TRY(X4.alloc(4 * cap * 2 * E * 4, total)); LRP_TRY(H4.alloc(4 * cap * H * 4, total)); LRP_TRY(P4.alloc(4 * cap * 2 * E * 4, total));
+    }
+    const size_t xs = TB * 2 * E, hs = TB * H;        // gate strides of X4 / H4 for this (T, B)
     float *vf = Vf.as<float>(), *pj = proj.as<float>(), *x = Xall.as<float>(), *z = Z.as<float>();
     auto g = [&](const char* nm) { return grads + off(nm); };
     // ---------------- forward
@@ -168,14 +176,27 @@ struct Trainer {
                        (size_t)B, E);
     LRP_TRY(mm(false, false, B * L, H, H, vf, H, W("Wv"), H, pj, H, false, st));
     hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), cap_in, x, B, T, E);
-    LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("lstm_Wi"), 4 * H, z, 5 * H, false, st));
-    LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("Wx"), H, z + 4 * H, 5 * H, false, st));
+    if (m_lin) {
+      hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(xs)), dim3(256), 0, st, x, m_lin, X4.as<float>(), (int)TB, B, 2 * E, 0, xs);
+      for (int gt = 0; gt < 4; ++gt)
+        LRP_TRY(mm(false, false, (int)TB, H, 2 * E, X4.as<float>() + gt * xs, 2 * E, W("lstm_Wi") + gt * H, 4 * H, z + gt * H, 5 * H, false, st));
+    } else {
+      LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("lstm_Wi"), 4 * H, z, 5 * H, false, st));
+    }
+    LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("Wx"), H, z + 4 * H, 5 * H, false, st));   // sentinel: un-dropped input (M:584)
     const size_t att_fwd_lds = (size_t)(L + 8 + 256) * 4, att_bwd_lds = (size_t)(2 * L + 8 + 512) * 4;
     for (int t = 0; t < T; ++t) {
       float* zt = z + (size_t)t * B * 5 * H;
       const float* hp = t > 0 ? Hst.as<float>() + (size_t)(t - 1) * BH : nullptr;
       if (t > 0) {
-        LRP_TRY(mm(false, false, B, 4 * H, H, hp, H, W("lstm_Wh"), 4 * H, zt, 5 * H, true, st));
+        if (m_lrec) {
+          float* h4 = H4.as<float>() + (size_t)t * BH;
+          hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(BH)), dim3(256), 0, st, hp, m_lrec, h4, B, B, H, t, hs);
+          for (int gt = 0; gt < 4; ++gt)
+            LRP_TRY(mm(false, false, B, H, H, h4 + gt * hs, H, W("lstm_Wh") + gt * H, 4 * H, zt + gt * H, 5 * H, true, st));
+        } else {
+          LRP_TRY(mm(false, false, B, 4 * H, H, hp, H, W("lstm_Wh"), 4 * H, zt, 5 * H, true, st));
+        }
         LRP_TRY(mm(false, false, B, H, H, hp, H, W("Wh"), H, zt + 4 * H, 5 * H, true, st));
       }
       hipLaunchKernelGGL(tr_cell_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, zt, W("lstm_b"),
@@ -227,18 +248,39 @@ struct Trainer {
                          t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, TC.as<float>() + t * BH,
                          SU.as<float>() + t * BH, dHtot.as<float>(), dS.as<float>(), dC.as<float>(), dzt, B, H);
       if (t > 0) {
-        LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("lstm_Wh"), 4 * H, dH.as<float>(), H, false, st));
+        if (m_lrec) {
+          float* p4 = P4.as<float>();
+          for (int gt = 0; gt < 4; ++gt)
+            LRP_TRY(mm(false, true, B, H, H, dzt + gt * H, 5 * H, W("lstm_Wh") + gt * H, 4 * H, p4 + gt * BH, H, false, st));
+          hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, p4, m_lrec, dH.as<float>(), B, B, H, t, BH);
+        } else {
+          LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("lstm_Wh"), 4 * H, dH.as<float>(), H, false, st));
+        }
         LRP_TRY(mm(false, true, B, H, H, dzt + 4 * H, 5 * H, W("Wh"), H, dH.as<float>(), H, true, st));
       }
     }
     LRP_HIP_CHECK(hipGetLastError());
     // ---------------- weight gradients of the recurrent part, K = (t, b) rows
     float* dx = dX.as<float>();
-    LRP_TRY(mm(false, true, (int)TB, 2 * E, 4 * H, dz, 5 * H, W("lstm_Wi"), 4 * H, dx, 2 * E, false, st));
+    if (m_lin) {
+      float* p4 = P4.as<float>();
+      for (int gt = 0; gt < 4; ++gt) {
+        LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + gt * H, 5 * H, W("lstm_Wi") + gt * H, 4 * H, p4 + gt * xs, 2 * E, false, st));
+        LRP_TRY(mm(true, false, 2 * E, H, (long)TB, X4.as<float>() + gt * xs, 2 * E, dz + gt * H, 5 * H, g("lstm_Wi") + gt * H, 4 * H, false, st));
+      }
+      hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(xs)), dim3(256), 0, st, p4, m_lin, dx, (int)TB, B, 2 * E, 0, xs);
+    } else {
+      LRP_TRY(mm(false, true, (int)TB, 2 * E, 4 * H, dz, 5 * H, W("lstm_Wi"), 4 * H, dx, 2 * E, false, st));
+      LRP_TRY(mm(true, false, 2 * E, 4 * H, (long)TB, x, 2 * E, dz, 5 * H, g("lstm_Wi"), 4 * H, false, st));
+    }
     LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + 4 * H, 5 * H, W("Wx"), H, dx, 2 * E, true, st));
-    LRP_TRY(mm(true, false, 2 * E, 4 * H, (long)TB, x, 2 * E, dz, 5 * H, g("lstm_Wi"), 4 * H, false, st));
     LRP_TRY(mm(true, false, 2 * E, H, (long)TB, x, 2 * E, dz + 4 * H, 5 * H, g("Wx"), H, false, st));
     const long Kr = (long)(T - 1) * B;
+    if (m_lrec) {
+      for (int gt = 0; gt < 4; ++gt)                  // rows t = 1 .. T-1 of the masked states and of dz
+        LRP_TRY(mm(true, false, H, H, Kr, H4.as<float>() + gt * hs + BH, H, dz + (size_t)B * 5 * H + gt * H, 5 * H,
+                   g("lstm_Wh") + gt * H, 4 * H, false, st));
+    } else
     LRP_TRY(mm(true, false, H, 4 * H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H, 5 * H, g("lstm_Wh"), 4 * H, false, st));
     LRP_TRY(mm(true, false, H, H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H + 4 * H, 5 * H, g("Wh"), H, false, st));
     LRP_HIP_CHECK(colsum(dz, 5 * H, (long)TB, 4 * H, g("lstm_b"), 0, wsf, ws_floats, st));

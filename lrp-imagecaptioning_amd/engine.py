@@ -217,7 +217,8 @@ class LRPEngine(object):
 
     def train_step(self, cap_in, y_idx, lrp_weight, masks=None, grads=None):
         """Gradients of the two-headed loss for the images last encoded.  cap_in / y_idx (B, T) ints (y -1 = no label),
-        lrp_weight (B, T, V).  masks: dict with optional 'image_features' (B, L, H), 'global' (B, E), 'output' (B, T, H).
+        lrp_weight (B, T, V).  masks: dict with optional 'image_features' (B, L, H), 'global' (B, E), 'output' (B, T, H),
+        'lstm_in' (T, 4, B, 2E), 'lstm_rec' (T, 4, B, H) (the LSTM cell's per-gate, per-step dropout).
         Returns (grads flat float32 device tensor, losses (5,) device tensor = total, loss head 1, loss head 2,
         accuracy head 1, accuracy head 2: the list `train_on_batch` returns)."""
         masks = masks or {}
@@ -236,15 +237,16 @@ class LRPEngine(object):
                 raise ValueError("mask '%s' must be %s" % (key, shape))
             return v
         mi, mg, mo = m("image_features", (B, self.L, self.H)), m("global", (B, self.E)), m("output", (B, T, self.H))
+        ml, mr = m("lstm_in", (T, 4, B, 2 * self.E)), m("lstm_rec", (T, 4, B, self.H))
         for k in masks:
-            if k not in ("image_features", "global", "output") and masks[k] is not None:
-                raise NotImplementedError("dropout mask '%s' is not supported by the fine-tune step" % k)
+            if k not in ("image_features", "global", "output", "lstm_in", "lstm_rec"):
+                raise ValueError("unknown dropout mask '%s'" % k)
         if grads is None:
             grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
         losses = torch.empty(5, dtype=torch.float32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(grads), p(losses),
-                                             self._stream()))
+        _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(ml), p(mr), p(grads),
+                                             p(losses), self._stream()))
         return grads, losses
 
     def train_apply(self, grads):

@@ -21,7 +21,8 @@ class TrainingLRPInferenceAdaptive(object):
                  seed=0, process_group=None):
         """explainer: an `ExplainImgCaptioningAdaptiveAttention` (its engine holds the weights).  Optimiser as compiled at
         models/model.py:1370 (`Adam(lr, clipvalue=0.01)`), dropout rate `config.drop_rate` (config.py:16) on the
-        image_features / global_img_feature / decoder output Dropout layers (M:1348, :1352, :1363)."""
+        image_features / global_img_feature / decoder output Dropout layers (M:1348, :1352, :1363) and inside the LSTM
+        cell (`dropout` / `recurrent_dropout`, M:1356-1358)."""
         self._explainer = explainer
         self._engine = explainer._engine
         self._lrp_layer = LRPInferenceLayerAdaptive(explainer, lrp_inference_mode, stop_words)
@@ -52,7 +53,8 @@ class TrainingLRPInferenceAdaptive(object):
             return None
         eng = self._engine
         mk = lambda *s: (torch.rand(*s, device=eng.device, generator=self._gen) >= p).to(torch.float32) / (1.0 - p)
-        return {"image_features": mk(B, eng.L, eng.H), "global": mk(B, eng.E), "output": mk(B, T, eng.H)}
+        return {"image_features": mk(B, eng.L, eng.H), "global": mk(B, eng.E), "output": mk(B, T, eng.H),
+                "lstm_in": mk(T, 4, B, 2 * eng.E), "lstm_rec": mk(T, 4, B, eng.H)}
 
     def train_on_batch(self, X, y, lrp_weight=None):
         """One iteration of the `while True` body (train.py:571-580).  X = [captions_input (B, T), images (B, H, W, 3)],

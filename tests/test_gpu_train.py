@@ -29,7 +29,8 @@ def _case(seed=0, B=3, Tn=5):
     lw = (1 + rs.uniform(0, 1, size=(B, Tn, V)) * (rs.uniform(size=(B, Tn, V)) < 0.2)).astype(np.float32)
     p = 0.5
     mk = lambda *s: ((rs.uniform(size=s) >= p) / (1 - p)).astype(np.float32)
-    masks = {"image_features": mk(B, L, H), "global": mk(B, H), "output": mk(B, Tn, H)}
+    masks = {"image_features": mk(B, L, H), "global": mk(B, H), "output": mk(B, Tn, H), "lstm_in": mk(Tn, 4, B, 2 * H),
+             "lstm_rec": mk(Tn, 4, B, H)}
     return w, X, cap_in, y, lw, masks
 
 
@@ -137,7 +138,8 @@ def test_gradients_match_oracle_midsize():
     y[0, 3:] = -1
     lw = (1 + rs.uniform(0, 1, size=(B, Tn, Vm)) * (rs.uniform(size=(B, Tn, Vm)) < 0.1)).astype(np.float32)
     mk = lambda *s: ((rs.uniform(size=s) >= 0.5) * 2.0).astype(np.float32)
-    masks = {"image_features": mk(B, Lm, Hm), "global": mk(B, Hm), "output": mk(B, Tn, Hm)}
+    masks = {"image_features": mk(B, Lm, Hm), "global": mk(B, Hm), "output": mk(B, Tn, Hm), "lstm_in": mk(Tn, 4, B, 2 * Hm),
+             "lstm_rec": mk(Tn, 4, B, Hm)}
     eng = LRPEngine(decoder="adaptive", cnn_cfg=cfg, img_hw=(hw, hw), L=Lm, D=Dm, H=Hm, E=Hm, V=Vm, max_images=B, max_tokens=8,
                     max_caption_len=Tn)
     eng.set_weights(w)
