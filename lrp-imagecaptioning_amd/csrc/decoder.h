@@ -4,10 +4,12 @@
 // forward() == _forward_beam_search, explain() == _explain_lstm_single_word[_sequence].
 #pragma once
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
 
+#include "cnn_kernels.h"
 #include "common.h"
 #include "conv_igemm.h"
 #include "decoder_gridtd_kernels.h"
@@ -138,13 +140,77 @@ struct Decoder {
     if (kind == LRP_DEC_ADAPTIVE) { for (const char* k : adaptive_names) known |= nm == k; }
     else { for (const char* k : gridtd_names) known |= nm == k; }
     if (!known) return fail(LRP_ERR_INVALID, "unknown weight name '%s'", nm.c_str());
+    if (raw_stale)
+      return fail(LRP_ERR_STATE, "the fine-tune step owns the weights of this handle (read them with lrp_train_get_master)");
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
     raw[nm].assign(data, data + n);
     raw_shape[nm].assign(shape, shape + ndim);
     finalized = false;
+    bx_ready = false;                                  // the scan's / gradient path's weight packs are derived too
+    grad_ready = false;
     return LRP_OK;
   }
+
+  // ---- fine-tune step: the derived operand copies rebuilt in place from device weights (adaptive decoder; every
+  // buffer below was sized by a previous finalize(); padding stays zero).  Wd(name) = device pointer of the Keras-layout
+  // matrix.  Returns 1 when there is nothing to rebuild in place yet (the caller then takes the host path).
+  static void tr2d(hipStream_t st, const float* src, int lds, int rows, int cols, float* dst, int ldd) {   // dst[c][r] = src[r][c]
+    hipLaunchKernelGGL(dec_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, st, src, lds, rows, cols, dst, ldd);
+  }
+  static hipError_t cp2d(hipStream_t st, const float* src, int lds, int rows, int cols, float* dst, int ldd) {
+    return hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToDevice, st);
+  }
+  int refresh_from_device(const std::function<const float*(const char*)>& Wd, hipStream_t st) {
+    if (kind != LRP_DEC_ADAPTIVE || !finalized) return 1;
+    if (!raw_stale) {                                  // last moment the host copies are current: build every lazily made pack
+      int64_t dummy = 0;
+      LRP_TRY(bx_prepare(&dummy));
+      if (!((H | E | D) & 3)) LRP_TRY(grad_prepare(&dummy));
+    }
+    const float *Wif = Wd("image_features_W"), *Wgl = Wd("global_W"), *Wi = Wd("lstm_Wi"), *Wh = Wd("lstm_Wh");
+    const int Kd = 2 * E + H, KD = conv_cinp(D), KH = conv_cinp(H);
+    tr2d(st, Wif, H, D, H, w_if_dual.as<float>(), KD);                                  // rows [0, H) and [H, 2H): W_if^T
+    tr2d(st, Wif, H, D, H, w_if_dual.as<float>() + (size_t)H * KD, KD);
+    tr2d(st, Wd("Wv"), H, H, H, w_v.as<float>(), KH);
+    tr2d(st, Wgl, E, D, E, WglobT.as<float>(), D);
+    tr2d(st, Wif, H, D, H, WifT.as<float>(), D);
+    LRP_HIP_CHECK(cp2d(st, Wif, H, D, H, w_ifT_pk.as<float>(), KH));                     // [d][j] = W_if[d][j], K padded
+    hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(w_ifT_pk.bytes / 32)), dim3(256), 0, st, w_ifT_pk.as<float>(),
+                       w_ifT_pks.as<float>(), w_ifT_pk.bytes / 32);
+    auto copy = [&](DevBuf& d, const char* nm, size_t n) {
+      return hipMemcpyAsync(d.p, Wd(nm), n * 4, hipMemcpyDeviceToDevice, st);
+    };
+    LRP_HIP_CHECK(copy(b_if, "image_features_b", H)); LRP_HIP_CHECK(copy(Wglob, "global_W", (size_t)D * E));
+    LRP_HIP_CHECK(copy(bglob, "global_b", E)); LRP_HIP_CHECK(copy(Wout, "output_W", (size_t)H * V));
+    LRP_HIP_CHECK(copy(bout, "output_b", V)); LRP_HIP_CHECK(copy(emb, "embedding", (size_t)V * E));
+    LRP_HIP_CHECK(copy(Wg, "Wg", (size_t)H * H)); LRP_HIP_CHECK(copy(Ws, "Ws", (size_t)H * H)); LRP_HIP_CHECK(copy(vvec, "V", H));
+    // Wcat (Kd x 5H) = [[Wi | Wx]; [Wh | Wh_sentinel]], bcat = [lstm_b | 0]
+    float* wc = Wcat.as<float>();
+    LRP_HIP_CHECK(cp2d(st, Wi, 4 * H, 2 * E, 4 * H, wc, 5 * H));
+    LRP_HIP_CHECK(cp2d(st, Wd("Wx"), H, 2 * E, H, wc + 4 * H, 5 * H));
+    LRP_HIP_CHECK(cp2d(st, Wh, 4 * H, H, 4 * H, wc + (size_t)2 * E * 5 * H, 5 * H));
+    LRP_HIP_CHECK(cp2d(st, Wd("Wh"), H, H, H, wc + (size_t)2 * E * 5 * H + 4 * H, 5 * H));
+    LRP_HIP_CHECK(copy(bcat, "lstm_b", 4 * H));
+    // gate-g block [Wi; Wh][:, 2H:3H] transposed (WgT) and as the batched scan's GEMM operand (bxWg1, rows padded to KH)
+    tr2d(st, Wi + 2 * H, 4 * H, 2 * E, H, WgT.as<float>(), Kd);
+    tr2d(st, Wh + 2 * H, 4 * H, H, H, WgT.as<float>() + 2 * E, Kd);
+    if (bx_ready) {
+      LRP_HIP_CHECK(cp2d(st, Wi + 2 * H, 4 * H, 2 * E, H, bxWg1.as<float>(), KH));
+      LRP_HIP_CHECK(cp2d(st, Wh + 2 * H, 4 * H, H, H, bxWg1.as<float>() + (size_t)2 * E * KH, KH));
+    }
+    if (grad_ready) {                                   // gradient baselines' operands (pack_rows)
+      const int K4 = conv_cinp(4 * H);
+      LRP_HIP_CHECK(cp2d(st, Wh, 4 * H, H, 4 * H, gW1.as<float>(), K4));
+      LRP_HIP_CHECK(cp2d(st, Wi, 4 * H, 2 * E, 4 * H, gW1.as<float>() + (size_t)H * K4, K4));
+      LRP_HIP_CHECK(cp2d(st, Wgl, E, D, E, gWglob.as<float>(), conv_cinp(E)));
+      LRP_HIP_CHECK(cp2d(st, Wif, H, D, H, gWif.as<float>(), KH));
+    }
+    LRP_HIP_CHECK(hipGetLastError());
+    raw_stale = true;
+    return LRP_OK;
+  }
+  bool raw_stale = false;                                // host copies in `raw` are older than the device operands
 
   int need(const char* nm, std::initializer_list<int64_t> shp) const {
     auto it = raw_shape.find(nm);

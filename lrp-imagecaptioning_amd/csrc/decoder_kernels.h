@@ -12,6 +12,22 @@
 
 namespace lrp {
 
+// dst[c * ldd + r] = src[r * lds + c]   (32 x 32 tiles through LDS; block (32, 8))
+__global__ void dec_transpose_kernel(const float* __restrict__ src, int lds, int rows, int cols, float* __restrict__ dst, int ldd) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    tile[j][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) dst[(size_t)c * ldd + r] = tile[threadIdx.x][j];
+  }
+}
+
+
 constexpr double LRP_EPS = 1e-7;     // K.epsilon() bound at E:157
 
 // z + sign(z)*eps, sign(0) = +1   (E:141-144)

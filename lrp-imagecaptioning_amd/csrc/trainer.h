@@ -349,13 +349,18 @@ struct Trainer {
       LRP_TRY(enc.repack_conv_from_device((int)li, master.as<float>() + params[2 * li].off, master.as<float>() + params[2 * li + 1].off,
                                           ws.as<float>(), st));
     const size_t dec0 = params[2 * enc.layers.size()].off, l0 = params[2].off;     // [0, l0): image layer; [dec0, n): decoder
+    std::function<const float*(const char*)> Wd = [&](const char* nm) -> const float* { return W(nm); };
+    const int drc = dec.refresh_from_device(Wd, st);   // 1: the decoder has not built its operand copies yet
+    if (drc != LRP_OK && drc != 1) return drc;
     LRP_HIP_CHECK(hipMemcpyAsync(host_pinned, master.p, l0 * 4, hipMemcpyDeviceToHost, st));
-    LRP_HIP_CHECK(hipMemcpyAsync(host_pinned + dec0, master.as<float>() + dec0, (n_total - dec0) * 4, hipMemcpyDeviceToHost, st));
+    if (drc == 1)
+      LRP_HIP_CHECK(hipMemcpyAsync(host_pinned + dec0, master.as<float>() + dec0, (n_total - dec0) * 4, hipMemcpyDeviceToHost, st));
     LRP_HIP_CHECK(hipStreamSynchronize(st));
     LRP_TRY(enc.set_conv_weight(0, host_pinned + params[0].off, total));
     LRP_TRY(enc.set_conv_bias(0, host_pinned + params[1].off, total));
-    for (size_t pi = 2 * enc.layers.size(); pi < params.size(); ++pi)
-      LRP_TRY(dec.set_weight(params[pi].name, host_pinned + params[pi].off, (int)params[pi].shape.size(), params[pi].shape.data(), total));
+    if (drc == 1)
+      for (size_t pi = 2 * enc.layers.size(); pi < params.size(); ++pi)
+        LRP_TRY(dec.set_weight(params[pi].name, host_pinned + params[pi].off, (int)params[pi].shape.size(), params[pi].shape.data(), total));
     enc.encoded = 0;                               // caches belong to the old weights
     return LRP_OK;
   }

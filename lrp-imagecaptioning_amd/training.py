@@ -70,7 +70,7 @@ class TrainingLRPInferenceAdaptive(object):
             y_idx = y.astype(np.int32)
         if lrp_weight is None:
             y_pred = self.predict_on_batch(X)
-            lrp_weight = self._lrp_layer.call([X[0], X[1], y_pred.cpu().numpy()], images_encoded=True)
+            lrp_weight = self._lrp_layer.call_device(X[1], y_pred, images_encoded=True)
             if eng.n_images < B:                       # nothing was explained (no positions): the caches are still needed
                 eng.encode_images(X[1])
         else:

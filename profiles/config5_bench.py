@@ -33,10 +33,8 @@ def main():
         torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return (time.perf_counter() - t) * 1e3, r
     tr.train_on_batch([cap_in, X], y)                                   # warm-up
     t_pred, y_pred = timed(lambda: tr.predict_on_batch([cap_in, X]))
-    yp = y_pred.cpu().numpy()
-    t_lrp, lw = timed(lambda: tr._lrp_layer.call([cap_in, X, yp]))
-    n_maps = int((lw != 1).sum())
-    lw_dev = torch.as_tensor(lw, dtype=torch.float32).cuda()
+    t_lrp, lw_dev = timed(lambda: tr._lrp_layer.call_device(X, y_pred, images_encoded=True))
+    n_maps = int((lw_dev != 1).sum())
     masks = tr._masks(B, T)
     t_step, (g, losses) = timed(lambda: eng.train_step(cap_in, y, lw_dev, masks, grads=tr._grads))
     t_apply, _ = timed(lambda: eng.train_apply(g))

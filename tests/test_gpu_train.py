@@ -91,6 +91,32 @@ def test_adam_step_matches_oracle_and_engine_follows():
     got = eng.cnn_explain([0], R).cpu().numpy()
     want = Cn.analyze(Cn.vgg_layers(wn, CFG), X[:1], R.reshape(1, 4, 4, D))
     assert rel_l1(got, want) < 1e-4
+    # ... and the decoder's derived matrices (concatenated LSTM kernel, transposed gate block, scan operand)
+    from oracle.decoder_ref import AdaptiveOracle
+    from oracle.decoder_grad_ref import AdaptiveGradOracle
+    cap = [5, 9, 17, 1]
+    for rounds in range(2):                              # second round: after another update (everything rebuilt in place)
+        eng.decoder_forward([cap])
+        o = AdaptiveOracle(wn, L, D, H, H)
+        o.forward(ref[:1].reshape(1, 4, 4, D).astype(np.float32), cap)
+        Rf, att, rw = eng.decoder_explain([0, 0], [1, 3])
+        for k, t in enumerate((1, 3)):
+            Ro, _ = o.explain(t)
+            assert rel_l1(Rf[k].cpu().numpy(), Ro.reshape(L, D)) < 1e-4
+        d, _ = eng.decoder_gradient([0], [3])
+        og = AdaptiveGradOracle(wn, L, D, H, H)
+        og.forward(ref[:1].reshape(1, 4, 4, D).astype(np.float32), cap)
+        assert rel_l1(d[0].cpu().numpy(), np.asarray(og.backward(3)[0]).reshape(L, D)) < 1e-4
+        if rounds == 0:
+            eng.encode_images(X)
+            g2, _ = eng.train_step(cap_in, y, lw, masks)
+            eng.train_apply(g2)
+            new = eng.train_weights()
+            wn = {k: new[k].reshape(np.shape(w[k])) for k in w}
+            eng.encode_images(X)
+            ref = Cn.forward(Cn.vgg_layers(wn, CFG), X).reshape(len(X), -1, D)
+    with pytest.raises(RuntimeError):
+        eng.set_weights({"Wv": w["Wv"]})                 # the trainer owns the weights now
     with pytest.raises(ValueError):
         eng.train_step(cap_in[:, :1], y[:, :1], lw[:, :1])           # T < 2
 
@@ -109,6 +135,11 @@ def test_training_loop_class():
     y_pred = tr.predict_on_batch([cap_in, X]).cpu().numpy()
     _, _, _, _, logits = T.loss_and_grads(w, CFG, X, cap_in, y, np.ones_like(lw))
     assert rel_l1(y_pred, logits) < 1e-5                                   # predict == the oracle's inference forward
+    y_dev = tr.predict_on_batch([cap_in, X])
+    lw_host = tr._lrp_layer.call([cap_in, X, y_dev.cpu().numpy()])
+    lw_dev = tr._lrp_layer.call_device(X, y_dev).cpu().numpy()
+    assert (lw_host != 1).sum() > 0
+    np.testing.assert_allclose(lw_dev, lw_host, rtol=1e-6)               # device-side assembly == the reference-shaped call
     onehot = np.zeros(y.shape + (V,), np.float32)
     for b in range(y.shape[0]):
         for t in range(y.shape[1]):
