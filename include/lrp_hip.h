@@ -274,6 +274,17 @@ int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, in
 int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, int32_t npix, int32_t C, int32_t mode,
                        void* stream);
 
+/* Operator-level entries of the fine-tune step's dense products (unit tests at real layer sizes; csrc/train_gemm.h).
+ * lrp_op_sgemm: C (+)= op(A) op(B) on the fp32 matrix cores, row-major with leading dimensions;
+ *   op(A)[m][k] = transA ? A[k*lda + m] : A[m*lda + k], op(B)[k][n] = transB ? B[n*ldb + k] : B[k*ldb + n]
+ *   (not both transposed).  ws_dev / ws_floats: scratch for the split over K (NULL: no split).
+ * lrp_op_conv_wgrad: weight and bias gradient of a 3x3 'same' convolution: x (NB,H,W,Cin), dz (NB,H,W,Cout) ->
+ *   dw (3,3,Cin,Cout) HWIO, db (Cout) or NULL; all nine taps in one launch, K = NB*H*W split deterministically. */
+int lrp_op_sgemm(const float* A_dev, const float* B_dev, float* C_dev, int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldb,
+                 int64_t ldc, int32_t transA, int32_t transB, int32_t accumulate, float* ws_dev, int64_t ws_floats, void* stream);
+int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H, int32_t W,
+                      int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream);
+
 /* ---- Fine-tune step of the LRP-inference training loop (train.py:573-581:
  * `keras_model.train_on_batch(X + [lrp_weight], [y, y])` on ImgCaptioningAdaptiveAttentionLRPInferenceModel,
  * models/model.py:1340-1374; VGG encoder + adaptive attention).  Per batch the caller runs lrp_encode_images,

@@ -59,6 +59,9 @@ SYMBOLS = {
     "lrp_decoder_gradient": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "lrp_cnn_walk": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
     "lrp_op_avgpool_lrp": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
+    "lrp_op_sgemm": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                               C.c_int32, _P, C.c_int64, _P]),
+    "lrp_op_conv_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
     "lrp_train_begin": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "lrp_train_flat_size": (C.c_int64, [_P]),
     "lrp_train_num_params": (C.c_int32, [_P]),

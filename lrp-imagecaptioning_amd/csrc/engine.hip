@@ -419,6 +419,32 @@ int lrp_preprocess_images(const uint8_t* rgb_dev, float* out_dev, int32_t NB, in
   return LRP_OK;
 }
 
+// ---- operator-level entries of the fine-tune step's products (unit tests of train_gemm.h at real layer sizes)
+int lrp_op_sgemm(const float* A_dev, const float* B_dev, float* C_dev, int32_t M, int32_t N, int64_t K, int64_t lda, int64_t ldb,
+                 int64_t ldc, int32_t transA, int32_t transB, int32_t accumulate, float* ws_dev, int64_t ws_floats, void* stream) {
+  if (!A_dev || !B_dev || !C_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (M < 1 || N < 1 || K < 1 || (transA && transB)) return fail(LRP_ERR_INVALID, "bad sgemm shape / transposes");
+  SgemmArgs a{};
+  a.A = A_dev; a.B = B_dev; a.C = C_dev; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.transA = transA != 0; a.transB = transB != 0; a.accumulate = accumulate != 0;
+  LRP_HIP_CHECK(sgemm(a, ws_dev, ws_dev ? (size_t)ws_floats : 0, S(stream)));
+  return LRP_OK;
+}
+
+int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H, int32_t W,
+                      int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream) {
+  if (!x_dev || !dz_dev || !dw_hwio_dev || !ws_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (NB < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(LRP_ERR_INVALID, "sizes must be positive");
+  if (ws_floats < (int64_t)2 * 9 * Cin * Cout) return fail(LRP_ERR_INVALID, "workspace smaller than 2 x 9 x Cin x Cout floats");
+  SgemmArgs a{};
+  a.A = x_dev; a.lda = Cin; a.B = dz_dev; a.ldb = Cout; a.C = dw_hwio_dev; a.ldc = Cout;
+  a.M = Cin; a.N = Cout; a.K = (long)NB * H * W; a.transA = 1;
+  a.gather = 1; a.gH = H; a.gW = W; a.taps = 9; a.tapC = (long)Cin * Cout;
+  LRP_HIP_CHECK(sgemm(a, ws_dev, (size_t)ws_floats, S(stream)));
+  if (db_dev) LRP_HIP_CHECK(colsum(dz_dev, Cout, (long)NB * H * W, Cout, db_dev, 0, ws_dev, (size_t)ws_floats, S(stream)));
+  return LRP_OK;
+}
+
 // ---- fine-tune step, trainer.h
 int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float beta2, float eps) {
   if (!h) return fail(LRP_ERR_INVALID, "null handle");

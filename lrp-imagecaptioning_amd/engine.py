@@ -382,6 +382,34 @@ def op_conv(x, w_hwio, bias, aux, mode, taps=9, split_bf16=False):
     return out
 
 
+def op_sgemm(A, B, transA=False, transB=False, C_init=None, split=True):
+    """C (+)= op(A) op(B) through lrp_op_sgemm (fp32 MFMA); A, B 2-D device tensors (views with a row stride allowed)."""
+    lib = _capi.load()
+    M, K = (A.shape[1], A.shape[0]) if transA else A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device) if C_init is None else C_init
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=A.device) if split else None
+    _capi.check(lib.lrp_op_sgemm(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(out.data_ptr()), M, N, K,
+                                 A.stride(0), B.stride(0), out.stride(0), int(transA), int(transB), int(C_init is not None),
+                                 C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+                                 _cur_stream(A.device)))
+    return out
+
+
+def op_conv_wgrad(x, dz):
+    """Weight / bias gradient of a 3x3 'same' conv (lrp_op_conv_wgrad): x (NB,H,W,Cin), dz (NB,H,W,Cout) -> (dw HWIO, db)."""
+    lib = _capi.load()
+    NB, H, W, Cin = x.shape
+    Cout = dz.shape[3]
+    dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=x.device)
+    db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=x.device)
+    _capi.check(lib.lrp_op_conv_wgrad(C.c_void_p(x.data_ptr()), C.c_void_p(dz.data_ptr()), C.c_void_p(dw.data_ptr()),
+                                      C.c_void_p(db.data_ptr()), NB, H, W, Cin, Cout, C.c_void_p(ws.data_ptr()), ws.numel(),
+                                      _cur_stream(x.device)))
+    return dw, db
+
+
 def _cur_stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 

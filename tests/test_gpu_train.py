@@ -188,3 +188,46 @@ def test_gradients_match_oracle_midsize():
     assert not bad, bad
     g2, _ = eng.train_step(cap_in, y, lw, masks)
     assert torch.equal(grads, g2)                       # no atomics anywhere: run-to-run identical
+
+
+SGEMM_CASES = [  # (M, N, K, transA, transB): the three forms at shapes of the step (tile edges, K split, strided views)
+    (512, 10000, 672, True, False), (672, 512, 10000, False, True), (672, 2048, 1024, False, False),
+    (32, 2048, 512, False, False), (32, 512, 2048, False, True), (136, 72, 5000, True, False), (64, 64, 100000, True, False),
+    (3, 64, 70000, True, False), (1, 1, 1, False, False), (129, 257, 33, False, True),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", SGEMM_CASES)
+def test_sgemm_matches_torch(M, N, K, ta, tb):
+    """csrc/train_gemm.h against a float64 torch product (the MFMA accumulates fp32: tolerance ~ sqrt(K) ulp)."""
+    from lrp_imagecaptioning_amd.engine import op_sgemm
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    pad = 8                                                # operands are views into wider buffers: lda / ldb != width
+    A = torch.randn((K, M + pad) if ta else (M, K + pad), device="cuda", generator=g)[:, :(M if ta else K)]
+    B = torch.randn((N, K + pad) if tb else (K, N + pad), device="cuda", generator=g)[:, :(K if tb else N)]
+    want = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    got = op_sgemm(A, B, ta, tb)
+    scale = want.abs().mean()
+    assert float((got.double() - want).abs().max() / scale) < 2e-5
+    C0 = torch.randn((M, N), device="cuda", generator=g)
+    got2 = op_sgemm(A, B, ta, tb, C_init=C0.clone())
+    assert float((got2.double() - (want + C0.double())).abs().max() / scale) < 2e-5
+    assert torch.equal(op_sgemm(A, B, ta, tb), got)       # deterministic K split
+
+
+@pytest.mark.parametrize("NB,HW,Cin,Cout", [(2, 224, 3, 64), (2, 112, 64, 128), (4, 28, 512, 512), (3, 14, 136, 72), (1, 5, 8, 8)])
+def test_conv_wgrad_matches_torch(NB, HW, Cin, Cout):
+    """lrp_op_conv_wgrad at VGG16 layer shapes against torch's conv weight gradient in float64 on the CPU."""
+    import torch.nn.functional as F
+    from lrp_imagecaptioning_amd.engine import op_conv_wgrad
+    g = torch.Generator().manual_seed(NB + HW)
+    x = torch.randn((NB, HW, HW, Cin), generator=g)
+    dz = torch.randn((NB, HW, HW, Cout), generator=g) * (torch.rand((NB, HW, HW, Cout), generator=g) > 0.5)
+    w = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w, b, padding=1)
+    y.backward(dz.double().permute(0, 3, 1, 2))
+    dw, db = op_conv_wgrad(x.cuda(), dz.cuda())
+    want = w.grad.permute(2, 3, 1, 0)                                   # OIHW -> HWIO
+    assert rel_l1(dw.cpu().numpy(), want.numpy()) < 1e-5
+    assert rel_l1(db.cpu().numpy(), b.grad.numpy()) < 1e-5
