@@ -13,6 +13,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace lrp {
 
@@ -187,7 +188,9 @@ inline bool sg_aligned(const void* p, long ld) { return (((uintptr_t)p) & 15) ==
 
 template <bool TA, bool TB>
 inline void sgemm_launch_tile(int tm, int tn, dim3 grid, hipStream_t st, const SgemmArgs& a) {
-  if (tm == 1 && tn == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 1, 1>), grid, dim3(256), 0, st, a);
+  if (tm == 4) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 4, 2>), grid, dim3(256), 0, st, a);
+  else if (tn == 4) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 2, 4>), grid, dim3(256), 0, st, a);
+  else if (tm == 1 && tn == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 1, 1>), grid, dim3(256), 0, st, a);
   else if (tm == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 1, 2>), grid, dim3(256), 0, st, a);
   else if (tn == 1) hipLaunchKernelGGL((sgemm_kernel<TA, TB, 2, 1>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((sgemm_kernel<TA, TB, 2, 2>), grid, dim3(256), 0, st, a);
@@ -200,7 +203,12 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   if (a.M < 1 || a.N < 1 || a.K < 1) return hipErrorInvalidValue;
   a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
   a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
-  const int tm = a.M <= 64 ? 1 : 2, tn = a.N <= 64 ? 1 : 2;
+  static const int big = [] { const char* e = getenv("LRP_SGEMM_BIG"); return e ? atoi(e) : 1; }();
+  int tm = a.M <= 64 ? 1 : 2, tn = a.N <= 64 ? 1 : 2;
+  if (big && a.K >= 4096) {                                       // 256 x 128 tiles: 1.5x the FLOPs per byte staged
+    if (a.M >= 256 && a.N >= 128) tm = 4;
+    else if (a.N >= 256 && a.M >= 128) tn = 4;
+  }
   const int gx = (a.N + 64 * tn - 1) / (64 * tn), gy = (a.M + 64 * tm - 1) / (64 * tm);
   int ks = 1;
   const int taps = a.gather && a.taps > 1 ? a.taps : 1;

@@ -380,6 +380,13 @@ __global__ __launch_bounds__(256) void tr_embedding_bwd_kernel(const float* __re
     dEmb[(size_t)row * E + e] = s;
   }
 }
+// Image-layer weight gradient from the product over the im2col matrix A1 = [x+ patch(27) | 0 | x- patch(27) | 0]:
+// dW[k][co] = G[k][co] + G[32 + k][co], k = tap * 3 + c < 27   (G = A1^T dZ, 64 x Cout)
+__global__ __launch_bounds__(256) void tr_fold_image_wgrad_kernel(const float* __restrict__ G, float* __restrict__ dW, int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < 27 * Cout) dW[i] = G[i] + G[32 * Cout + i];
+}
+
 // keras Adam with clipvalue (optimizers.py: clip, moments, update); lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) from the host
 __global__ __launch_bounds__(256) void tr_adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, size_t n, float lr_t, float clip, float b1, float b2,

@@ -312,7 +312,13 @@ struct Trainer {
       const ConvLayer& Ly = enc.layers[li];
       const long K = (long)B * Ly.H * Ly.W;
       float* gw = grads + params[2 * li].off;
-      {
+      if (li == 0) {
+        // the image layer: one product over the im2col matrix the forward already built (64 columns = 27 taps x
+        // channels for x+ and again for x-) instead of nine M = 3 products
+        float* G = dX.as<float>();                  // (64 x cout) scratch; dX is dead by now
+        LRP_TRY(mm(true, false, 64, Ly.cout, K, enc.a1.as<float>(), 64, dZ, Ly.cout, G, Ly.cout, false, st));
+        hipLaunchKernelGGL(tr_fold_image_wgrad_kernel, dim3((27 * Ly.cout + 255) / 256), dim3(256), 0, st, G, gw, Ly.cout);
+      } else {
         SgemmArgs a{};                              // all nine taps in one launch (blockIdx.z = tap x K slice)
         a.A = enc.layer_input(li); a.lda = Ly.cin; a.B = dZ; a.ldb = Ly.cout; a.C = gw; a.ldc = Ly.cout;
         a.M = Ly.cin; a.N = Ly.cout; a.K = K; a.transA = 1; a.transB = 0;
