@@ -287,7 +287,8 @@ int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_de
 
 /* ---- Fine-tune step of the LRP-inference training loop (train.py:573-581:
  * `keras_model.train_on_batch(X + [lrp_weight], [y, y])` on ImgCaptioningAdaptiveAttentionLRPInferenceModel,
- * models/model.py:1340-1374; VGG encoder + adaptive attention).  Per batch the caller runs lrp_encode_images,
+ * models/model.py:1340-1374, and its grid-TD twin, train.py:645-656 on ImgCaptioningGridTDLRPInferenceModel,
+ * models/model.py:1254-1311; VGG encoder, the decoder the handle was created with).  Per batch the caller runs lrp_encode_images,
  * computes lrp_weight with the explain entry points above, then:
  *   lrp_train_step : training-mode decoder forward on the cached features, loss 0.5 CE(y, logits[:, :-1]) +
  *                    0.5 CE(y, (logits * lrp_weight)[:, :-1]) (M:95-103, :1370-1373), backward through the decoder and
@@ -303,15 +304,16 @@ int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_de
  * lrp_weight_dev (B, T, V) float32.  Dropout masks (values 0 or 1/(1-p)) or NULL: image_features (B, L, H),
  * global (B, E), output (B, T, H); LSTM-cell dropout (keras `dropout` / `recurrent_dropout`, one mask per gate i f c o
  * and per step because the wrapper calls the cell inside the K.rnn loop, M:582): lstm_in (T, 4, B, 2E),
- * lstm_rec (T, 4, B, H). */
+ * lstm_rec (T, 4, B, H) (for grid-TD the language LSTM: lstm_in (T, 4, B, 2H)); logits (B, T, V): the grid-TD model's
+ * Dropout on the logits (M:1303-1304), NULL for the adaptive model. */
 int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float beta2, float eps);
 int64_t lrp_train_flat_size(const lrp_handle* h);
 int32_t lrp_train_num_params(const lrp_handle* h);
 int lrp_train_param_info(const lrp_handle* h, int32_t i, const char** name, int64_t* offset, int64_t* size);
 int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const int32_t* y_idx_dev,
                    const float* lrp_weight_dev, const float* mask_image_features_dev, const float* mask_global_dev,
-                   const float* mask_output_dev, const float* mask_lstm_in_dev, const float* mask_lstm_rec_dev, float* grads_dev,
-                   float* losses_dev, void* stream);
+                   const float* mask_output_dev, const float* mask_lstm_in_dev, const float* mask_lstm_rec_dev,
+                   const float* mask_logits_dev, float* grads_dev, float* losses_dev, void* stream);
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream);
 int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
 

@@ -162,17 +162,18 @@ struct Decoder {
     return hipMemcpy2DAsync(dst, (size_t)ldd * 4, src, (size_t)lds * 4, (size_t)cols * 4, rows, hipMemcpyDeviceToDevice, st);
   }
   int refresh_from_device(const std::function<const float*(const char*)>& Wd, hipStream_t st) {
-    if (kind != LRP_DEC_ADAPTIVE || !finalized) return 1;
+    if (!finalized) return 1;
     if (!raw_stale) {                                  // last moment the host copies are current: build every lazily made pack
       int64_t dummy = 0;
       LRP_TRY(bx_prepare(&dummy));
       if (!((H | E | D) & 3)) LRP_TRY(grad_prepare(&dummy));
     }
-    const float *Wif = Wd("image_features_W"), *Wgl = Wd("global_W"), *Wi = Wd("lstm_Wi"), *Wh = Wd("lstm_Wh");
-    const int Kd = 2 * E + H, KD = conv_cinp(D), KH = conv_cinp(H);
+    const bool td = kind == LRP_DEC_GRIDTD;
+    const float *Wif = Wd("image_features_W"), *Wgl = Wd("global_W");
+    const int KD = conv_cinp(D), KH = conv_cinp(H), K4 = conv_cinp(4 * H);
     tr2d(st, Wif, H, D, H, w_if_dual.as<float>(), KD);                                  // rows [0, H) and [H, 2H): W_if^T
     tr2d(st, Wif, H, D, H, w_if_dual.as<float>() + (size_t)H * KD, KD);
-    tr2d(st, Wd("Wv"), H, H, H, w_v.as<float>(), KH);
+    tr2d(st, Wd(td ? "W_va" : "Wv"), H, H, H, w_v.as<float>(), KH);
     tr2d(st, Wgl, E, D, E, WglobT.as<float>(), D);
     tr2d(st, Wif, H, D, H, WifT.as<float>(), D);
     LRP_HIP_CHECK(cp2d(st, Wif, H, D, H, w_ifT_pk.as<float>(), KH));                     // [d][j] = W_if[d][j], K padded
@@ -184,25 +185,44 @@ struct Decoder {
     LRP_HIP_CHECK(copy(b_if, "image_features_b", H)); LRP_HIP_CHECK(copy(Wglob, "global_W", (size_t)D * E));
     LRP_HIP_CHECK(copy(bglob, "global_b", E)); LRP_HIP_CHECK(copy(Wout, "output_W", (size_t)H * V));
     LRP_HIP_CHECK(copy(bout, "output_b", V)); LRP_HIP_CHECK(copy(emb, "embedding", (size_t)V * E));
-    LRP_HIP_CHECK(copy(Wg, "Wg", (size_t)H * H)); LRP_HIP_CHECK(copy(Ws, "Ws", (size_t)H * H)); LRP_HIP_CHECK(copy(vvec, "V", H));
-    // Wcat (Kd x 5H) = [[Wi | Wx]; [Wh | Wh_sentinel]], bcat = [lstm_b | 0]
-    float* wc = Wcat.as<float>();
-    LRP_HIP_CHECK(cp2d(st, Wi, 4 * H, 2 * E, 4 * H, wc, 5 * H));
-    LRP_HIP_CHECK(cp2d(st, Wd("Wx"), H, 2 * E, H, wc + 4 * H, 5 * H));
-    LRP_HIP_CHECK(cp2d(st, Wh, 4 * H, H, 4 * H, wc + (size_t)2 * E * 5 * H, 5 * H));
-    LRP_HIP_CHECK(cp2d(st, Wd("Wh"), H, H, H, wc + (size_t)2 * E * 5 * H + 4 * H, 5 * H));
-    LRP_HIP_CHECK(copy(bcat, "lstm_b", 4 * H));
-    // gate-g block [Wi; Wh][:, 2H:3H] transposed (WgT) and as the batched scan's GEMM operand (bxWg1, rows padded to KH)
-    tr2d(st, Wi + 2 * H, 4 * H, 2 * E, H, WgT.as<float>(), Kd);
-    tr2d(st, Wh + 2 * H, 4 * H, H, H, WgT.as<float>() + 2 * E, Kd);
-    if (bx_ready) {
-      LRP_HIP_CHECK(cp2d(st, Wi + 2 * H, 4 * H, 2 * E, H, bxWg1.as<float>(), KH));
-      LRP_HIP_CHECK(cp2d(st, Wh + 2 * H, 4 * H, H, H, bxWg1.as<float>() + (size_t)2 * E * KH, KH));
+    LRP_HIP_CHECK(copy(Wg, td ? "W_ha" : "Wg", (size_t)H * H)); LRP_HIP_CHECK(copy(Ws, td ? "W_s" : "Ws", (size_t)H * H));
+    LRP_HIP_CHECK(copy(vvec, td ? "W_a" : "V", H));
+    // one LSTM: Wcat (Kd x N) = [[Wi | Wsx]; [Wh | Wsh]] (N = 5H with a sentinel, else 4H), bias row, transposed gate-g
+    // block WgT (H x Kd), the scan's GEMM operand (rows of the gate-g block, K padded) and the gradient path's pack_rows
+    auto lstm = [&](const char* wi, const char* wh, const char* wsx, const char* wsh, const char* bias, int Kx, DevBuf& Wc,
+                    DevBuf& bc, DevBuf& WgT_, DevBuf* bxW, DevBuf* gW) -> int {
+      const float *Wi = Wd(wi), *Wh = Wd(wh);
+      const int Kd = Kx + H, Nn = wsx ? 5 * H : 4 * H;
+      float* wc = Wc.as<float>();
+      LRP_HIP_CHECK(cp2d(st, Wi, 4 * H, Kx, 4 * H, wc, Nn));
+      LRP_HIP_CHECK(cp2d(st, Wh, 4 * H, H, 4 * H, wc + (size_t)Kx * Nn, Nn));
+      if (wsx) {
+        LRP_HIP_CHECK(cp2d(st, Wd(wsx), H, Kx, H, wc + 4 * H, Nn));
+        LRP_HIP_CHECK(cp2d(st, Wd(wsh), H, H, H, wc + (size_t)Kx * Nn + 4 * H, Nn));
+      }
+      LRP_HIP_CHECK(hipMemcpyAsync(bc.p, Wd(bias), (size_t)4 * H * 4, hipMemcpyDeviceToDevice, st));
+      tr2d(st, Wi + 2 * H, 4 * H, Kx, H, WgT_.as<float>(), Kd);
+      tr2d(st, Wh + 2 * H, 4 * H, H, H, WgT_.as<float>() + Kx, Kd);
+      if (bxW) {
+        LRP_HIP_CHECK(cp2d(st, Wi + 2 * H, 4 * H, Kx, H, bxW->as<float>(), KH));
+        LRP_HIP_CHECK(cp2d(st, Wh + 2 * H, 4 * H, H, H, bxW->as<float>() + (size_t)Kx * KH, KH));
+      }
+      if (gW) {                                         // rows = [Wh (H) ; Wi (Kx)], K = 4H
+        LRP_HIP_CHECK(cp2d(st, Wh, 4 * H, H, 4 * H, gW->as<float>(), K4));
+        LRP_HIP_CHECK(cp2d(st, Wi, 4 * H, Kx, 4 * H, gW->as<float>() + (size_t)H * K4, K4));
+      }
+      return LRP_OK;
+    };
+    if (td) {
+      LRP_TRY(lstm("td_Wi", "td_Wh", "W_x", "W_h", "td_b", H + 2 * E, Wcat, bcat, WgT, bx_ready ? &bxWg1 : nullptr,
+                   grad_ready ? &gW1 : nullptr));
+      LRP_TRY(lstm("lang_Wi", "lang_Wh", nullptr, nullptr, "lang_b", 2 * H, Wcat2, bcat2, Wg2T, bx_ready ? &bxWg2 : nullptr,
+                   grad_ready ? &gW2 : nullptr));
+    } else {
+      LRP_TRY(lstm("lstm_Wi", "lstm_Wh", "Wx", "Wh", "lstm_b", 2 * E, Wcat, bcat, WgT, bx_ready ? &bxWg1 : nullptr,
+                   grad_ready ? &gW1 : nullptr));
     }
-    if (grad_ready) {                                   // gradient baselines' operands (pack_rows)
-      const int K4 = conv_cinp(4 * H);
-      LRP_HIP_CHECK(cp2d(st, Wh, 4 * H, H, 4 * H, gW1.as<float>(), K4));
-      LRP_HIP_CHECK(cp2d(st, Wi, 4 * H, 2 * E, 4 * H, gW1.as<float>() + (size_t)H * K4, K4));
+    if (grad_ready) {
       LRP_HIP_CHECK(cp2d(st, Wgl, E, D, E, gWglob.as<float>(), conv_cinp(E)));
       LRP_HIP_CHECK(cp2d(st, Wif, H, D, H, gWif.as<float>(), KH));
     }

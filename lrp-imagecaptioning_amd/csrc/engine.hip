@@ -469,11 +469,14 @@ int lrp_train_param_info(const lrp_handle* h, int32_t i, const char** name, int6
 
 int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const int32_t* y_idx_dev,
                    const float* lrp_weight_dev, const float* mask_image_features_dev, const float* mask_global_dev,
-                   const float* mask_output_dev, const float* mask_lstm_in_dev, const float* mask_lstm_rec_dev, float* grads_dev,
-                   float* losses_dev, void* stream) {
+                   const float* mask_output_dev, const float* mask_lstm_in_dev, const float* mask_lstm_rec_dev,
+                   const float* mask_logits_dev, float* grads_dev, float* losses_dev, void* stream) {
   if (!h || !cap_in_dev || !y_idx_dev || !lrp_weight_dev || !grads_dev) return fail(LRP_ERR_INVALID, "null argument");
-  return h->trainer.step(h->enc, h->feat(), B, T, cap_in_dev, y_idx_dev, lrp_weight_dev, mask_image_features_dev, mask_global_dev,
-                         mask_output_dev, mask_lstm_in_dev, mask_lstm_rec_dev, grads_dev, losses_dev, &h->ws_bytes, S(stream));
+  Trainer::StepIn in{};
+  in.feat = h->feat(); in.B = B; in.T = T; in.cap_in = cap_in_dev; in.y_idx = y_idx_dev; in.lrp_weight = lrp_weight_dev;
+  in.m_if = mask_image_features_dev; in.m_glob = mask_global_dev; in.m_out = mask_output_dev; in.m_lin = mask_lstm_in_dev;
+  in.m_lrec = mask_lstm_rec_dev; in.m_logits = mask_logits_dev; in.grads = grads_dev; in.losses_dev = losses_dev; in.st = S(stream);
+  return h->trainer.step(h->enc, in, &h->ws_bytes);
 }
 
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream) {

@@ -67,15 +67,38 @@ __global__ __launch_bounds__(256) void tr_mean_rows_bwd_kernel(float* __restrict
     dfeat[i] += dfavg[b * D + i % D] / (float)L;
   }
 }
-// X[t][b] = [embedding[cap_in[b][t]] | glob[b]]   (M:581 input_x)
+// X[t][b] = [embedding[cap_in[b][t]] | glob[b]] (adaptive, M:581 input_x: emb_off 0, glob_off E) or [glob | embedding]
+// (grid-TD, the non-recurrent part of M:792: glob_off 0, emb_off E)
 __global__ __launch_bounds__(256) void tr_build_x_kernel(const float* __restrict__ emb, const float* __restrict__ glob,
-                                                         const int* __restrict__ cap_in, float* __restrict__ X, int B, int T, int E) {
+                                                         const int* __restrict__ cap_in, float* __restrict__ X, int B, int T, int E,
+                                                         int emb_off, int glob_off) {
   const int t = blockIdx.x / B, b = blockIdx.x % B;
   const int row = cap_in[b * T + t];
   float* x = X + (size_t)blockIdx.x * 2 * E;
   for (int e = threadIdx.x; e < E; e += 256) {
-    x[e] = emb[(size_t)row * E + e];
-    x[E + e] = glob[(size_t)b * E + e];
+    x[emb_off + e] = emb[(size_t)row * E + e];
+    x[glob_off + e] = glob[(size_t)b * E + e];
+  }
+}
+// grid-TD output of a step and its backward head: OUTm = (h2 + c_hat) * mask (M:816 + Dropout M:1299);
+// DCH = dOUTm * mask, dH2tot = dH2 + DCH
+__global__ __launch_bounds__(256) void tr_out_fwd_kernel(const float* __restrict__ h2, const float* __restrict__ chat,
+                                                         const float* __restrict__ mask_out, float* __restrict__ OUTm, int B, int H, int T,
+                                                         int t) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * H; idx += gridDim.x * 256) {
+    float o = h2[idx] + chat[idx];
+    if (mask_out) o *= mask_out[((size_t)(idx / H) * T + t) * H + idx % H];
+    OUTm[idx] = o;
+  }
+}
+__global__ __launch_bounds__(256) void tr_out_bwd_kernel(const float* __restrict__ dOUTm, const float* __restrict__ mask_out,
+                                                         const float* __restrict__ dH2, float* __restrict__ DCH, float* __restrict__ dH2tot,
+                                                         int B, int H, int T, int t) {
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * H; idx += gridDim.x * 256) {
+    float d = dOUTm[idx];
+    if (mask_out) d *= mask_out[((size_t)(idx / H) * T + t) * H + idx % H];
+    DCH[idx] = d;
+    dH2tot[idx] = (dH2 ? dH2[idx] : 0.f) + d;
   }
 }
 // LSTM-cell dropout (keras LSTMCell.call, implementation 1: one mask per gate on the inputs and on h; the wrapper calls
@@ -107,22 +130,52 @@ __global__ __launch_bounds__(256) void tr_gate_masks_bwd_kernel(const float* __r
   }
 }
 
+// the same for an input that is the concatenation [a | b] of two (B, H) rows (grid-TD language LSTM, x2 = [c_hat | h1]):
+// out[g][b][2H]; mask (T, 4, B, 2H).  Backward: da += first halves, db += second halves of sum_g part[g] * mask.
+__global__ __launch_bounds__(256) void tr_gate_masks2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ mask, float* __restrict__ out, int B, int H, int t,
+                                                             size_t gate_stride) {
+  const int W2 = 2 * H;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * W2; idx += gridDim.x * 256) {
+    const int bb = idx / W2, w = idx % W2;
+    const float v = w < H ? a[(size_t)bb * H + w] : b[(size_t)bb * H + w - H];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[g * gate_stride + idx] = v * mask[(((size_t)t * 4 + g) * B + bb) * W2 + w];
+  }
+}
+__global__ __launch_bounds__(256) void tr_gate_masks2_bwd_kernel(const float* __restrict__ part, const float* __restrict__ mask,
+                                                                 float* __restrict__ da, float* __restrict__ db, int B, int H, int t) {
+  const int W2 = 2 * H;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * W2; idx += gridDim.x * 256) {
+    const int bb = idx / W2, w = idx % W2;
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s += part[(size_t)g * B * W2 + idx] * mask[(((size_t)t * 4 + g) * B + bb) * W2 + w];
+    if (w < H) da[(size_t)bb * H + w] += s;
+    else db[(size_t)bb * H + w - H] += s;
+  }
+}
+
 // LSTM cell + sentinel of one step (keras LSTMCell.call, gate order i f c o; M:582-584).  Z row = [z_i z_f z_g z_o | u]
 // before the bias; G row = activated gates, C / Hs / TC (= tanh c) / SU (= sigmoid u) / S rows of this step.
 __global__ __launch_bounds__(256) void tr_cell_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ bias,
                                                           const float* __restrict__ Cprev, float* __restrict__ G, float* __restrict__ C,
                                                           float* __restrict__ Hs, float* __restrict__ TC, float* __restrict__ SU,
-                                                          float* __restrict__ S, int B, int H) {
+                                                          float* __restrict__ S, int B, int H, int ldz) {
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * H; idx += gridDim.x * 256) {
     const int b = idx / H, h = idx % H;
-    const float* z = Z + (size_t)b * 5 * H;
+    const float* z = Z + (size_t)b * ldz;
     const float i = tr_sigmoid(z[h] + bias[h]), f = tr_sigmoid(z[H + h] + bias[H + h]);
     const float g = tanhf(z[2 * H + h] + bias[2 * H + h]), o = tr_sigmoid(z[3 * H + h] + bias[3 * H + h]);
     const float c = f * (Cprev ? Cprev[idx] : 0.f) + i * g;
-    const float tc = tanhf(c), su = tr_sigmoid(z[4 * H + h]);
+    const float tc = tanhf(c);
     float* gg = G + (size_t)b * 4 * H;
     gg[h] = i; gg[H + h] = f; gg[2 * H + h] = g; gg[3 * H + h] = o;
-    C[idx] = c; Hs[idx] = o * tc; TC[idx] = tc; SU[idx] = su; S[idx] = tc * su;
+    C[idx] = c; Hs[idx] = o * tc; TC[idx] = tc;
+    if (S) {                                       // cells with a visual sentinel (ldz = 5H)
+      const float su = tr_sigmoid(z[4 * H + h]);
+      SU[idx] = su; S[idx] = tc * su;
+    }
   }
 }
 // Adaptive attention of one step (M:586-599), two launches:
@@ -181,7 +234,7 @@ __global__ __launch_bounds__(256) void tr_att_mix_kernel(const float* __restrict
     c = part[hl] + part[64 + hl] + part[128 + hl] + part[192 + hl];
     const size_t o = (size_t)b * H + h;
     CTX[o] = c;
-    float out = Hs[o] + beta * S[o] + (1.f - beta) * c;
+    float out = (Hs ? Hs[o] : 0.f) + beta * S[o] + (1.f - beta) * c;       // Hs null: c_hat alone (grid-TD)
     if (mask_out) out *= mask_out[((size_t)b * T + t) * H + h];
     OUTm[o] = out;
   }
@@ -189,9 +242,10 @@ __global__ __launch_bounds__(256) void tr_att_mix_kernel(const float* __restrict
 // Two-headed loss (M:95-103, :1364-1373) of one (t, b) row, in place: Z row (logits before the bias) -> d loss / d logits.
 // part[row] = (CE head 1, CE head 2, hit head 1, hit head 2, labelled) — hit = the label is the arg-max (M:105-124).
 // Rows of the last time step and rows without a label give zero.
+// ml: Dropout on the logits (grid-TD model, M:1303-1304), (B, T, V) or null.
 __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, const float* __restrict__ bout, const float* __restrict__ lw,
-                                                      const int* __restrict__ y_idx, float* __restrict__ part, int B, int T, int V,
-                                                      float scale) {
+                                                      const float* __restrict__ ml, const int* __restrict__ y_idx,
+                                                      float* __restrict__ part, int B, int T, int V, float scale) {
   __shared__ float red[4];
   const int row = blockIdx.x, t = row / B, b = row % B, tid = threadIdx.x;
   float* z = Z + (size_t)row * V;
@@ -202,21 +256,23 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, con
     return;
   }
   const float* w = lw + ((size_t)b * T + t) * V;
+  const float* mk = ml ? ml + ((size_t)b * T + t) * V : nullptr;
+  auto logit = [&](int k) { const float x = z[k] + bout[k]; return mk ? x * mk[k] : x; };
   float m1 = -INFINITY, m2 = -INFINITY;
   for (int k = tid; k < V; k += 256) {
-    const float x = z[k] + bout[k];
+    const float x = logit(k);
     m1 = fmaxf(m1, x); m2 = fmaxf(m2, x * w[k]);
   }
   m1 = tr_block_max(m1, red);
   m2 = tr_block_max(m2, red);
   float s1 = 0.f, s2 = 0.f;
   for (int k = tid; k < V; k += 256) {
-    const float x = z[k] + bout[k];
+    const float x = logit(k);
     s1 += expf(x - m1); s2 += expf(x * w[k] - m2);
   }
   s1 = tr_block_sum(s1, red);
   s2 = tr_block_sum(s2, red);
-  const float zy = z[y] + bout[y];
+  const float zy = logit(y);
   __syncthreads();
   if (tid == 0) {
     part[5 * row] = -(zy - m1 - logf(s1));
@@ -226,9 +282,10 @@ __global__ __launch_bounds__(256) void tr_loss_kernel(float* __restrict__ Z, con
     part[5 * row + 4] = 1.f;
   }
   for (int k = tid; k < V; k += 256) {
-    const float x = z[k] + bout[k];
+    const float x = logit(k);
     const float d = k == y ? 1.f : 0.f;
-    z[k] = scale * (0.5f * (expf(x - m1) / s1 - d) + 0.5f * w[k] * (expf(x * w[k] - m2) / s2 - d));
+    const float g = scale * (0.5f * (expf(x - m1) / s1 - d) + 0.5f * w[k] * (expf(x * w[k] - m2) / s2 - d));
+    z[k] = mk ? g * mk[k] : g;
   }
 }
 // losses[0..4] = (0.5 l1 + 0.5 l2, l1, l2, accuracy head 1, accuracy head 2) — what train_on_batch returns
@@ -255,7 +312,7 @@ __global__ __launch_bounds__(256) void tr_att_bwd_head_kernel(const float* __res
                                                               const float* __restrict__ BETA, const float* __restrict__ dOUTm,
                                                               const float* __restrict__ mask_out, const float* __restrict__ dH,
                                                               float* __restrict__ dHtot, float* __restrict__ dS, float* __restrict__ dCtx,
-                                                              float* __restrict__ dBeta, int H, int T, int t) {
+                                                              float* __restrict__ dBeta, int H, int T, int t, int add_to_h) {
   __shared__ float red[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const float beta = BETA[b];
@@ -264,7 +321,7 @@ __global__ __launch_bounds__(256) void tr_att_bwd_head_kernel(const float* __res
     const size_t o = (size_t)b * H + h;
     float d = dOUTm[o];
     if (mask_out) d *= mask_out[((size_t)b * T + t) * H + h];
-    dHtot[o] = (dH ? dH[o] : 0.f) + d;
+    dHtot[o] = (dH ? dH[o] : 0.f) + (add_to_h ? d : 0.f);     // adaptive: out = h + c_hat; grid-TD: d is d c_hat only
     dS[o] = beta * d;
     dCtx[o] = (1.f - beta) * d;
     dbeta += d * (S[o] - CTX[o]);
@@ -340,35 +397,36 @@ __global__ __launch_bounds__(256) void tr_att_bwd_main_kernel(const float* __res
 __global__ __launch_bounds__(256) void tr_cell_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Cprev,
                                                           const float* __restrict__ TC, const float* __restrict__ SU,
                                                           const float* __restrict__ dHtot, const float* __restrict__ dS,
-                                                          float* __restrict__ dC, float* __restrict__ DZ, int B, int H) {
+                                                          float* __restrict__ dC, float* __restrict__ DZ, int B, int H, int ldz) {
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * H; idx += gridDim.x * 256) {
     const int b = idx / H, h = idx % H;
     const float* gg = G + (size_t)b * 4 * H;
     const float i = gg[h], f = gg[H + h], g = gg[2 * H + h], o = gg[3 * H + h];
-    const float tc = TC[idx], su = SU[idx], ds = dS[idx], dh = dHtot[idx];
+    const float tc = TC[idx], su = dS ? SU[idx] : 0.f, ds = dS ? dS[idx] : 0.f, dh = dHtot[idx];
     const float dct = dC[idx] + (ds * su + dh * o) * (1.f - tc * tc);
-    float* dz = DZ + (size_t)b * 5 * H;
+    float* dz = DZ + (size_t)b * ldz;
     dz[h] = dct * g * i * (1.f - i);
     dz[H + h] = dct * (Cprev ? Cprev[idx] : 0.f) * f * (1.f - f);
     dz[2 * H + h] = dct * i * (1.f - g * g);
     dz[3 * H + h] = dh * tc * o * (1.f - o);
-    dz[4 * H + h] = ds * tc * su * (1.f - su);
+    if (dS) dz[4 * H + h] = ds * tc * su * (1.f - su);
     dC[idx] = dct * f;
   }
 }
 // dglob[b][e] = sum_t dX[t][b][E + e]
-__global__ __launch_bounds__(256) void tr_dglob_kernel(const float* __restrict__ dX, float* __restrict__ dglob, int B, int T, int E) {
+__global__ __launch_bounds__(256) void tr_dglob_kernel(const float* __restrict__ dX, float* __restrict__ dglob, int B, int T, int E,
+                                                       int glob_off) {
   for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * E; idx += gridDim.x * 256) {
     const int b = idx / E, e = idx % E;
     float s = 0.f;
-    for (int t = 0; t < T; ++t) s += dX[((size_t)t * B + b) * 2 * E + E + e];
+    for (int t = 0; t < T; ++t) s += dX[((size_t)t * B + b) * 2 * E + glob_off + e];
     dglob[idx] = s;
   }
 }
 // Embedding gradient: dEmb[row] = sum of the dX word halves of every (t, b) that read that row, in (t, b) order
 // (one workgroup per (t, b); the first reader of a row sums for all of them — no atomics, run-to-run identical).
 __global__ __launch_bounds__(256) void tr_embedding_bwd_kernel(const float* __restrict__ dX, const int* __restrict__ cap_in,
-                                                               float* __restrict__ dEmb, int B, int T, int E) {
+                                                               float* __restrict__ dEmb, int B, int T, int E, int emb_off) {
   const int me = blockIdx.x, n = B * T;
   const int row = cap_in[(me % B) * T + me / B];
   for (int j = 0; j < me; ++j)
@@ -376,7 +434,7 @@ __global__ __launch_bounds__(256) void tr_embedding_bwd_kernel(const float* __re
   for (int e = threadIdx.x; e < E; e += 256) {
     float s = 0.f;
     for (int j = me; j < n; ++j)
-      if (cap_in[(j % B) * T + j / B] == row) s += dX[(size_t)j * 2 * E + e];
+      if (cap_in[(j % B) * T + j / B] == row) s += dX[(size_t)j * 2 * E + emb_off + e];
     dEmb[(size_t)row * E + e] = s;
   }
 }

@@ -35,7 +35,7 @@ struct TrainParam {
 };
 
 struct Trainer {
-  bool ready = false;
+  bool ready = false, gridtd = false;
   int Bm = 0, Tm = 0, L = 0, D = 0, H = 0, E = 0, V = 0;
   std::vector<TrainParam> params;
   size_t n_total = 0;
@@ -48,6 +48,7 @@ struct Trainer {
   // forward state (time-major rows (t, b))
   DevBuf Vf, favg, glob, proj, Xall, Z, Gt, Cst, Hst, TC, SU, Sst, HW, SW, ALPHA, BETA, CTX, OUTm, logits, part, losses;
   // backward state
+  DevBuf Z2, G2, C2, H2, TC2, CHAT, DZ2, dH2, dC2, DCH, dH2tot;   // grid-TD: language LSTM rows, c_hat rows, carries
   DevBuf X4, H4, P4;                           // LSTM-cell dropout: per-gate masked inputs (4, T, B, 2E) / states (4, T, B, H), partials
   DevBuf Esc, dCtx, dBeta;                     // attention scores / d alpha of the current step, per-step scratch
   DevBuf dOUTm, dHtot, dS, dH, dC, DZ, DZS, DHW, dProj, dVf, dVacc, dX, dglob, dfavg, dF, ws, ident;
@@ -64,7 +65,7 @@ struct Trainer {
 
   int begin(Encoder& enc, Decoder& dec, const lrp_config& c, float lr_, float clip_, float b1_, float b2_, float eps_,
             int64_t* total) {
-    if (dec.kind != LRP_DEC_ADAPTIVE) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step is built for the adaptive-attention captioner");
+    gridtd = dec.kind == LRP_DEC_GRIDTD;
     if (ready) return fail(LRP_ERR_STATE, "lrp_train_begin was already called on this handle");
     if (c.E != c.H) return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step needs E == H");
     LRP_TRY(enc.check_ready());
@@ -87,8 +88,14 @@ struct Trainer {
     add("image_features_W", {D, H}); add("image_features_b", {H});
     add("global_W", {D, E}); add("global_b", {E});
     add("embedding", {V, E});
-    add("lstm_Wi", {2 * E, 4 * H}); add("lstm_Wh", {H, 4 * H}); add("lstm_b", {4 * H});
-    add("Wv", {H, H}); add("Wg", {H, H}); add("V", {H, 1}); add("Wx", {2 * E, H}); add("Wh", {H, H}); add("Ws", {H, H});
+    if (gridtd) {
+      add("td_Wi", {H + 2 * E, 4 * H}); add("td_Wh", {H, 4 * H}); add("td_b", {4 * H});
+      add("lang_Wi", {2 * H, 4 * H}); add("lang_Wh", {H, 4 * H}); add("lang_b", {4 * H});
+      add("W_va", {H, H}); add("W_ha", {H, H}); add("W_a", {H, 1}); add("W_x", {H + 2 * E, H}); add("W_h", {H, H}); add("W_s", {H, H});
+    } else {
+      add("lstm_Wi", {2 * E, 4 * H}); add("lstm_Wh", {H, 4 * H}); add("lstm_b", {4 * H});
+      add("Wv", {H, H}); add("Wg", {H, H}); add("V", {H, 1}); add("Wx", {2 * E, H}); add("Wh", {H, H}); add("Ws", {H, H});
+    }
     add("output_W", {H, V}); add("output_b", {V});
     host.assign(n_total, 0.f);
     size_t pi = 0;
@@ -124,6 +131,11 @@ struct Trainer {
     LRP_TRY(DZ.alloc(TB * 5 * H * 4, total)); LRP_TRY(dProj.alloc(B * L * H * 4, total)); LRP_TRY(dVf.alloc(B * L * H * 4, total));
     LRP_TRY(dX.alloc(TB * 2 * E * 4, total)); LRP_TRY(dglob.alloc(B * E * 4, total)); LRP_TRY(dfavg.alloc(B * D * 4, total));
     LRP_TRY(dF.alloc(B * L * D * 4, total));
+    if (gridtd) {                                     // second cell (language LSTM) + c_hat rows
+      LRP_TRY(Z2.alloc(TB * 4 * H * 4, total)); LRP_TRY(G2.alloc(TB * 4 * H * 4, total)); LRP_TRY(DZ2.alloc(TB * 4 * H * 4, total));
+      for (DevBuf* d : {&C2, &H2, &TC2, &CHAT}) LRP_TRY(d->alloc(TB * H * 4, total));
+      for (DevBuf* d : {&dH2, &dC2, &DCH, &dH2tot}) LRP_TRY(d->alloc(B * H * 4, total));
+    }
     ws_floats = (size_t)16 << 20;
     LRP_TRY(ws.alloc(ws_floats * 4, total));
     std::vector<int> id(Bm);
@@ -148,80 +160,60 @@ struct Trainer {
 
   // One step: gradients of 0.5 CE(y, logits) + 0.5 CE(y, logits * lrp_weight) for the B images last encoded.
   // cap_in (B, T) embedding rows, y_idx (B, T) class index or -1, lrp_weight (B, T, V); masks null = no dropout:
-  // m_if (B, L, H), m_glob (B, E), m_out (B, T, H).  grads_dev: n_total floats (caller's).  losses_dev: 5 floats.
-  // LSTM-cell dropout (keras `dropout` / `recurrent_dropout`): m_lin (T, 4, B, 2E), m_lrec (T, 4, B, H), gate order i f c o.
-  int step(Encoder& enc, const float* feat, int B, int T, const int* cap_in, const int* y_idx, const float* lrp_weight,
-           const float* m_if, const float* m_glob, const float* m_out, const float* m_lin, const float* m_lrec, float* grads,
-           float* losses_dev, int64_t* total, hipStream_t st) {
+  // m_if (B, L, H), m_glob (B, E), m_out (B, T, H), m_logits (B, T, V; the grid-TD model's Dropout on the logits, M:1303-1304).
+  // LSTM-cell dropout (keras `dropout` / `recurrent_dropout`; the language LSTM for grid-TD): m_lin (T, 4, B, 2E),
+  // m_lrec (T, 4, B, H), gate order i f c o.  grads_dev: n_total floats (caller's).  losses_dev: 5 floats.
+  struct StepIn {
+    const float* feat; int B, T; const int* cap_in; const int* y_idx; const float* lrp_weight;
+    const float *m_if, *m_glob, *m_out, *m_lin, *m_lrec, *m_logits;
+    float* grads; float* losses_dev; hipStream_t st;
+  };
+  const char* nm_proj() const { return gridtd ? "W_va" : "Wv"; }
+  const char* nm_hatt() const { return gridtd ? "W_ha" : "Wg"; }
+  const char* nm_satt() const { return gridtd ? "W_s" : "Ws"; }
+  const char* nm_vatt() const { return gridtd ? "W_a" : "V"; }
+
+  int step(Encoder& enc, const StepIn& in, int64_t* total) {
     if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
+    const int B = in.B, T = in.T;
+    hipStream_t st = in.st;
     if (B < 1 || B > Bm || T < 2 || T > Tm) return fail(LRP_ERR_INVALID, "B=%d / T=%d outside [1,%d] / [2,%d]", B, T, Bm, Tm);
     if (enc.encoded < B || enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run (after lrp_train_begin) on the batch first");
+    if (in.m_logits && !gridtd) return fail(LRP_ERR_INVALID, "the adaptive model has no Dropout on the logits");
     for (size_t li = 0; li + 1 < enc.layers.size(); ++li)
       if (!enc.layers[li].pool_after && !enc.layers[li].Akeep.p) return fail(LRP_ERR_STATE, "activations were not kept");
     const size_t TB = (size_t)T * B, BH = (size_t)B * H;
-    if ((m_lin || m_lrec) && !X4.p) {                 // allocated on first use
+    if ((in.m_lin || in.m_lrec) && !X4.p) {              // allocated on first use
       const size_t cap = (size_t)Bm * Tm;
       LRP_TRY(X4.alloc(4 * cap * 2 * E * 4, total)); LRP_TRY(H4.alloc(4 * cap * H * 4, total)); LRP_TRY(P4.alloc(4 * cap * 2 * E * 4, total));
     }
-    const size_t xs = TB * 2 * E, hs = TB * H;        // gate strides of X4 / H4 for this (T, B)
-    float *vf = Vf.as<float>(), *pj = proj.as<float>(), *x = Xall.as<float>(), *z = Z.as<float>();
+    const float* feat = in.feat;
+    float* grads = in.grads;
+    float *vf = Vf.as<float>(), *pj = proj.as<float>(), *x = Xall.as<float>();
     auto g = [&](const char* nm) { return grads + off(nm); };
-    // ---------------- forward
+    // ---------------- forward: the per-image statics (M:1343-1352, get_constants M:602-604)
     LRP_TRY(mm(false, false, B * L, H, D, feat, D, W("image_features_W"), H, vf, H, false, st));
-    hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, vf, W("image_features_b"), m_if,
+    hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, vf, W("image_features_b"), in.m_if,
                        (size_t)B * L, H);
     hipLaunchKernelGGL(tr_mean_rows_kernel, dim3(B), dim3(256), 0, st, feat, favg.as<float>(), L, D);
     LRP_TRY(mm(false, false, B, E, D, favg.as<float>(), D, W("global_W"), E, glob.as<float>(), E, false, st));
-    hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, glob.as<float>(), W("global_b"), m_glob,
+    hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, glob.as<float>(), W("global_b"), in.m_glob,
                        (size_t)B, E);
-    LRP_TRY(mm(false, false, B * L, H, H, vf, H, W("Wv"), H, pj, H, false, st));
-    hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), cap_in, x, B, T, E);
-    if (m_lin) {
-      hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(xs)), dim3(256), 0, st, x, m_lin, X4.as<float>(), (int)TB, B, 2 * E, 0, xs);
-      for (int gt = 0; gt < 4; ++gt)
-        LRP_TRY(mm(false, false, (int)TB, H, 2 * E, X4.as<float>() + gt * xs, 2 * E, W("lstm_Wi") + gt * H, 4 * H, z + gt * H, 5 * H, false, st));
-    } else {
-      LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("lstm_Wi"), 4 * H, z, 5 * H, false, st));
-    }
-    LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("Wx"), H, z + 4 * H, 5 * H, false, st));   // sentinel: un-dropped input (M:584)
-    const size_t att_fwd_lds = (size_t)(L + 8 + 256) * 4, att_bwd_lds = (size_t)(2 * L + 8 + 512) * 4;
-    for (int t = 0; t < T; ++t) {
-      float* zt = z + (size_t)t * B * 5 * H;
-      const float* hp = t > 0 ? Hst.as<float>() + (size_t)(t - 1) * BH : nullptr;
-      if (t > 0) {
-        if (m_lrec) {
-          float* h4 = H4.as<float>() + (size_t)t * BH;
-          hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(BH)), dim3(256), 0, st, hp, m_lrec, h4, B, B, H, t, hs);
-          for (int gt = 0; gt < 4; ++gt)
-            LRP_TRY(mm(false, false, B, H, H, h4 + gt * hs, H, W("lstm_Wh") + gt * H, 4 * H, zt + gt * H, 5 * H, true, st));
-        } else {
-          LRP_TRY(mm(false, false, B, 4 * H, H, hp, H, W("lstm_Wh"), 4 * H, zt, 5 * H, true, st));
-        }
-        LRP_TRY(mm(false, false, B, H, H, hp, H, W("Wh"), H, zt + 4 * H, 5 * H, true, st));
-      }
-      hipLaunchKernelGGL(tr_cell_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, zt, W("lstm_b"),
-                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, Gt.as<float>() + (size_t)t * B * 4 * H,
-                         Cst.as<float>() + t * BH, Hst.as<float>() + t * BH, TC.as<float>() + t * BH, SU.as<float>() + t * BH,
-                         Sst.as<float>() + t * BH, B, H);
-      LRP_TRY(mm(false, false, B, H, H, Hst.as<float>() + t * BH, H, W("Wg"), H, HW.as<float>() + t * BH, H, false, st));
-      LRP_TRY(mm(false, false, B, H, H, Sst.as<float>() + t * BH, H, W("Ws"), H, SW.as<float>() + t * BH, H, false, st));
-      hipLaunchKernelGGL(tr_att_scores_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, pj, HW.as<float>() + t * BH, W("V"),
-                         Esc.as<float>(), L, H);
-      hipLaunchKernelGGL(tr_att_mix_kernel, dim3(B, (H + 63) / 64), dim3(256), att_fwd_lds, st, Esc.as<float>(), vf,
-                         HW.as<float>() + t * BH, SW.as<float>() + t * BH, W("V"), Hst.as<float>() + t * BH, Sst.as<float>() + t * BH,
-                         m_out, ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, CTX.as<float>() + t * BH,
-                         OUTm.as<float>() + t * BH, L, H, T, t);
-    }
+    LRP_TRY(mm(false, false, B * L, H, H, vf, H, W(nm_proj()), H, pj, H, false, st));
+    // X rows: [emb | glob] (adaptive input_x) or [glob | emb] (the non-recurrent part of the top-down LSTM's input)
+    hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), in.cap_in, x, B, T, E,
+                       gridtd ? E : 0, gridtd ? 0 : E);
+    LRP_TRY(gridtd ? scan_fwd_gridtd(in) : scan_fwd_adaptive(in));
     LRP_HIP_CHECK(hipGetLastError());
+    // ---------------- output layer, two-headed loss, d logits in place
     float* lg = logits.as<float>();
     LRP_TRY(mm(false, false, (int)TB, V, H, OUTm.as<float>(), H, W("output_W"), V, lg, V, false, st));
     const float scale = 1.f / (float)((size_t)B * (T - 1));
-    hipLaunchKernelGGL(tr_loss_kernel, dim3((unsigned)TB), dim3(256), 0, st, lg, W("output_b"), lrp_weight, y_idx, part.as<float>(), B, T, V,
-                       scale);
+    hipLaunchKernelGGL(tr_loss_kernel, dim3((unsigned)TB), dim3(256), 0, st, lg, W("output_b"), in.lrp_weight, in.m_logits, in.y_idx,
+                       part.as<float>(), B, T, V, scale);
     hipLaunchKernelGGL(tr_loss_final_kernel, dim3(1), dim3(64), 0, st, part.as<float>(), (int)TB, scale, losses.as<float>());
     LRP_HIP_CHECK(hipGetLastError());
-    if (losses_dev) LRP_HIP_CHECK(hipMemcpyAsync(losses_dev, losses.p, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
-    // ---------------- backward: output layer
+    if (in.losses_dev) LRP_HIP_CHECK(hipMemcpyAsync(in.losses_dev, losses.p, 5 * sizeof(float), hipMemcpyDeviceToDevice, st));
     float* wsf = ws.as<float>();
     LRP_TRY(mm(true, false, H, V, (long)TB, OUTm.as<float>(), H, lg, V, g("output_W"), V, false, st));
     LRP_HIP_CHECK(colsum(lg, V, (long)TB, V, g("output_b"), 0, wsf, ws_floats, st));
@@ -230,76 +222,25 @@ struct Trainer {
     LRP_HIP_CHECK(hipMemsetAsync(dVf.p, 0, (size_t)B * L * H * 4, st));
     LRP_HIP_CHECK(hipMemsetAsync(dVacc.p, 0, BH * 4, st));
     LRP_HIP_CHECK(hipMemsetAsync(dC.p, 0, BH * 4, st));
-    float* dz = DZ.as<float>();
-    for (int t = T - 1; t >= 0; --t) {
-      hipLaunchKernelGGL(tr_att_bwd_head_kernel, dim3(B), dim3(256), 0, st, Sst.as<float>() + t * BH, CTX.as<float>() + t * BH,
-                         BETA.as<float>() + (size_t)t * B, dOUTm.as<float>() + t * BH, m_out,
-                         t == T - 1 ? (const float*)nullptr : dH.as<float>(), dHtot.as<float>(), dS.as<float>(), dCtx.as<float>(),
-                         dBeta.as<float>(), H, T, t);
-      hipLaunchKernelGGL(tr_att_bwd_dalpha_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, vf, dCtx.as<float>(), Esc.as<float>(), L, H);
-      hipLaunchKernelGGL(tr_att_bwd_main_kernel, dim3(B, (H + 63) / 64), dim3(256), att_bwd_lds, st, pj, HW.as<float>() + t * BH,
-                         SW.as<float>() + t * BH, W("V"), ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B,
-                         Esc.as<float>(), dBeta.as<float>(), dCtx.as<float>(), DZS.as<float>() + t * BH, DHW.as<float>() + t * BH,
-                         dProj.as<float>(), dVf.as<float>(), dVacc.as<float>(), L, H);
-      LRP_TRY(mm(false, true, B, H, H, DZS.as<float>() + t * BH, H, W("Ws"), H, dS.as<float>(), H, true, st));
-      LRP_TRY(mm(false, true, B, H, H, DHW.as<float>() + t * BH, H, W("Wg"), H, dHtot.as<float>(), H, true, st));
-      float* dzt = dz + (size_t)t * B * 5 * H;
-      hipLaunchKernelGGL(tr_cell_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, Gt.as<float>() + (size_t)t * B * 4 * H,
-                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, TC.as<float>() + t * BH,
-                         SU.as<float>() + t * BH, dHtot.as<float>(), dS.as<float>(), dC.as<float>(), dzt, B, H);
-      if (t > 0) {
-        if (m_lrec) {
-          float* p4 = P4.as<float>();
-          for (int gt = 0; gt < 4; ++gt)
-            LRP_TRY(mm(false, true, B, H, H, dzt + gt * H, 5 * H, W("lstm_Wh") + gt * H, 4 * H, p4 + gt * BH, H, false, st));
-          hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, p4, m_lrec, dH.as<float>(), B, B, H, t, BH);
-        } else {
-          LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("lstm_Wh"), 4 * H, dH.as<float>(), H, false, st));
-        }
-        LRP_TRY(mm(false, true, B, H, H, dzt + 4 * H, 5 * H, W("Wh"), H, dH.as<float>(), H, true, st));
-      }
-    }
+    // ---------------- reverse scan + the weight gradients of the recurrent part (K = (t, b) rows); leaves dX
+    LRP_TRY(gridtd ? scan_bwd_gridtd(in) : scan_bwd_adaptive(in));
     LRP_HIP_CHECK(hipGetLastError());
-    // ---------------- weight gradients of the recurrent part, K = (t, b) rows
+    // ---------------- attention statics, embedding, global / image_features branches
     float* dx = dX.as<float>();
-    if (m_lin) {
-      float* p4 = P4.as<float>();
-      for (int gt = 0; gt < 4; ++gt) {
-        LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + gt * H, 5 * H, W("lstm_Wi") + gt * H, 4 * H, p4 + gt * xs, 2 * E, false, st));
-        LRP_TRY(mm(true, false, 2 * E, H, (long)TB, X4.as<float>() + gt * xs, 2 * E, dz + gt * H, 5 * H, g("lstm_Wi") + gt * H, 4 * H, false, st));
-      }
-      hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(xs)), dim3(256), 0, st, p4, m_lin, dx, (int)TB, B, 2 * E, 0, xs);
-    } else {
-      LRP_TRY(mm(false, true, (int)TB, 2 * E, 4 * H, dz, 5 * H, W("lstm_Wi"), 4 * H, dx, 2 * E, false, st));
-      LRP_TRY(mm(true, false, 2 * E, 4 * H, (long)TB, x, 2 * E, dz, 5 * H, g("lstm_Wi"), 4 * H, false, st));
-    }
-    LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + 4 * H, 5 * H, W("Wx"), H, dx, 2 * E, true, st));
-    LRP_TRY(mm(true, false, 2 * E, H, (long)TB, x, 2 * E, dz + 4 * H, 5 * H, g("Wx"), H, false, st));
-    const long Kr = (long)(T - 1) * B;
-    if (m_lrec) {
-      for (int gt = 0; gt < 4; ++gt)                  // rows t = 1 .. T-1 of the masked states and of dz
-        LRP_TRY(mm(true, false, H, H, Kr, H4.as<float>() + gt * hs + BH, H, dz + (size_t)B * 5 * H + gt * H, 5 * H,
-                   g("lstm_Wh") + gt * H, 4 * H, false, st));
-    } else
-    LRP_TRY(mm(true, false, H, 4 * H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H, 5 * H, g("lstm_Wh"), 4 * H, false, st));
-    LRP_TRY(mm(true, false, H, H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H + 4 * H, 5 * H, g("Wh"), H, false, st));
-    LRP_HIP_CHECK(colsum(dz, 5 * H, (long)TB, 4 * H, g("lstm_b"), 0, wsf, ws_floats, st));
-    LRP_TRY(mm(true, false, H, H, (long)TB, Hst.as<float>(), H, DHW.as<float>(), H, g("Wg"), H, false, st));
-    LRP_TRY(mm(true, false, H, H, (long)TB, Sst.as<float>(), H, DZS.as<float>(), H, g("Ws"), H, false, st));
-    LRP_HIP_CHECK(colsum(dVacc.as<float>(), H, B, H, g("V"), 0, wsf, ws_floats, st));
-    LRP_TRY(mm(true, false, H, H, (long)B * L, vf, H, dProj.as<float>(), H, g("Wv"), H, false, st));
-    LRP_TRY(mm(false, true, B * L, H, H, dProj.as<float>(), H, W("Wv"), H, dVf.as<float>(), H, true, st));
+    LRP_TRY(mm(true, false, H, H, (long)TB, Hst.as<float>(), H, DHW.as<float>(), H, g(nm_hatt()), H, false, st));
+    LRP_TRY(mm(true, false, H, H, (long)TB, Sst.as<float>(), H, DZS.as<float>(), H, g(nm_satt()), H, false, st));
+    LRP_HIP_CHECK(colsum(dVacc.as<float>(), H, B, H, g(nm_vatt()), 0, wsf, ws_floats, st));
+    LRP_TRY(mm(true, false, H, H, (long)B * L, vf, H, dProj.as<float>(), H, g(nm_proj()), H, false, st));
+    LRP_TRY(mm(false, true, B * L, H, H, dProj.as<float>(), H, W(nm_proj()), H, dVf.as<float>(), H, true, st));
     LRP_HIP_CHECK(hipMemsetAsync(g("embedding"), 0, (size_t)V * E * 4, st));
-    hipLaunchKernelGGL(tr_embedding_bwd_kernel, dim3((unsigned)TB), dim3(256), 0, st, dx, cap_in, g("embedding"), B, T, E);
-    // global feature branch
-    hipLaunchKernelGGL(tr_dglob_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, dx, dglob.as<float>(), B, T, E);
-    hipLaunchKernelGGL(tr_relu_mask_bwd_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, dglob.as<float>(), glob.as<float>(), m_glob,
+    hipLaunchKernelGGL(tr_embedding_bwd_kernel, dim3((unsigned)TB), dim3(256), 0, st, dx, in.cap_in, g("embedding"), B, T, E, gridtd ? E : 0);
+    hipLaunchKernelGGL(tr_dglob_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, dx, dglob.as<float>(), B, T, E, gridtd ? 0 : E);
+    hipLaunchKernelGGL(tr_relu_mask_bwd_kernel, dim3(grid_for((size_t)B * E)), dim3(256), 0, st, dglob.as<float>(), glob.as<float>(), in.m_glob,
                        (size_t)B * E);
     LRP_TRY(mm(true, false, D, E, B, favg.as<float>(), D, dglob.as<float>(), E, g("global_W"), E, false, st));
     LRP_HIP_CHECK(colsum(dglob.as<float>(), E, B, E, g("global_b"), 0, wsf, ws_floats, st));
     LRP_TRY(mm(false, true, B, D, E, dglob.as<float>(), E, W("global_W"), E, dfavg.as<float>(), D, false, st));
-    // image_features branch
-    hipLaunchKernelGGL(tr_relu_mask_bwd_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, dVf.as<float>(), vf, m_if,
+    hipLaunchKernelGGL(tr_relu_mask_bwd_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, dVf.as<float>(), vf, in.m_if,
                        (size_t)B * L * H);
     LRP_TRY(mm(true, false, D, H, (long)B * L, feat, D, dVf.as<float>(), H, g("image_features_W"), H, false, st));
     LRP_HIP_CHECK(colsum(dVf.as<float>(), H, (long)B * L, H, g("image_features_b"), 0, wsf, ws_floats, st));
@@ -307,7 +248,7 @@ struct Trainer {
     hipLaunchKernelGGL(tr_mean_rows_bwd_kernel, dim3(grid_for((size_t)B * L * D)), dim3(256), 0, st, dF.as<float>(), dfavg.as<float>(), L, D,
                        (size_t)B * L * D);
     LRP_HIP_CHECK(hipGetLastError());
-    // ---------------- encoder: Gradient walk + one weight-gradient product per layer and tap
+    // ---------------- encoder: Gradient walk + one weight-gradient product per layer
     std::function<int(int, const float*)> hook = [&](int li, const float* dZ) -> int {
       const ConvLayer& Ly = enc.layers[li];
       const long K = (long)B * Ly.H * Ly.W;
@@ -330,6 +271,263 @@ struct Trainer {
     };
     LRP_TRY(enc.explain(B, ident.as<int>(), dF.as<float>(), nullptr, st, 1, &hook));
     stepped = true;
+    return LRP_OK;
+  }
+
+  // attention of step t for the rows hrow (h or h1) / srow (sentinel): HW, SW, scores, soft-max, beta, context
+  int attention_fwd(const StepIn& in, int t, const float* hs_for_out, const float* mask_out, float* out_rows) {
+    const int B = in.B, T = in.T;
+    const size_t BH = (size_t)B * H;
+    hipStream_t st = in.st;
+    LRP_TRY(mm(false, false, B, H, H, Hst.as<float>() + t * BH, H, W(nm_hatt()), H, HW.as<float>() + t * BH, H, false, st));
+    LRP_TRY(mm(false, false, B, H, H, Sst.as<float>() + t * BH, H, W(nm_satt()), H, SW.as<float>() + t * BH, H, false, st));
+    hipLaunchKernelGGL(tr_att_scores_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, proj.as<float>(), HW.as<float>() + t * BH, W(nm_vatt()),
+                       Esc.as<float>(), L, H);
+    hipLaunchKernelGGL(tr_att_mix_kernel, dim3(B, (H + 63) / 64), dim3(256), (size_t)(L + 8 + 256) * 4, st, Esc.as<float>(), Vf.as<float>(),
+                       HW.as<float>() + t * BH, SW.as<float>() + t * BH, W(nm_vatt()), hs_for_out, Sst.as<float>() + t * BH, mask_out,
+                       ALPHA.as<float>() + (size_t)t * B * L, BETA.as<float>() + (size_t)t * B, CTX.as<float>() + t * BH, out_rows, L, H, T, t);
+    return LRP_OK;
+  }
+  // its backward: d = gradient at c_hat (+ at h when add_to_h); dHin = what already flows into h; leaves dHtot, dS
+  int attention_bwd(const StepIn& in, int t, const float* d_rows, const float* mask_out, const float* dHin, int add_to_h) {
+    const int B = in.B, T = in.T;
+    const size_t BH = (size_t)B * H;
+    hipStream_t st = in.st;
+    hipLaunchKernelGGL(tr_att_bwd_head_kernel, dim3(B), dim3(256), 0, st, Sst.as<float>() + t * BH, CTX.as<float>() + t * BH,
+                       BETA.as<float>() + (size_t)t * B, d_rows, mask_out, dHin, dHtot.as<float>(), dS.as<float>(), dCtx.as<float>(),
+                       dBeta.as<float>(), H, T, t, add_to_h);
+    hipLaunchKernelGGL(tr_att_bwd_dalpha_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, Vf.as<float>(), dCtx.as<float>(), Esc.as<float>(), L, H);
+    hipLaunchKernelGGL(tr_att_bwd_main_kernel, dim3(B, (H + 63) / 64), dim3(256), (size_t)(2 * L + 8 + 512) * 4, st, proj.as<float>(),
+                       HW.as<float>() + t * BH, SW.as<float>() + t * BH, W(nm_vatt()), ALPHA.as<float>() + (size_t)t * B * L,
+                       BETA.as<float>() + (size_t)t * B, Esc.as<float>(), dBeta.as<float>(), dCtx.as<float>(), DZS.as<float>() + t * BH,
+                       DHW.as<float>() + t * BH, dProj.as<float>(), dVf.as<float>(), dVacc.as<float>(), L, H);
+    LRP_TRY(mm(false, true, B, H, H, DZS.as<float>() + t * BH, H, W(nm_satt()), H, dS.as<float>(), H, true, st));
+    LRP_TRY(mm(false, true, B, H, H, DHW.as<float>() + t * BH, H, W(nm_hatt()), H, dHtot.as<float>(), H, true, st));
+    return LRP_OK;
+  }
+
+  // ---- adaptive attention (ExternalAttentionRNNWrapperLocalAttentionV3.step, M:573-600)
+  int scan_fwd_adaptive(const StepIn& in) {
+    const int B = in.B, T = in.T;
+    const size_t TB = (size_t)T * B, BH = (size_t)B * H, xs = TB * 2 * E, hs = TB * H;
+    hipStream_t st = in.st;
+    float *x = Xall.as<float>(), *z = Z.as<float>();
+    if (in.m_lin) {
+      hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(xs)), dim3(256), 0, st, x, in.m_lin, X4.as<float>(), (int)TB, B, 2 * E, 0, xs);
+      for (int gt = 0; gt < 4; ++gt)
+        LRP_TRY(mm(false, false, (int)TB, H, 2 * E, X4.as<float>() + gt * xs, 2 * E, W("lstm_Wi") + gt * H, 4 * H, z + gt * H, 5 * H, false, st));
+    } else {
+      LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("lstm_Wi"), 4 * H, z, 5 * H, false, st));
+    }
+    LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("Wx"), H, z + 4 * H, 5 * H, false, st));   // sentinel: un-dropped input (M:584)
+    for (int t = 0; t < T; ++t) {
+      float* zt = z + (size_t)t * B * 5 * H;
+      const float* hp = t > 0 ? Hst.as<float>() + (size_t)(t - 1) * BH : nullptr;
+      if (t > 0) {
+        if (in.m_lrec) {
+          float* h4 = H4.as<float>() + (size_t)t * BH;
+          hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(BH)), dim3(256), 0, st, hp, in.m_lrec, h4, B, B, H, t, hs);
+          for (int gt = 0; gt < 4; ++gt)
+            LRP_TRY(mm(false, false, B, H, H, h4 + gt * hs, H, W("lstm_Wh") + gt * H, 4 * H, zt + gt * H, 5 * H, true, st));
+        } else {
+          LRP_TRY(mm(false, false, B, 4 * H, H, hp, H, W("lstm_Wh"), 4 * H, zt, 5 * H, true, st));
+        }
+        LRP_TRY(mm(false, false, B, H, H, hp, H, W("Wh"), H, zt + 4 * H, 5 * H, true, st));
+      }
+      hipLaunchKernelGGL(tr_cell_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, zt, W("lstm_b"),
+                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, Gt.as<float>() + (size_t)t * B * 4 * H,
+                         Cst.as<float>() + t * BH, Hst.as<float>() + t * BH, TC.as<float>() + t * BH, SU.as<float>() + t * BH,
+                         Sst.as<float>() + t * BH, B, H, 5 * H);
+      LRP_TRY(attention_fwd(in, t, Hst.as<float>() + t * BH, in.m_out, OUTm.as<float>() + t * BH));
+    }
+    return LRP_OK;
+  }
+  int scan_bwd_adaptive(const StepIn& in) {
+    const int B = in.B, T = in.T;
+    const size_t TB = (size_t)T * B, BH = (size_t)B * H, xs = TB * 2 * E, hs = TB * H;
+    hipStream_t st = in.st;
+    float *x = Xall.as<float>(), *dz = DZ.as<float>(), *dx = dX.as<float>(), *wsf = ws.as<float>();
+    float* grads = in.grads;
+    auto g = [&](const char* nm) { return grads + off(nm); };
+    for (int t = T - 1; t >= 0; --t) {
+      LRP_TRY(attention_bwd(in, t, dOUTm.as<float>() + t * BH, in.m_out, t == T - 1 ? (const float*)nullptr : dH.as<float>(), 1));
+      float* dzt = dz + (size_t)t * B * 5 * H;
+      hipLaunchKernelGGL(tr_cell_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, Gt.as<float>() + (size_t)t * B * 4 * H,
+                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, TC.as<float>() + t * BH,
+                         SU.as<float>() + t * BH, dHtot.as<float>(), dS.as<float>(), dC.as<float>(), dzt, B, H, 5 * H);
+      if (t > 0) {
+        if (in.m_lrec) {
+          float* p4 = P4.as<float>();
+          for (int gt = 0; gt < 4; ++gt)
+            LRP_TRY(mm(false, true, B, H, H, dzt + gt * H, 5 * H, W("lstm_Wh") + gt * H, 4 * H, p4 + gt * BH, H, false, st));
+          hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, p4, in.m_lrec, dH.as<float>(), B, B, H, t, BH);
+        } else {
+          LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("lstm_Wh"), 4 * H, dH.as<float>(), H, false, st));
+        }
+        LRP_TRY(mm(false, true, B, H, H, dzt + 4 * H, 5 * H, W("Wh"), H, dH.as<float>(), H, true, st));
+      }
+    }
+    if (in.m_lin) {
+      float* p4 = P4.as<float>();
+      for (int gt = 0; gt < 4; ++gt) {
+        LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + gt * H, 5 * H, W("lstm_Wi") + gt * H, 4 * H, p4 + gt * xs, 2 * E, false, st));
+        LRP_TRY(mm(true, false, 2 * E, H, (long)TB, X4.as<float>() + gt * xs, 2 * E, dz + gt * H, 5 * H, g("lstm_Wi") + gt * H, 4 * H, false, st));
+      }
+      hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(xs)), dim3(256), 0, st, p4, in.m_lin, dx, (int)TB, B, 2 * E, 0, xs);
+    } else {
+      LRP_TRY(mm(false, true, (int)TB, 2 * E, 4 * H, dz, 5 * H, W("lstm_Wi"), 4 * H, dx, 2 * E, false, st));
+      LRP_TRY(mm(true, false, 2 * E, 4 * H, (long)TB, x, 2 * E, dz, 5 * H, g("lstm_Wi"), 4 * H, false, st));
+    }
+    LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + 4 * H, 5 * H, W("Wx"), H, dx, 2 * E, true, st));
+    LRP_TRY(mm(true, false, 2 * E, H, (long)TB, x, 2 * E, dz + 4 * H, 5 * H, g("Wx"), H, false, st));
+    const long Kr = (long)(T - 1) * B;
+    if (in.m_lrec) {
+      for (int gt = 0; gt < 4; ++gt)                  // rows t = 1 .. T-1 of the masked states and of dz
+        LRP_TRY(mm(true, false, H, H, Kr, H4.as<float>() + gt * hs + BH, H, dz + (size_t)B * 5 * H + gt * H, 5 * H,
+                   g("lstm_Wh") + gt * H, 4 * H, false, st));
+    } else {
+      LRP_TRY(mm(true, false, H, 4 * H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H, 5 * H, g("lstm_Wh"), 4 * H, false, st));
+    }
+    LRP_TRY(mm(true, false, H, H, Kr, Hst.as<float>(), H, dz + (size_t)B * 5 * H + 4 * H, 5 * H, g("Wh"), H, false, st));
+    LRP_HIP_CHECK(colsum(dz, 5 * H, (long)TB, 4 * H, g("lstm_b"), 0, wsf, ws_floats, st));
+    return LRP_OK;
+  }
+
+  // ---- grid-TD (ExternalBottomUpAttentionAdaptive.step, M:784-818): top-down cell on [h2_prev | glob | emb] with the
+  // sentinel, attention on h1, language cell (keras LSTMCell, with its dropout) on [c_hat | h1], out = h2 + c_hat.
+  // Row stores: Hst / Cst / Gt / TC / SU / Sst / Z / DZ = top-down cell (h1 ...), H2 / C2 / G2 / TC2 / Z2 / DZ2 = language cell.
+  int scan_fwd_gridtd(const StepIn& in) {
+    const int B = in.B, T = in.T, K1 = H + 2 * E;
+    const size_t TB = (size_t)T * B, BH = (size_t)B * H, xs = TB * 2 * H, hs = TB * H;
+    hipStream_t st = in.st;
+    float *x = Xall.as<float>(), *z = Z.as<float>(), *z2 = Z2.as<float>();
+    (void)K1;
+    // [glob | emb] part of every step's input at once: rows H.. of td_Wi / W_x
+    LRP_TRY(mm(false, false, (int)TB, 4 * H, 2 * E, x, 2 * E, W("td_Wi") + (size_t)H * 4 * H, 4 * H, z, 5 * H, false, st));
+    LRP_TRY(mm(false, false, (int)TB, H, 2 * E, x, 2 * E, W("W_x") + (size_t)H * H, H, z + 4 * H, 5 * H, false, st));
+    for (int t = 0; t < T; ++t) {
+      float* zt = z + (size_t)t * B * 5 * H;
+      float* z2t = z2 + (size_t)t * B * 4 * H;
+      const float* h1p = t > 0 ? Hst.as<float>() + (size_t)(t - 1) * BH : nullptr;
+      const float* h2p = t > 0 ? H2.as<float>() + (size_t)(t - 1) * BH : nullptr;
+      if (t > 0) {
+        LRP_TRY(mm(false, false, B, 4 * H, H, h2p, H, W("td_Wi"), 4 * H, zt, 5 * H, true, st));
+        LRP_TRY(mm(false, false, B, H, H, h2p, H, W("W_x"), H, zt + 4 * H, 5 * H, true, st));
+        LRP_TRY(mm(false, false, B, 4 * H, H, h1p, H, W("td_Wh"), 4 * H, zt, 5 * H, true, st));
+        LRP_TRY(mm(false, false, B, H, H, h1p, H, W("W_h"), H, zt + 4 * H, 5 * H, true, st));
+      }
+      hipLaunchKernelGGL(tr_cell_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, zt, W("td_b"),
+                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, Gt.as<float>() + (size_t)t * B * 4 * H,
+                         Cst.as<float>() + t * BH, Hst.as<float>() + t * BH, TC.as<float>() + t * BH, SU.as<float>() + t * BH,
+                         Sst.as<float>() + t * BH, B, H, 5 * H);
+      float* chat = CHAT.as<float>() + t * BH;
+      LRP_TRY(attention_fwd(in, t, nullptr, nullptr, chat));                        // c_hat alone, no mask
+      // language LSTM on x2 = [c_hat | h1]
+      const float* h1 = Hst.as<float>() + t * BH;
+      if (in.m_lin) {
+        // masked copies of both halves of x2: X4 rows [g][t][b][2H]; products per gate
+        float* x4 = X4.as<float>() + (size_t)t * B * 2 * H;
+        hipLaunchKernelGGL(tr_gate_masks2_kernel, dim3(grid_for((size_t)B * 2 * H)), dim3(256), 0, st, chat, h1, in.m_lin, x4, B, H, t, xs);
+        for (int gt = 0; gt < 4; ++gt)
+          LRP_TRY(mm(false, false, B, H, 2 * H, x4 + gt * xs, 2 * H, W("lang_Wi") + gt * H, 4 * H, z2t + gt * H, 4 * H, false, st));
+      } else {
+        LRP_TRY(mm(false, false, B, 4 * H, H, chat, H, W("lang_Wi"), 4 * H, z2t, 4 * H, false, st));
+        LRP_TRY(mm(false, false, B, 4 * H, H, h1, H, W("lang_Wi") + (size_t)H * 4 * H, 4 * H, z2t, 4 * H, true, st));
+      }
+      if (t > 0) {
+        if (in.m_lrec) {
+          float* h4 = H4.as<float>() + (size_t)t * BH;
+          hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(BH)), dim3(256), 0, st, h2p, in.m_lrec, h4, B, B, H, t, hs);
+          for (int gt = 0; gt < 4; ++gt)
+            LRP_TRY(mm(false, false, B, H, H, h4 + gt * hs, H, W("lang_Wh") + gt * H, 4 * H, z2t + gt * H, 4 * H, true, st));
+        } else {
+          LRP_TRY(mm(false, false, B, 4 * H, H, h2p, H, W("lang_Wh"), 4 * H, z2t, 4 * H, true, st));
+        }
+      }
+      hipLaunchKernelGGL(tr_cell_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, z2t, W("lang_b"),
+                         t > 0 ? C2.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, G2.as<float>() + (size_t)t * B * 4 * H,
+                         C2.as<float>() + t * BH, H2.as<float>() + t * BH, TC2.as<float>() + t * BH, (float*)nullptr, (float*)nullptr, B, H,
+                         4 * H);
+      hipLaunchKernelGGL(tr_out_fwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, H2.as<float>() + t * BH, chat, in.m_out,
+                         OUTm.as<float>() + t * BH, B, H, T, t);
+    }
+    return LRP_OK;
+  }
+  int scan_bwd_gridtd(const StepIn& in) {
+    const int B = in.B, T = in.T;
+    const size_t TB = (size_t)T * B, BH = (size_t)B * H, xs = TB * 2 * H, hs = TB * H;
+    hipStream_t st = in.st;
+    float *x = Xall.as<float>(), *dz = DZ.as<float>(), *dz2 = DZ2.as<float>(), *dx = dX.as<float>(), *wsf = ws.as<float>();
+    float* grads = in.grads;
+    auto g = [&](const char* nm) { return grads + off(nm); };
+    LRP_HIP_CHECK(hipMemsetAsync(dC2.p, 0, BH * 4, st));
+    LRP_HIP_CHECK(hipMemsetAsync(dH.p, 0, BH * 4, st));          // dH = carry into h1, dH2 = carry into h2
+    for (int t = T - 1; t >= 0; --t) {
+      float* dzt = dz + (size_t)t * B * 5 * H;
+      float* dz2t = dz2 + (size_t)t * B * 4 * H;
+      hipLaunchKernelGGL(tr_out_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, dOUTm.as<float>() + t * BH, in.m_out,
+                         t == T - 1 ? (const float*)nullptr : dH2.as<float>(), DCH.as<float>(), dH2tot.as<float>(), B, H, T, t);
+      hipLaunchKernelGGL(tr_cell_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, G2.as<float>() + (size_t)t * B * 4 * H,
+                         t > 0 ? C2.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, TC2.as<float>() + t * BH,
+                         (const float*)nullptr, dH2tot.as<float>(), (const float*)nullptr, dC2.as<float>(), dz2t, B, H, 4 * H);
+      // back through x2 = [c_hat | h1] (and the cell's input masks): d c_hat += ..., d h1 (carry dH) += ...
+      if (in.m_lin) {
+        float* p4 = P4.as<float>();
+        for (int gt = 0; gt < 4; ++gt)
+          LRP_TRY(mm(false, true, B, 2 * H, H, dz2t + gt * H, 4 * H, W("lang_Wi") + gt * H, 4 * H, p4 + gt * (size_t)B * 2 * H, 2 * H, false, st));
+        hipLaunchKernelGGL(tr_gate_masks2_bwd_kernel, dim3(grid_for((size_t)B * 2 * H)), dim3(256), 0, st, p4, in.m_lin, DCH.as<float>(),
+                           dH.as<float>(), B, H, t);
+      } else {
+        LRP_TRY(mm(false, true, B, H, 4 * H, dz2t, 4 * H, W("lang_Wi"), 4 * H, DCH.as<float>(), H, true, st));
+        LRP_TRY(mm(false, true, B, H, 4 * H, dz2t, 4 * H, W("lang_Wi") + (size_t)H * 4 * H, 4 * H, dH.as<float>(), H, true, st));
+      }
+      if (t > 0) {                                    // carry into h2_{t-1} through the recurrent kernel
+        if (in.m_lrec) {
+          float* p4 = P4.as<float>();
+          for (int gt = 0; gt < 4; ++gt)
+            LRP_TRY(mm(false, true, B, H, H, dz2t + gt * H, 4 * H, W("lang_Wh") + gt * H, 4 * H, p4 + gt * BH, H, false, st));
+          hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, p4, in.m_lrec, dH2.as<float>(), B, B, H, t, BH);
+        } else {
+          LRP_TRY(mm(false, true, B, H, 4 * H, dz2t, 4 * H, W("lang_Wh"), 4 * H, dH2.as<float>(), H, false, st));
+        }
+      }
+      LRP_TRY(attention_bwd(in, t, DCH.as<float>(), nullptr, dH.as<float>(), 0));
+      hipLaunchKernelGGL(tr_cell_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, Gt.as<float>() + (size_t)t * B * 4 * H,
+                         t > 0 ? Cst.as<float>() + (size_t)(t - 1) * BH : (const float*)nullptr, TC.as<float>() + t * BH,
+                         SU.as<float>() + t * BH, dHtot.as<float>(), dS.as<float>(), dC.as<float>(), dzt, B, H, 5 * H);
+      if (t > 0) {
+        LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("td_Wh"), 4 * H, dH.as<float>(), H, false, st));
+        LRP_TRY(mm(false, true, B, H, H, dzt + 4 * H, 5 * H, W("W_h"), H, dH.as<float>(), H, true, st));
+        LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("td_Wi"), 4 * H, dH2.as<float>(), H, true, st));      // rows [0, H) of td_Wi: h2_prev
+        LRP_TRY(mm(false, true, B, H, H, dzt + 4 * H, 5 * H, W("W_x"), H, dH2.as<float>(), H, true, st));
+      }
+    }
+    // [glob | emb] part of the top-down input: dX rows; weight gradients, K = (t, b) rows
+    LRP_TRY(mm(false, true, (int)TB, 2 * E, 4 * H, dz, 5 * H, W("td_Wi") + (size_t)H * 4 * H, 4 * H, dx, 2 * E, false, st));
+    LRP_TRY(mm(false, true, (int)TB, 2 * E, H, dz + 4 * H, 5 * H, W("W_x") + (size_t)H * H, H, dx, 2 * E, true, st));
+    LRP_TRY(mm(true, false, 2 * E, 4 * H, (long)TB, x, 2 * E, dz, 5 * H, g("td_Wi") + (size_t)H * 4 * H, 4 * H, false, st));
+    LRP_TRY(mm(true, false, 2 * E, H, (long)TB, x, 2 * E, dz + 4 * H, 5 * H, g("W_x") + (size_t)H * H, H, false, st));
+    const long Kr = (long)(T - 1) * B;
+    const float *dz1 = dz + (size_t)B * 5 * H, *dz21 = dz2 + (size_t)B * 4 * H;       // rows t = 1 .. T-1
+    LRP_TRY(mm(true, false, H, 4 * H, Kr, H2.as<float>(), H, dz1, 5 * H, g("td_Wi"), 4 * H, false, st));
+    LRP_TRY(mm(true, false, H, H, Kr, H2.as<float>(), H, dz1 + 4 * H, 5 * H, g("W_x"), H, false, st));
+    LRP_TRY(mm(true, false, H, 4 * H, Kr, Hst.as<float>(), H, dz1, 5 * H, g("td_Wh"), 4 * H, false, st));
+    LRP_TRY(mm(true, false, H, H, Kr, Hst.as<float>(), H, dz1 + 4 * H, 5 * H, g("W_h"), H, false, st));
+    LRP_HIP_CHECK(colsum(dz, 5 * H, (long)TB, 4 * H, g("td_b"), 0, wsf, ws_floats, st));
+    if (in.m_lin) {
+      for (int gt = 0; gt < 4; ++gt)
+        LRP_TRY(mm(true, false, 2 * H, H, (long)TB, X4.as<float>() + gt * xs, 2 * H, dz2 + gt * H, 4 * H, g("lang_Wi") + gt * H, 4 * H, false, st));
+    } else {
+      LRP_TRY(mm(true, false, H, 4 * H, (long)TB, CHAT.as<float>(), H, dz2, 4 * H, g("lang_Wi"), 4 * H, false, st));
+      LRP_TRY(mm(true, false, H, 4 * H, (long)TB, Hst.as<float>(), H, dz2, 4 * H, g("lang_Wi") + (size_t)H * 4 * H, 4 * H, false, st));
+    }
+    if (in.m_lrec) {
+      for (int gt = 0; gt < 4; ++gt)
+        LRP_TRY(mm(true, false, H, H, Kr, H4.as<float>() + gt * hs + BH, H, dz21 + gt * H, 4 * H, g("lang_Wh") + gt * H, 4 * H, false, st));
+    } else {
+      LRP_TRY(mm(true, false, H, 4 * H, Kr, H2.as<float>(), H, dz21, 4 * H, g("lang_Wh"), 4 * H, false, st));
+    }
+    LRP_HIP_CHECK(colsum(dz2, 4 * H, (long)TB, 4 * H, g("lang_b"), 0, wsf, ws_floats, st));
     return LRP_OK;
   }
 

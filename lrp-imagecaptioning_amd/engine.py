@@ -237,16 +237,18 @@ class LRPEngine(object):
                 raise ValueError("mask '%s' must be %s" % (key, shape))
             return v
         mi, mg, mo = m("image_features", (B, self.L, self.H)), m("global", (B, self.E)), m("output", (B, T, self.H))
-        ml, mr = m("lstm_in", (T, 4, B, 2 * self.E)), m("lstm_rec", (T, 4, B, self.H))
+        win = 2 * self.H if self.decoder == "gridtd" else 2 * self.E         # language LSTM input [c_hat | h1] / [emb | glob]
+        ml, mr = m("lstm_in", (T, 4, B, win)), m("lstm_rec", (T, 4, B, self.H))
+        mz = m("logits", (B, T, self.V))
         for k in masks:
-            if k not in ("image_features", "global", "output", "lstm_in", "lstm_rec"):
+            if k not in ("image_features", "global", "output", "lstm_in", "lstm_rec", "logits"):
                 raise ValueError("unknown dropout mask '%s'" % k)
         if grads is None:
             grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
         losses = torch.empty(5, dtype=torch.float32, device=self.device)
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(ml), p(mr), p(grads),
-                                             p(losses), self._stream()))
+        _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(ml), p(mr), p(mz),
+                                             p(grads), p(losses), self._stream()))
         return grads, losses
 
     def train_apply(self, grads):
@@ -255,12 +257,15 @@ class LRPEngine(object):
         self.n_images = 0
         self.captions = None
 
-    def train_weights(self):
-        """Master weights as {name: float32 ndarray} (checkpointing / tests)."""
+    def train_weights_device(self):
+        """Master weights as {name: flat float32 device view} of one fresh copy of the flat buffer."""
         flat = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
         _capi.check(self._lib.lrp_train_get_master(self._h, C.c_void_p(flat.data_ptr()), self._stream()))
-        f = flat.cpu().numpy()
-        return {k: f[o:o + n].copy() for k, (o, n) in self.train_layout.items()}
+        return {k: flat[o:o + n] for k, (o, n) in self.train_layout.items()}
+
+    def train_weights(self):
+        """Master weights as {name: float32 ndarray} (checkpointing / tests)."""
+        return {k: v.cpu().numpy().copy() for k, v in self.train_weights_device().items()}
 
     # ------------------------------------------------------------------ caption generation (SURVEY 8f-4)
     def gen_begin(self, n_rows):

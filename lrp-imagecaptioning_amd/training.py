@@ -12,12 +12,15 @@ its shard of the batch; the flat gradient is averaged with ONE all-reduce (RCCL 
 import numpy as np
 import torch
 
-from .lrp_inference import LRPInferenceLayerAdaptive
+from .lrp_inference import LRPInferenceLayerAdaptive, LRPInferenceLayergridTD
 from .parallel import average_gradients
 
 
 class TrainingLRPInferenceAdaptive(object):
-    def __init__(self, explainer, learning_rate=2e-4, clipvalue=0.01, drop_rate=0.5, lrp_inference_mode="mean", stop_words=(),
+    _LAYER = LRPInferenceLayerAdaptive
+    _CLIPVALUE = 0.01                                  # models/model.py:1370
+
+    def __init__(self, explainer, learning_rate=2e-4, clipvalue=None, drop_rate=0.5, lrp_inference_mode="mean", stop_words=(),
                  seed=0, process_group=None):
         """explainer: an `ExplainImgCaptioningAdaptiveAttention` (its engine holds the weights).  Optimiser as compiled at
         models/model.py:1370 (`Adam(lr, clipvalue=0.01)`), dropout rate `config.drop_rate` (config.py:16) on the
@@ -25,7 +28,8 @@ class TrainingLRPInferenceAdaptive(object):
         cell (`dropout` / `recurrent_dropout`, M:1356-1358)."""
         self._explainer = explainer
         self._engine = explainer._engine
-        self._lrp_layer = LRPInferenceLayerAdaptive(explainer, lrp_inference_mode, stop_words)
+        self._lrp_layer = self._LAYER(explainer, lrp_inference_mode, stop_words)
+        clipvalue = self._CLIPVALUE if clipvalue is None else clipvalue
         self._drop_rate = float(drop_rate)
         self._gen = torch.Generator(device=self._engine.device)
         self._gen.manual_seed(int(seed))
@@ -45,7 +49,10 @@ class TrainingLRPInferenceAdaptive(object):
         if not np.all(cap_in[:, 0] + 1 == int(eng.cfg.sos_id)):
             raise ValueError("captions_input must start with the start-of-sentence token")
         eng.decoder_forward(caps)
-        return eng.read_state("caption_preds")[:B, :T].to(torch.float32)
+        return self._logits(B, T)
+
+    def _logits(self, B, T):
+        return self._engine.read_state("caption_preds")[:B, :T].to(torch.float32)
 
     def _masks(self, B, T):
         p = self._drop_rate
@@ -53,8 +60,11 @@ class TrainingLRPInferenceAdaptive(object):
             return None
         eng = self._engine
         mk = lambda *s: (torch.rand(*s, device=eng.device, generator=self._gen) >= p).to(torch.float32) / (1.0 - p)
-        return {"image_features": mk(B, eng.L, eng.H), "global": mk(B, eng.E), "output": mk(B, T, eng.H),
-                "lstm_in": mk(T, 4, B, 2 * eng.E), "lstm_rec": mk(T, 4, B, eng.H)}
+        masks = {"image_features": mk(B, eng.L, eng.H), "global": mk(B, eng.E), "output": mk(B, T, eng.H),
+                 "lstm_in": mk(T, 4, B, 2 * eng.E), "lstm_rec": mk(T, 4, B, eng.H)}
+        if eng.decoder == "gridtd":
+            masks["logits"] = mk(B, T, eng.V)          # Dropout on the logits (M:1303-1304)
+        return masks
 
     def train_on_batch(self, X, y, lrp_weight=None):
         """One iteration of the `while True` body (train.py:571-580).  X = [captions_input (B, T), images (B, H, W, 3)],
@@ -82,3 +92,23 @@ class TrainingLRPInferenceAdaptive(object):
 
     def get_weights(self):
         return self._engine.train_weights()
+
+
+class TrainingLRPInferenceGridTD(TrainingLRPInferenceAdaptive):
+    """train.py:596-669 on ImgCaptioningGridTDLRPInferenceModel (models/model.py:1254-1311): the same loop body over the
+    grid-TD captioner — `Adam(lr, clipvalue=0.1)` (M:1307), a Dropout on the logits as well (M:1303-1304), dropout
+    inside the language LSTM.  `predict_on_batch` returns the Keras model's logits, (h2 + c_hat) W + b (M:816), not the
+    explainer's h2-only replay (models/explainers.py:1154)."""
+    _LAYER = LRPInferenceLayergridTD
+    _CLIPVALUE = 0.1
+
+    def _logits(self, B, T):
+        from .engine import op_sgemm
+        eng = self._engine
+        w = eng.train_weights_device()
+        Wout = w["output_W"].view(eng.H, eng.V)
+        h2 = eng.read_state("h2t")[:B, 1:T + 1].to(torch.float32).reshape(B * T, eng.H).contiguous()
+        ch = eng.read_state("context_hat")[:B, 1:T + 1].to(torch.float32).reshape(B * T, eng.H).contiguous()
+        out = op_sgemm(h2, Wout, split=False)
+        out = op_sgemm(ch, Wout, C_init=out, split=False)
+        return (out + w["output_b"]).view(B, T, eng.V)

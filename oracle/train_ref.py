@@ -36,15 +36,18 @@ import torch.nn.functional as F
 
 DT = torch.float64
 
+GRIDTD_PARAMS = ("image_features_W", "image_features_b", "global_W", "global_b", "embedding", "td_Wi", "td_Wh", "td_b",
+                 "lang_Wi", "lang_Wh", "lang_b", "W_va", "W_ha", "W_a", "W_x", "W_h", "W_s", "output_W", "output_b")
+
 DECODER_PARAMS = ("image_features_W", "image_features_b", "global_W", "global_b", "embedding", "lstm_Wi", "lstm_Wh",
                   "lstm_b", "Wv", "Wg", "V", "Wx", "Wh", "Ws", "output_W", "output_b")
 
 
-def param_names(cnn_cfg):
+def param_names(cnn_cfg, kind="adaptive"):
     names = []
     for name, _, _, _ in cnn_cfg:
         names += [name + "_W", name + "_b"]
-    return names + list(DECODER_PARAMS)
+    return names + list(DECODER_PARAMS if kind == "adaptive" else GRIDTD_PARAMS)
 
 
 def _t(a):
@@ -106,6 +109,60 @@ def decoder_logits(w, feat, cap_in, masks=None):
     return out @ w["output_W"] + w["output_b"]
 
 
+def decoder_logits_gridtd(w, feat, cap_in, masks=None):
+    """Grid-TD (bottom-up / top-down) captioner in training mode: ImgCaptioningGridTDLRPInferenceModel.build (M:1275-1311)
+    + ExternalBottomUpAttentionAdaptive.step (M:784-818) with its hand-written top-down cell (M:668-682).  Unlike the
+    adaptive model there is a Dropout on the logits as well (M:1303-1304): mask 'logits' (B, T, V).  The language LSTM is a
+    keras cell called inside the loop (M:812): per-step, per-gate masks 'lstm_in' (T, 4, B, 2H) / 'lstm_rec' (T, 4, B, H)."""
+    masks = masks or {}
+    B, T = cap_in.shape
+    H = w["td_Wh"].shape[0]
+    m = lambda k: masks.get(k)
+    Vf = F.relu(feat @ w["image_features_W"] + w["image_features_b"])
+    if m("image_features") is not None:
+        Vf = Vf * m("image_features")
+    glob = F.relu(feat.mean(dim=1) @ w["global_W"] + w["global_b"])
+    if m("global") is not None:
+        glob = glob * m("global")
+    emb = w["embedding"][cap_in]
+    proj = Vf @ w["W_va"]
+    z = lambda: torch.zeros(B, H, dtype=DT)
+    h1, c1, h2, c2 = z(), z(), z(), z()
+    outs = []
+    for t in range(T):
+        x1 = torch.cat([h2, glob, emb[:, t]], dim=1)                                   # M:792
+        zz = x1 @ w["td_Wi"] + h1 @ w["td_Wh"] + w["td_b"]                             # M:668-682
+        i_, f_, g_, o_ = torch.sigmoid(zz[:, :H]), torch.sigmoid(zz[:, H:2 * H]), torch.tanh(zz[:, 2 * H:3 * H]), torch.sigmoid(zz[:, 3 * H:])
+        c1n = f_ * c1 + i_ * g_
+        h1n = o_ * torch.tanh(c1n)
+        s = torch.tanh(c1n) * torch.sigmoid(x1 @ w["W_x"] + h1 @ w["W_h"])             # M:797 (h1 = previous state)
+        hw = h1n @ w["W_ha"]
+        z_s = torch.tanh(s @ w["W_s"] + hw) @ w["W_a"]                                 # M:799
+        e = (torch.tanh(proj + hw[:, None, :]) @ w["W_a"])[..., 0]                     # M:800-801
+        alpha = torch.softmax(e, dim=1)
+        beta = torch.softmax(torch.cat([e, z_s], dim=1), dim=1)[:, -1:]                # M:804-806
+        ctx = (alpha[..., None] * Vf).sum(dim=1)
+        c_hat = beta * s + (1 - beta) * ctx                                            # M:808
+        x2 = torch.cat([c_hat, h1n], dim=1)                                            # M:810
+        zs = []
+        for g in range(4):
+            xi = x2 if m("lstm_in") is None else x2 * m("lstm_in")[t, g]
+            hi = h2 if m("lstm_rec") is None else h2 * m("lstm_rec")[t, g]
+            zs.append(xi @ w["lang_Wi"][:, g * H:(g + 1) * H] + hi @ w["lang_Wh"][:, g * H:(g + 1) * H] + w["lang_b"][g * H:(g + 1) * H])
+        i2, f2, g2, o2 = torch.sigmoid(zs[0]), torch.sigmoid(zs[1]), torch.tanh(zs[2]), torch.sigmoid(zs[3])
+        c2n = f2 * c2 + i2 * g2
+        h2n = o2 * torch.tanh(c2n)
+        outs.append(h2n + c_hat)                                                       # M:816
+        h1, c1, h2, c2 = h1n, c1n, h2n, c2n
+    out = torch.stack(outs, dim=1)
+    if m("output") is not None:
+        out = out * m("output")
+    logits = out @ w["output_W"] + w["output_b"]
+    if m("logits") is not None:
+        logits = logits * m("logits")
+    return logits
+
+
 def two_head_loss(logits, lrp_weight, y_idx):
     """M:95-103 with loss_weights [0.5, 0.5] (M:1370-1373).  y_idx (B, T) class index, -1 = all-zero label row."""
     B, T, V = logits.shape
@@ -118,12 +175,13 @@ def two_head_loss(logits, lrp_weight, y_idx):
     return 0.5 * l1 + 0.5 * l2, l1, l2
 
 
-def loss_and_grads(weights, cnn_cfg, images, cap_in, y_idx, lrp_weight, masks=None):
+def loss_and_grads(weights, cnn_cfg, images, cap_in, y_idx, lrp_weight, masks=None, kind="adaptive"):
     """-> (total, l1, l2, {name: grad ndarray}) for every parameter of the training model."""
-    w = {k: _t(v).requires_grad_(True) for k, v in weights.items() if k in set(param_names(cnn_cfg))}
+    w = {k: _t(v).requires_grad_(True) for k, v in weights.items() if k in set(param_names(cnn_cfg, kind))}
     mk = {k: _t(v) for k, v in (masks or {}).items() if v is not None}
     feat = cnn_features(w, cnn_cfg, _t(images))
-    logits = decoder_logits(w, feat, torch.as_tensor(np.asarray(cap_in)).long(), mk)
+    fwd = decoder_logits if kind == "adaptive" else decoder_logits_gridtd
+    logits = fwd(w, feat, torch.as_tensor(np.asarray(cap_in)).long(), mk)
     total, l1, l2 = two_head_loss(logits, _t(lrp_weight), torch.as_tensor(np.asarray(y_idx)).long())
     total.backward()
     grads = {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape))) for k, v in w.items()}

@@ -231,3 +231,77 @@ def test_conv_wgrad_matches_torch(NB, HW, Cin, Cout):
     want = w.grad.permute(2, 3, 1, 0)                                   # OIHW -> HWIO
     assert rel_l1(dw.cpu().numpy(), want.numpy()) < 1e-5
     assert rel_l1(db.cpu().numpy(), b.grad.numpy()) < 1e-5
+
+
+def _gridtd_case(seed=21, B=3, Tn=5):
+    from lrp_imagecaptioning_amd.synthetic import gridtd_weights
+    rs = np.random.RandomState(seed)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    X = (rs.uniform(0, 255, size=(B, HW, HW, 3)) - 110).astype(np.float32) / 64
+    cap_in = np.concatenate([np.full((B, 1), 1), rs.randint(2, V, size=(B, Tn - 1))], axis=1).astype(np.int32)
+    y = rs.randint(0, V, size=(B, Tn)).astype(np.int32)
+    y[1, -2:] = -1
+    lw = (1 + rs.uniform(0, 1, size=(B, Tn, V)) * (rs.uniform(size=(B, Tn, V)) < 0.2)).astype(np.float32)
+    mk = lambda *s: ((rs.uniform(size=s) >= 0.5) * 2.0).astype(np.float32)
+    masks = {"image_features": mk(B, L, H), "global": mk(B, H), "output": mk(B, Tn, H), "lstm_in": mk(Tn, 4, B, 2 * H),
+             "lstm_rec": mk(Tn, 4, B, H), "logits": mk(B, Tn, V)}
+    return w, X, cap_in, y, lw, masks
+
+
+@pytest.mark.parametrize("with_masks", [False, True])
+def test_gridtd_gradients_match_oracle(with_masks):
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    from oracle import train_ref as T
+    w, X, cap_in, y, lw, masks = _gridtd_case()
+    if not with_masks:
+        masks = None
+    eng = LRPEngine(decoder="gridtd", cnn_cfg=CFG, img_hw=(HW, HW), L=L, D=D, H=H, E=H, V=V, max_images=4, max_tokens=8,
+                    max_caption_len=6)
+    eng.set_weights(w)
+    layout = eng.train_begin(lr=1e-3, clipvalue=0.1)
+    assert set(layout) == set(T.param_names(CFG, "gridtd"))
+    eng.encode_images(X)
+    grads, losses = eng.train_step(cap_in, y, lw, masks)
+    total, l1, l2, g, _ = T.loss_and_grads(w, CFG, X, cap_in, y, lw, masks, kind="gridtd")
+    np.testing.assert_allclose(losses.cpu().numpy()[:3], [total, l1, l2], rtol=2e-5)
+    gf = grads.cpu().numpy()
+    bad = {}
+    for name, (off, n) in layout.items():
+        e = rel_l1(gf[off:off + n], g[name])
+        if not e < 2e-4:
+            bad[name] = e
+    assert not bad, bad
+
+
+def test_gridtd_training_loop_and_operand_rebuild():
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningGridTDModel
+    from lrp_imagecaptioning_amd.training import TrainingLRPInferenceGridTD
+    from oracle import cnn_lrp_ref as Cn
+    from oracle import train_ref as T
+    from oracle.decoder_ref import GridTDOracle
+    w, X, cap_in, y, lw, _ = _gridtd_case(23, B=4)
+    X = X * 64
+    spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V, cnn_cfg=CFG,
+                            img_hw=(HW, HW))
+    ex = ExplainImgCaptioningGridTDModel(spec, None, None, max_caption_length=5, max_images=4)
+    tr = TrainingLRPInferenceGridTD(ex, learning_rate=2e-3, drop_rate=0.0)
+    y_pred = tr.predict_on_batch([cap_in, X]).cpu().numpy()
+    _, _, _, _, logits = T.loss_and_grads(w, CFG, X, cap_in, y, np.ones_like(lw), kind="gridtd")
+    assert rel_l1(y_pred, logits) < 1e-5                                   # the Keras model's logits (h2 + c_hat)
+    losses = [tr.train_on_batch([cap_in, X], y)[0] for _ in range(10)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    # after ten updates (operands rebuilt in place nine times) the explanation follows the master weights
+    new = tr.get_weights()
+    wn = {k: new[k].reshape(np.shape(w[k])) for k in w}
+    eng = ex._engine
+    eng.encode_images(X[:1])
+    feat = Cn.forward(Cn.vgg_layers(wn, CFG), X[:1]).astype(np.float32)
+    cap = [5, 9, 17, 1]
+    eng.decoder_forward([cap])
+    o = GridTDOracle(wn, L, D, H, H)
+    o.forward(feat, cap)
+    Rf, _, _ = eng.decoder_explain([0, 0], [1, 3])
+    for k, t in enumerate((1, 3)):
+        Ro, _ = o.explain(t)
+        assert rel_l1(Rf[k].cpu().numpy(), Ro.reshape(L, D)) < 1e-4

@@ -71,3 +71,23 @@ def test_adam_clipvalue_step():
     lr_t = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9)
     np.testing.assert_allclose(p1, p - lr_t * m1 / (np.sqrt(v1) + 1e-7))
     assert np.all(np.sign(p - p1)[g != 0] == np.sign(g)[g != 0]) and p1[4] == p[4]
+
+
+def test_gridtd_hidden_states_match_decoder_oracle():
+    """The grid-TD training graph against oracle/decoder_ref.GridTDOracle (pinned by reference outputs).  The explainer's
+    replay takes its logits from h2 alone (E:1154) while the Keras model uses h2 + c_hat (M:816): compare h2 + c_hat."""
+    from lrp_imagecaptioning_amd.synthetic import gridtd_weights
+    from oracle.decoder_ref import GridTDOracle
+    rs = np.random.RandomState(2)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    X = rs.uniform(-2, 2, size=(1, HW, HW, 3)).astype(np.float32)
+    cap = [5, 9, 14, 1]
+    cap_in = np.array([[1] + [c - 1 for c in cap[:-1]]])
+    y = np.array([[c - 1 for c in cap]])
+    _, _, _, g, logits = T.loss_and_grads(w, CFG, X, cap_in, y, np.ones((1, 4, V)), kind="gridtd")
+    o = GridTDOracle(w, L, D, H, H)
+    o.forward(C.forward(C.vgg_layers(w, CFG), X).astype(np.float32), cap)
+    want = (o.h2t[1:] + o.context_hat[1:]) @ w["output_W"] + w["output_b"]
+    np.testing.assert_allclose(logits[0], want, rtol=2e-4, atol=2e-5)
+    assert set(g) == set(T.param_names(CFG, "gridtd")) and all(np.isfinite(v).all() for v in g.values())
