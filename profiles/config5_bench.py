@@ -14,16 +14,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     import torch
-    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention
-    from lrp_imagecaptioning_amd.synthetic import adaptive_weights, images, vgg_weights
-    from lrp_imagecaptioning_amd.training import TrainingLRPInferenceAdaptive
+    from lrp_imagecaptioning_amd.explainers import (CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention,
+                                                    ExplainImgCaptioningGridTDModel)
+    from lrp_imagecaptioning_amd.synthetic import adaptive_weights, gridtd_weights, images, vgg_weights
+    from lrp_imagecaptioning_amd.training import TrainingLRPInferenceAdaptive, TrainingLRPInferenceGridTD
     B, T, V = int(os.environ.get("B", 8)), int(os.environ.get("T", 21)), 10000
+    kind = os.environ.get("DEC", "adaptive")            # DEC=gridtd: the grid-TD twin (train.py:596-669)
     rs = np.random.RandomState(0)
     w = vgg_weights(rs)
-    w.update(adaptive_weights(rs, 196, 512, 512, 512, V))
+    w.update((adaptive_weights if kind == "adaptive" else gridtd_weights)(rs, 196, 512, 512, 512, V))
     spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512, vocab_size=V)
-    ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=T - 1, max_images=B)
-    tr = TrainingLRPInferenceAdaptive(ex, learning_rate=2e-4, clipvalue=0.01, drop_rate=0.5)
+    if kind == "adaptive":
+        ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=T - 1, max_images=B)
+        tr = TrainingLRPInferenceAdaptive(ex, learning_rate=2e-4, drop_rate=0.5)
+    else:
+        ex = ExplainImgCaptioningGridTDModel(spec, None, None, max_caption_length=T - 1, max_images=B)
+        tr = TrainingLRPInferenceGridTD(ex, learning_rate=2e-4, drop_rate=0.5)
     eng = ex._engine
     X = torch.as_tensor(images(rs, B)).cuda()
     cap_in = np.concatenate([np.full((B, 1), 1), rs.randint(2, V, size=(B, T - 1))], axis=1).astype(np.int32)
@@ -40,9 +46,9 @@ def main():
     t_apply, _ = timed(lambda: eng.train_apply(g))
     n = 3
     t_all, _ = timed(lambda: [tr.train_on_batch([cap_in, X], y) for _ in range(n)])
-    print("config5 (fine-tune step, VGG16 + adaptive, B=%d, T=%d, %d heat-maps): %.1f ms/iteration; predict %.1f, lrp_weight %.1f, "
+    print("config5 (fine-tune step, VGG16 + %s, B=%d, T=%d, %d heat-maps): %.1f ms/iteration; predict %.1f, lrp_weight %.1f, "
           "gradients %.1f, Adam + operand rebuild %.1f ms; losses %s; workspace %.1f GB" % (
-              B, T, n_maps, t_all / n, t_pred, t_lrp, t_step, t_apply, [round(float(v), 4) for v in losses.cpu()],
+              kind, B, T, n_maps, t_all / n, t_pred, t_lrp, t_step, t_apply, [round(float(v), 4) for v in losses.cpu()],
               eng.workspace_bytes / 1e9))
     assert torch.isfinite(g).all()
     if os.environ.get("CPU", "0") != "0":
@@ -53,7 +59,7 @@ def main():
         torch.set_grad_enabled(True)
         t0 = time.perf_counter()
         T.loss_and_grads(w, VGG16_CFG, X[:1].cpu().numpy(), cap_in[:1], y[:1], lw_dev[:1].cpu().numpy(),
-                         {k: (v[:1] if k in ("image_features", "global", "output") else v[:, :, :1]).cpu().numpy() for k, v in masks.items()})
+                         {k: (v[:, :, :1] if k in ("lstm_in", "lstm_rec") else v[:1]).cpu().numpy() for k, v in masks.items()}, kind=kind)
         dt = time.perf_counter() - t0
         print("cpu port of the gradient step: %.1f s per image on %d threads (x%d images per batch; GPU: %.1f ms for %d)"
               % (dt, torch.get_num_threads(), B, t_step, B))
