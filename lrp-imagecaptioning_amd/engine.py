@@ -228,6 +228,13 @@ class LRPEngine(object):
         lw = self._dev(lrp_weight).reshape(B, T, self.V)
         if tuple(yi.shape) != (B, T):
             raise ValueError("y_idx must have the shape of cap_in")
+        # the kernels index the embedding / the logits with these: validate on the host side of the boundary
+        if int(ci.min()) < 0 or int(ci.max()) >= self.V:
+            raise ValueError("cap_in holds embedding rows outside [0, V)")
+        if int(yi.min()) < -1 or int(yi.max()) >= self.V:
+            raise ValueError("y_idx holds class indices outside [-1, V)")
+        if B > self.n_images:
+            raise RuntimeError("encode_images must run on the batch before train_step")
         def m(key, shape):
             v = masks.get(key)
             if v is None:

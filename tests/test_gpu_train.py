@@ -119,6 +119,12 @@ def test_adam_step_matches_oracle_and_engine_follows():
         eng.set_weights({"Wv": w["Wv"]})                 # the trainer owns the weights now
     with pytest.raises(ValueError):
         eng.train_step(cap_in[:, :1], y[:, :1], lw[:, :1])           # T < 2
+    bad = cap_in.copy(); bad[0, 0] = V
+    with pytest.raises(ValueError):
+        eng.train_step(bad, y, lw)                                   # embedding row out of range
+    bad = y.copy(); bad[0, 0] = V
+    with pytest.raises(ValueError):
+        eng.train_step(cap_in, bad, lw)                              # label out of range
 
 
 def test_training_loop_class():
