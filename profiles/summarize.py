@@ -16,6 +16,8 @@ def agg(path, key_len=120):
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"][:key_len]
         out[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in n[k]:
+            out[k]["_duration_ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         n[k].add(r["Dispatch_Id"])
     return out, {k: len(v) for k, v in n.items()}
 
@@ -36,6 +38,9 @@ def main(tag):
         if gui:
             # GRBM_GUI_ACTIVE sums the 8 XCDs; 1024 SIMDs each able to hold one MFMA-cycle per cycle
             d["mfma_busy_frac"] = round(v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024), 4)
+            if v.get("_duration_ns"):
+                # shader clock the kernel actually ran at: busy cycles of one XCD / wall time of its dispatches
+                d["shader_clock_ghz"] = round(gui / 8 / v["_duration_ns"], 3)
         wc = v.get("SQ_WAVE_CYCLES", 0.0)
         if wc:
             d["wait_any_frac"] = round(v.get("SQ_WAIT_ANY", 0.0) / wc, 4)
