@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
     }
     __syncthreads();
   }
-  float* C = a.ksplit > 1 ? a.ws + (size_t)blockIdx.z * a.M * a.N : a.C + (size_t)tap * a.tapC;
-  const long ldc = a.ksplit > 1 ? a.N : a.ldc;
-  const bool accum = a.ksplit > 1 ? false : a.accumulate != 0;
+  const bool partial = a.ksplit > 1 || a.taps > 1;     // through the workspace; sgemm_reduce_kernel finishes
+  float* C = partial ? a.ws + (size_t)blockIdx.z * a.M * a.N : a.C;
+  const long ldc = partial ? a.N : a.ldc;
+  const bool accum = partial ? false : a.accumulate != 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -223,10 +224,10 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
     if ((size_t)ks * per > ws_floats) ks = (int)(ws_floats / per);
     if (ks < 1) ks = 1;
   }
-  if (taps > 1 && ks < 2) ks = 2;                                 // (the tap-folded launch always goes through the partials)
   long chunk = ((steps + ks - 1) / ks) * SG_BK;
   ks = (int)((a.K + chunk - 1) / chunk);
-  if (taps > 1 && (ks < 2 || !ws || (size_t)ks * a.M * a.N * taps > ws_floats)) return hipErrorInvalidValue;
+  // (the tap-folded launch always goes through the partials, also with a single K slice)
+  if (taps > 1 && (!ws || (size_t)ks * a.M * a.N * taps > ws_floats)) return hipErrorInvalidValue;
   a.ksplit = ks; a.kchunk = chunk; a.ws = ws;
   dim3 grid(gx, gy, ks * taps);
   if (a.transA && !a.transB) sgemm_launch_tile<true, false>(tm, tn, grid, st, a);
@@ -235,7 +236,7 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   else return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (ks > 1) {
+  if (ks > 1 || taps > 1) {
     const size_t mn = (size_t)a.M * a.N * taps;
     const unsigned blocks = (unsigned)((mn + 255) / 256 < 4096 ? (mn + 255) / 256 : 4096);
     hipLaunchKernelGGL(sgemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, a.C, a.M, a.N, a.ldc, ks, a.accumulate, taps,

@@ -311,3 +311,23 @@ def test_gridtd_training_loop_and_operand_rebuild():
     for k, t in enumerate((1, 3)):
         Ro, _ = o.explain(t)
         assert rel_l1(Rf[k].cpu().numpy(), Ro.reshape(L, D)) < 1e-4
+
+
+def test_train_step_edge_cases():
+    """Smallest shapes and degenerate labels: B = 1 / T = 2; no labelled row at all (zero loss, zero gradient);
+    lrp_weight == 1 everywhere (both heads see the same logits)."""
+    from oracle import train_ref as T
+    w, X, cap_in, y, lw, _ = _case(5, B=3, Tn=5)
+    eng = _engine(w, 3)
+    layout = eng.train_begin()
+    eng.encode_images(X[:1])
+    g1, l1 = eng.train_step(cap_in[:1, :2], y[:1, :2], lw[:1, :2])
+    tot, a, b, g, _ = T.loss_and_grads(w, CFG, X[:1], cap_in[:1, :2], y[:1, :2], lw[:1, :2])
+    np.testing.assert_allclose(l1.cpu().numpy()[:3], [tot, a, b], rtol=2e-5)
+    gf = g1.cpu().numpy()
+    assert all(rel_l1(gf[o:o + n], g[k]) < 2e-4 for k, (o, n) in layout.items() if np.abs(g[k]).sum() > 0)
+    eng.encode_images(X)
+    g0, l0 = eng.train_step(cap_in, np.full_like(y, -1), lw)
+    assert float(l0[0]) == 0.0 and float(g0.abs().max()) == 0.0
+    _, l2 = eng.train_step(cap_in, y, np.ones_like(lw))
+    assert float(l2[1]) == float(l2[2]) and float(l2[3]) == float(l2[4])
