@@ -624,7 +624,7 @@ struct Decoder {
     }
     if (tailA.p && (D & 7) == 0) {
       // tail on the matrix cores, as for the adaptive decoder
-      const bool split = prec == PREC_BF16X3;
+      const bool split = prec == PREC_BF16X3 && tail_split();
       hipLaunchKernelGGL(gtd_tail_a_kernel, dim3((L * (H / 8) + 255) / 256, n), dim3(256), 0, st, img_dev, t_dev,
                          if_pre.as<float>(), a.att, a.rho, tailA.as<float>(), Tm, L, H, split ? 1 : 0);
       LRP_HIP_CHECK(hipGetLastError());
@@ -786,6 +786,13 @@ struct Decoder {
         g[(size_t)d * H + j] = d < Kx ? Wi[(size_t)d * 4 * H + 2 * H + j] : Wh[(size_t)(d - Kx) * 4 * H + 2 * H + j];
     return g;
   }
+  // tail GEMM of the decoder LRP (R at the image_features layer back to the CNN features): exact fp32 MFMA by default —
+  // its split-bf16 form saves 0.2 ms of a 40 ms step and costs the decoder half 5x of its parity margin
+  // (R_feat 3-10e-6 instead of 0.4-1.2e-6 vs the float64 oracle).  LRP_DEC_TAIL_SPLIT=1 re-enables it.
+  static bool tail_split() {
+    static const bool v = [] { const char* e = getenv("LRP_DEC_TAIL_SPLIT"); return e && atoi(e) != 0; }();
+    return v;
+  }
   static bool batched_scan() {            // LRP_DEC_BATCHED=0: one workgroup per unit (dec_explain_adaptive_kernel)
     const char* e = getenv("LRP_DEC_BATCHED");
     return !e || atoi(e) != 0;
@@ -861,7 +868,7 @@ struct Decoder {
     }
     if (tailA.p && (D & 7) == 0) {
       // tail on the matrix cores: A operand -> 1-tap conv_igemm with the F-multiply as its gate -> mean-pool share
-      const bool split = prec == PREC_BF16X3;
+      const bool split = prec == PREC_BF16X3 && tail_split();
       TailAArgs aa{};
       aa.img_idx = img_dev; aa.tpos = t_dev; aa.vfeat = vfeat.as<float>(); aa.ipre = ipre.as<double>(); aa.att = a.att;
       aa.rho = a.rctx; aa.A = tailA.as<float>(); aa.Tm = Tm; aa.L = L; aa.H = H; aa.split = split;
