@@ -136,7 +136,9 @@ struct Trainer {
       for (DevBuf* d : {&C2, &H2, &TC2, &CHAT}) LRP_TRY(d->alloc(TB * H * 4, total));
       for (DevBuf* d : {&dH2, &dC2, &DCH, &dH2tot}) LRP_TRY(d->alloc(B * H * 4, total));
     }
-    ws_floats = (size_t)16 << 20;
+    ws_floats = (size_t)16 << 20;                     // K-split partials; at least two slices of the widest layer's nine taps
+    for (const ConvLayer& Ly : enc.layers) ws_floats = std::max(ws_floats, (size_t)2 * 9 * Ly.cin * Ly.cout);
+    ws_floats = std::max(ws_floats, (size_t)2 * H * V);
     LRP_TRY(ws.alloc(ws_floats * 4, total));
     std::vector<int> id(Bm);
     for (int i = 0; i < Bm; ++i) id[i] = i;
