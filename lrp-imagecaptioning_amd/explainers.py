@@ -45,11 +45,15 @@ class CaptionModelSpec(object):
     """What the reference reads off `model` (E:26-39): encoder kind, dims, and the weights."""
 
     def __init__(self, weights, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512,
-                 vocab_size=None, cnn_cfg=VGG16_CFG, img_hw=(224, 224), resnet=None):
-        """img_encoder 'vgg16' (config.py:36-40: block5_conv3, 196 x 512) or 'resnet101' (config.py:41-45:
-        conv5_block3_out, 49 x 2048; `resnet` = dict(stem, stacks), default ResNet-101)."""
-        if img_encoder not in ("vgg16", "resnet101"):
-            raise NotImplementedError("the img_encode is not valid, [vgg16, resnet101]")     # explain_image.py:25-26
+                 vocab_size=None, cnn_cfg=None, img_hw=(224, 224), resnet=None):
+        """img_encoder 'vgg16' (config.py:36-40: block5_conv3, 196 x 512), 'vgg19' (config.py:37: block5_conv4) or
+        'resnet101' (config.py:41-45: conv5_block3_out, 49 x 2048; `resnet` = dict(stem, stacks), default ResNet-101).
+        cnn_cfg: the conv list of a VGG-style encoder (default: the full-size one of `img_encoder`)."""
+        if img_encoder not in ("vgg16", "vgg19", "resnet101"):
+            raise NotImplementedError("the img_encode is not valid, [vgg16, vgg19, resnet101]")     # explain_image.py:25-26
+        if cnn_cfg is None:
+            from .synthetic import VGG19_CFG
+            cnn_cfg = VGG19_CFG if img_encoder == "vgg19" else VGG16_CFG
         if img_encoder == "resnet101" and resnet is None:
             from .synthetic import RESNET101_STACKS
             resnet = {"stem": 64, "stacks": RESNET101_STACKS}

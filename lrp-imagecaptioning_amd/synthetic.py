@@ -93,6 +93,18 @@ VGG16_CFG = [  # (name, C_in, C_out, pool_after)   keras.applications.vgg16 up t
 ]
 
 
+VGG19_CFG = [  # keras.applications.vgg19 up to block5_conv4 (config.py:37: the layer_name of the 'vgg19' encoder)
+    ("block1_conv1", 3, 64, False), ("block1_conv2", 64, 64, True),
+    ("block2_conv1", 64, 128, False), ("block2_conv2", 128, 128, True),
+    ("block3_conv1", 128, 256, False), ("block3_conv2", 256, 256, False), ("block3_conv3", 256, 256, False),
+    ("block3_conv4", 256, 256, True),
+    ("block4_conv1", 256, 512, False), ("block4_conv2", 512, 512, False), ("block4_conv3", 512, 512, False),
+    ("block4_conv4", 512, 512, True),
+    ("block5_conv1", 512, 512, False), ("block5_conv2", 512, 512, False), ("block5_conv3", 512, 512, False),
+    ("block5_conv4", 512, 512, False),
+]
+
+
 def vgg_weights(rs, cfg=VGG16_CFG, bias_std=0.05):
     """He-normal HWIO kernels (3,3,Cin,Cout) and mixed-sign biases (exercise the
     b+/b- split of relevance_rule.py:256-260).  ImageNet weights cannot be fetched."""

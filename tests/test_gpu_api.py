@@ -312,3 +312,34 @@ def test_generation_api_errors():
     assert np.abs(a[0] - a[1]).max() > 1e-6
     np.testing.assert_allclose(a[0], b[1], rtol=1e-12)
     np.testing.assert_allclose(a[1], b[0], rtol=1e-12)
+
+
+def test_vgg19_topology():
+    """'vgg19' (config.py:36-37, explain_image.py:17-20): the 16-conv topology up to block5_conv4, here at reduced
+    width, through the explainer protocol against the oracle."""
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention
+    from lrp_imagecaptioning_amd.harness import Explainer
+    from lrp_imagecaptioning_amd.synthetic import VGG19_CFG
+    cfg = [(n, 3 if i == 0 else max(8, ci // 16), max(8, co // 16), p) for i, (n, ci, co, p) in enumerate(VGG19_CFG)]
+    hw, Lv, Dv = 32, 4, cfg[-1][2]
+    rs = np.random.RandomState(9)
+    w = vgg_weights(rs, cfg, bias_std=0.2)
+    w.update(adaptive_weights(rs, Lv, Dv, H, H, V))
+    spec = CaptionModelSpec(w, img_encoder="vgg19", hidden_dim=H, embedding_dim=H, L=Lv, D=Dv, vocab_size=V, cnn_cfg=cfg,
+                            img_hw=(hw, hw))
+    assert len(CaptionModelSpec(w, img_encoder="vgg19", L=196, D=512).cnn_cfg) == 16
+    ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=6)
+    assert Explainer(spec, None, ex, 6, beam_size=2)._color_conversion == "BGRtoRGB"
+    X = rs.uniform(-120, 130, size=(1, hw, hw, 3)).astype(np.float32)
+    cap = [7, 12, 33, 1]
+    ex._forward_beam_search((None, X), cap)
+    layers = C.vgg_layers(w, cfg)
+    o = AdaptiveOracle(w, Lv, Dv, H, H)
+    o.forward(C.forward(layers, X).astype(np.float32), cap)
+    worst = 0.0
+    for t in (1, 3):
+        R, _ = ex._explain_lstm_single_word_sequence(t)
+        Rref, _ = o.explain(t)
+        worst = max(worst, rel_l1(ex._explain_CNN(X, R), C.analyze(layers, X, Rref)))
+    report("api_vgg19", max_rel_l1=worst)
+    assert worst < TOL, worst
