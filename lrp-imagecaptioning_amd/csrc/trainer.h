@@ -50,6 +50,7 @@ struct Trainer {
   // backward state
   DevBuf Z2, G2, C2, H2, TC2, CHAT, DZ2, dH2, dC2, DCH, dH2tot;   // grid-TD: language LSTM rows, c_hat rows, carries
   DevBuf X4, H4, P4;                           // LSTM-cell dropout: per-gate masked inputs (4, T, B, 2E) / states (4, T, B, H), partials
+  DevBuf Gimg;                                 // A1^T dZ of the image layer (64 x cout) before the x+ / x- halves are folded
   DevBuf Esc, dCtx, dBeta;                     // attention scores / d alpha of the current step, per-step scratch
   DevBuf dOUTm, dHtot, dS, dH, dC, DZ, DZS, DHW, dProj, dVf, dVacc, dX, dglob, dfavg, dF, ws, ident;
   size_t ws_floats = 0;
@@ -140,6 +141,7 @@ struct Trainer {
     for (const ConvLayer& Ly : enc.layers) ws_floats = std::max(ws_floats, (size_t)2 * 9 * Ly.cin * Ly.cout);
     ws_floats = std::max(ws_floats, (size_t)2 * H * V);
     LRP_TRY(ws.alloc(ws_floats * 4, total));
+    LRP_TRY(Gimg.alloc((size_t)64 * enc.layers[0].cout * 4, total));
     std::vector<int> id(Bm);
     for (int i = 0; i < Bm; ++i) id[i] = i;
     LRP_TRY(ident.alloc(Bm * sizeof(int), total));
@@ -258,7 +260,7 @@ struct Trainer {
       if (li == 0) {
         // the image layer: one product over the im2col matrix the forward already built (64 columns = 27 taps x
         // channels for x+ and again for x-) instead of nine M = 3 products
-        float* G = dX.as<float>();                  // (64 x cout) scratch; dX is dead by now
+        float* G = Gimg.as<float>();                // (64 x cout) scratch
         LRP_TRY(mm(true, false, 64, Ly.cout, K, enc.a1.as<float>(), 64, dZ, Ly.cout, G, Ly.cout, false, st));
         hipLaunchKernelGGL(tr_fold_image_wgrad_kernel, dim3((27 * Ly.cout + 255) / 256), dim3(256), 0, st, G, gw, Ly.cout);
       } else {
@@ -544,8 +546,9 @@ struct Trainer {
     return sync_engine(enc, dec, total, st);
   }
 
-  // Encoder operand copies are rebuilt on the device (cnn_kernels.h pack_*_dev); the image layer (1.7 K weights) and
-  // the decoder's derived matrices still go through their host packers.
+  // Operand copies are rebuilt on the device: the encoder's by cnn_kernels.h pack_*_dev, the decoder's by
+  // Decoder::refresh_from_device.  Only the image layer (1.7 K weights) goes through its host packer — and the decoder
+  // once, if no forward has built its buffers yet (refresh returns 1).
   int sync_engine(Encoder& enc, Decoder& dec, int64_t* total, hipStream_t st) {
     if (enc.gates_pending) {                       // the side stream may still read the operand copies we replace
       LRP_HIP_CHECK(hipStreamWaitEvent(st, enc.ev_gates, 0));
