@@ -91,7 +91,15 @@ class TrainingLRPInferenceAdaptive(object):
         return [float(v) for v in losses.cpu().numpy()]
 
     def get_weights(self):
-        return self._engine.train_weights()
+        """Master weights, shaped like the arrays the model was built from (conv HWIO, dense (in, out))."""
+        shapes = {k: np.shape(v) for k, v in self._explainer._model.weights.items()}
+        return {k: v.reshape(shapes.get(k, v.shape)) for k, v in self._engine.train_weights().items()}
+
+    def save_weights(self, path):
+        """`keras_model.save_weights(...)` of the loop (train.py:585-587): an `.npz` bundle of the current master
+        weights that the explainer classes take back as `weight_path` (hdf5 is not available here)."""
+        np.savez(path, **self.get_weights())
+        return path
 
 
 class TrainingLRPInferenceGridTD(TrainingLRPInferenceAdaptive):

@@ -155,9 +155,21 @@ def test_training_loop_class():
     assert len(first) == 5 and np.isfinite(first).all()
     # the first call's loss is the oracle's loss for the lrp_weight the layer produced
     w1 = tr.get_weights()
-    assert any(np.abs(w1[k] - np.asarray(w[k]).ravel()).max() > 0 for k in ("c1_W", "lstm_Wi", "output_W"))
+    assert any(np.abs(w1[k] - np.asarray(w[k])).max() > 0 for k in ("c1_W", "lstm_Wi", "output_W"))
     losses = [first[0]] + [tr.train_on_batch([cap_in, X], y)[0] for _ in range(12)]
     assert losses[-1] < losses[0], losses                                  # same batch over and over: the loss goes down
+    # checkpoint round trip (train.py:585-587 save_weights -> E:27 load_weights): a fresh explainer on the bundle
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = tr.save_weights(os.path.join(d, "keras_model_00.npz"))
+        after = tr.predict_on_batch([cap_in, X]).cpu().numpy()
+        spec2 = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=H, embedding_dim=H, L=L, D=D, vocab_size=V, cnn_cfg=CFG,
+                                 img_hw=(HW, HW))
+        ex2 = ExplainImgCaptioningAdaptiveAttention(spec2, path, None, max_caption_length=5, max_images=4)
+        ex2._engine.encode_images(X)
+        ex2._engine.decoder_forward([[int(c) + 1 for c in cap_in[b, 1:]] + [1] for b in range(len(X))])
+        again = ex2._engine.read_state("caption_preds")[:, :cap_in.shape[1]].cpu().numpy()
+    np.testing.assert_allclose(again, after, rtol=1e-5, atol=1e-6)
 
 
 def test_gradients_match_oracle_midsize():
