@@ -197,15 +197,16 @@ def pmc_traffic_per_launch(precision="bf16x3"):
     conv launches comes from the newest committed PMC summary (profiles/run_profile.sh: separate
     --pmc FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    # the committed summaries are of the default-precision run; an fp32-mode profile would be r*_pmc_summary_fp32.json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % ("" if precision == "bf16x3" else "_fp32"))))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
     tot = n = 0.0
     for k, v in d.items():
-        # reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5)
+        # reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5) / fused image layer (6)
         m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>", k)
-        if m and m.group(1) in ("2", "3", "5") and m.group(2) == ("1" if precision == "bf16x3" else "0"):
+        if m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == ("1" if precision == "bf16x3" else "0"):
             if "fetch_bytes_per_launch_x2corr" in v and "write_bytes_per_launch" in v:
                 tot += (v["fetch_bytes_per_launch_x2corr"] + v["write_bytes_per_launch"]) * v["launches"]
                 n += v["launches"]
