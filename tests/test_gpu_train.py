@@ -365,7 +365,11 @@ def test_gradients_match_oracle_vgg16_full_size():
     layout = eng.train_begin()
     eng.encode_images(X)
     grads, losses = eng.train_step(cap_in, y, lw)
+    import time
+    t0 = time.perf_counter()
     total, l1, l2, g, _ = T.loss_and_grads(w, VGG16_CFG, X, cap_in, y, lw)
+    from gpu_util import report
+    report("train_full_size", cpu_oracle_seconds_per_image=round(time.perf_counter() - t0, 2), cpu_threads=torch.get_num_threads())
     np.testing.assert_allclose(losses.cpu().numpy()[:3], [total, l1, l2], rtol=1e-4)
     gf = grads.cpu().numpy()
     errs = {name: rel_l1(gf[off:off + n], g[name]) for name, (off, n) in layout.items()}
