@@ -131,17 +131,26 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
     }
     const float* Ac = As[cur] + (lane >> 5) * LDA + wm * 32 * TM + (lane & 31);
     const float* Bc = Bs[cur] + (lane >> 5) * LDB + wn * 32 * TN + (lane & 31);
+    // fragments of k-pair kk + 1 are read while the MFMAs of kk issue (two register sets)
+    float av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = Ac[32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = Bc[32 * j];
 #pragma unroll
     for (int kk = 0; kk < SG_BK / 2; ++kk) {
-      float av[TM], bv[TN];
+      const int c = kk & 1, nx = c ^ 1;
+      if (kk + 1 < SG_BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = Ac[2 * kk * LDA + 32 * i];
+        for (int i = 0; i < TM; ++i) av[nx][i] = Ac[2 * (kk + 1) * LDA + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bc[2 * kk * LDB + 32 * j];
+        for (int j = 0; j < TN; ++j) bv[nx][j] = Bc[2 * (kk + 1) * LDB + 32 * j];
+      }
+      __builtin_amdgcn_sched_barrier(0);            // keep the reads above the MFMAs (hipcc sinks them to their first use)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
     }
     if (more) {
       sg_put<TA, BM>(As[cur ^ 1], tid, ra);
