@@ -190,7 +190,8 @@ class ExplainImgCaptioningAttentionModel(object):
         return out, pairs, att, rw, R
 
     def _beam_search(self, X, beam_size=3):
-        """Caption generation (E:51-120).  Upstream of the LRP path (captions are an input to it); provided so harnesses
+        """Caption generation (E:51-120; the batched form of inference.py:178-253: with room for several images'
+        beams — max_images >= images x beam_size — one decoder step serves all of them).  Upstream of the LRP path (captions are an input to it); provided so harnesses
         run end to end.  The hypotheses' decoder state stays on the device (lrp_decoder_gen_begin / _gen_step): one
         decoder step per search step for all beams, where the reference re-runs the whole captioner on every partial
         caption (E:71).  Beam bookkeeping as in `_beam_search_replay`."""
@@ -201,46 +202,55 @@ class ExplainImgCaptioningAttentionModel(object):
         if beam_size > eng.max_images:
             return self._beam_search_replay(X, beam_size)          # not enough feature slots for one row per beam
         results = []
-        for img in imgs_input:
-            eng.encode_images(img[None])
-            feat = eng.get_features()[:1]
-            eng.set_features(feat.expand(beam_size, -1, -1).contiguous())      # one row (feature slot) per beam
-            eng.gen_begin(beam_size)
-            beams = [([], 0.0)]                  # (word ids so far, log prob); beam k lives in row k
-            rows = [0]
-            complete = []
+        k = beam_size
+        group = max(1, eng.max_images // k)      # images searched together: one decoder step serves all their beams
+        for lo in range(0, len(imgs_input), group):
+            imgs = imgs_input[lo:lo + group]
+            G = len(imgs)
+            eng.encode_images(imgs)
+            feat = eng.get_features()[:G]
+            eng.set_features(feat.repeat_interleave(k, dim=0).contiguous())    # one row (feature slot) per (image, beam)
+            eng.gen_begin(G * k)
+            beams = [[([], 0.0)] for _ in range(G)]      # per image: (word ids so far, log prob); beam j lives in row i*k + j
+            rows = [[0] for _ in range(G)]
+            complete = [[] for _ in range(G)]
             for s in range(self._max_caption_length):
                 if s == 0:
                     logits = eng.gen_step(0)
                 else:
-                    parent = rows + [rows[0]] * (beam_size - len(rows))
-                    word = [b[0][-1] for b in beams] + [beams[0][0][-1]] * (beam_size - len(beams))
+                    parent, word = [], []
+                    for i in range(G):
+                        pr = rows[i] + [rows[i][0]] * (k - len(rows[i]))
+                        parent += [i * k + r for r in pr]
+                        word += [b[0][-1] for b in beams[i]] + [beams[i][0][0][-1]] * (k - len(beams[i]))
                     logits = eng.gen_step(s, parent, word)
                 logits = logits.cpu().numpy()
-                cand = []
-                for r, (words, lp) in enumerate(beams):
-                    lg = logits[r]
-                    logp = lg - lg.max()
-                    logp = logp - np.log(np.exp(logp).sum())
-                    top = np.argpartition(logp, -beam_size)[-beam_size:]
-                    for k in top:
-                        w = int(k) + 1                      # model column -> tokenizer id (E:92)
-                        if w == EOS:
-                            complete.append((words, lp + float(logp[k])))
-                        cand.append((words + [w], lp + float(logp[k]), r))
-                cand.sort(key=lambda c: -c[1])
-                keep = [c for c in cand if c[0][-1] != EOS][:beam_size] or cand[:beam_size]
-                beams = [(c[0], c[1]) for c in keep]
-                rows = [c[2] for c in keep]
-            complete.sort(key=lambda c: -c[1])
-            beams.sort(key=lambda c: -c[1])
-            out = []
-            for i in range(beam_size):
-                if i < len(complete):
-                    out.append(complete[i][0] + [EOS])
-                elif i < len(beams):
-                    out.append(beams[i][0] + [EOS])
-            results.append(out)
+                for i in range(G):
+                    cand = []
+                    for r, (words, lp) in enumerate(beams[i]):
+                        lg = logits[i * k + r]
+                        logp = lg - lg.max()
+                        logp = logp - np.log(np.exp(logp).sum())
+                        top = np.argpartition(logp, -k)[-k:]
+                        for c in top:
+                            w = int(c) + 1                      # model column -> tokenizer id (E:92)
+                            if w == EOS:
+                                complete[i].append((words, lp + float(logp[c])))
+                            cand.append((words + [w], lp + float(logp[c]), r))
+                    cand.sort(key=lambda c: -c[1])
+                    keep = [c for c in cand if c[0][-1] != EOS][:k] or cand[:k]
+                    beams[i] = [(c[0], c[1]) for c in keep]
+                    rows[i] = [c[2] for c in keep]
+            for i in range(G):
+                complete[i].sort(key=lambda c: -c[1])
+                beams[i].sort(key=lambda c: -c[1])
+                out = []
+                for j in range(k):
+                    if j < len(complete[i]):
+                        out.append(complete[i][j][0] + [EOS])
+                    elif j < len(beams[i]):
+                        out.append(beams[i][j][0] + [EOS])
+                results.append(out)
         self.caption = None
         self._state_cache = {}
         return results[0] if len(results) == 1 else results

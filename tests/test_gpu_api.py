@@ -274,6 +274,10 @@ def test_incremental_beam_search_equals_replay(kind):
             words.append(nxt)
         g1 = ex._beam_search((None, X[b:b + 1]), beam_size=1)[0]
         assert g1[:len(words)] == words[:len(g1) - 1] or g1 == words + [1], (g1, words)
+    # several images at once (inference.py:178-253): with max_images = 8 and beam 3 both images share every decoder step
+    ex8 = cls(spec, None, None, max_caption_length=7, max_images=8)
+    both = ex8._beam_search((None, X), beam_size=3)
+    assert both == [ex._beam_search((None, X[b:b + 1]), beam_size=3) for b in range(2)]
 
 
 def test_generation_api_errors():
