@@ -161,10 +161,8 @@ struct Encoder {
     return LRP_OK;
   }
   // input of conv li as the last encode left it (li >= 1; the image itself for li = 0)
-  const float* x1_last = nullptr;                  // input of conv 1 (the image layer's output sits in a ping-pong buffer)
   const float* layer_input(int li) const {
     if (li == 0) return images.as<float>();
-    if (li == 1) return x1_last;
     const ConvLayer& P = layers[li - 1];
     return P.pool_after ? P.P.as<float>() : P.Akeep.as<float>();
   }
@@ -344,8 +342,6 @@ struct Encoder {
     for (const ConvLayer& L : layers)
       if (L.cout & 7) mixed = false;
     const bool overlap = mixed && side && overlap_enabled() && layers.size() > 1;
-    if (keep_acts && !overlap)
-      return fail(LRP_ERR_UNSUPPORTED, "the fine-tune step needs the overlapped encode (default precision mode, widths % 8 == 0)");
     std::vector<const float*> xin(layers.size() + 1, nullptr);   // overlapped path: input of every conv
     for (size_t li = 0; li < layers.size(); ++li) {
       ConvLayer& L = layers[li];
@@ -426,7 +422,12 @@ struct Encoder {
         float* t = x; x = a; a = t;                   // next input = a_l
       }
       xin[li + 1] = x;
-      if (li == 0) x1_last = x;
+      if (keep_acts) {
+        // layers that run through the ping-pong buffers (the image layer always; every layer of the exact-fp32 / not
+        // overlapped forward): park the next conv's input where layer_input() looks for it
+        const size_t bytes = (size_t)B * L.act_elems() * sizeof(float) / (L.pool_after ? 4 : 1);
+        LRP_HIP_CHECK(hipMemcpyAsync(L.pool_after ? L.P.p : L.Akeep.p, x, bytes, hipMemcpyDeviceToDevice, st));
+      }
       if (mixed && !overlap) {                        // split8 copy of the next conv's input
         const size_t n8 = (size_t)B * layers[li + 1].H * layers[li + 1].W * layers[li + 1].cin / 8;
         hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, x, bufXs.as<float>(), n8);

@@ -42,13 +42,16 @@ def _engine(w, B):
     return eng
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("with_masks", [False, True])
-def test_gradients_match_oracle(with_masks):
+def test_gradients_match_oracle(with_masks, precision):
+    """(precision = the engine's arithmetic mode: 'fp32' also takes the encoder's not-overlapped forward)"""
     from oracle import train_ref as T
     w, X, cap_in, y, lw, masks = _case()
     if not with_masks:
         masks = None
     eng = _engine(w, len(X))
+    eng.set_precision(precision)
     layout = eng.train_begin(lr=1e-3, clipvalue=0.01)
     assert set(layout) == set(T.param_names(CFG))
     eng.encode_images(X)
