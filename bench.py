@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--cpu-sample-tokens", type=int, default=10, help="tokens of one caption the CPU port explains (~1 s each)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16x3_fast"],
                     help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (default) or exact fp32 MFMA")
+    ap.add_argument("--handles", type=int, default=2,
+                    help="batches in flight per GPU: consecutive steps alternate between this many lrp_handles on their own "
+                         "HIP streams (pipeline.py); 1 = strictly one step after the other")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                         "the N>1 control path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -98,19 +101,21 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from lrp_imagecaptioning_amd.engine import LRPEngine
     from lrp_imagecaptioning_amd.parallel import broadcast_weights, shard_range
+    from lrp_imagecaptioning_amd.pipeline import LRPPipeline
     from lrp_imagecaptioning_amd.synthetic import captions, images
 
     B, T, V = args.batch, args.tokens, args.vocab
-    eng = LRPEngine(decoder="adaptive", V=V, max_images=B, max_tokens=B * T, max_caption_len=T + 1, device=local)
-    eng.set_precision(args.precision)
+    pipe = LRPPipeline(max(1, args.handles), decoder="adaptive", V=V, max_images=B, max_tokens=B * T, max_caption_len=T + 1,
+                       device=local)
+    eng = pipe.engines[0]
+    pipe.set_precision(args.precision)
     # frozen weights: rank 0 owns them, everyone else receives them over RCCL/xGMI
     w_host = synth_weights(0, V) if rank == 0 else None
     if world > 1:
-        eng.set_weights_from_device(broadcast_weights(w_host, synth_weights_shapes(V), local, dist))
+        pipe.set_weights_from_device(broadcast_weights(w_host, synth_weights_shapes(V), local, dist))
     else:
-        eng.set_weights(w_host)
+        pipe.set_weights(w_host)
 
     # this rank's shard of the global batch (global batch = world * B images)
     lo, hi = shard_range(world * B, world, rank)
@@ -119,12 +124,12 @@ def main():
     caps = captions(rs, hi - lo, T, V)
     img_idx = [b for b in range(B) for _ in range(T)]
     tpos = [t for _ in range(B) for t in range(1, T + 1)]
-    out = torch.empty((B * T, 224, 224, 3), dtype=torch.float32, device=X.device)
+    outs = [torch.empty((B * T, 224, 224, 3), dtype=torch.float32, device=X.device) for _ in pipe.engines]
+    out = outs[0]
 
     def step():
-        eng.encode_images(X)
-        eng.decoder_forward(caps)
-        eng.explain_tokens(img_idx, tpos, out=out)
+        # one pass of the hot path over one batch; consecutive steps go to alternating handles / streams
+        pipe.explain_batch(X, caps, img_idx, tpos, out=outs[pipe._next])
 
     for _ in range(args.warmup):
         step()
@@ -144,9 +149,10 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=X.device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    assert torch.isfinite(out).all()
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
 
-    # dominant kernel, measured live with HIP events on the launch stream (outside the timed region)
+    # dominant kernel, measured live with HIP events on the launch stream (outside the timed region, nothing else in flight)
+    pipe._next = 0
     eng.profile_enable(True)
     step()
     torch.cuda.synchronize()
@@ -181,7 +187,11 @@ def main():
             "config": {"workload": "batch=%d synthetic 224x224 per GPU, VGG16 + adaptive-attention, LRP per-token "
                                    "heat-maps, %d words/caption, V=%d (BASELINE configs[1])" % (B, T, V),
                        "heatmaps_per_step": world * B * T, "parallelism": "image-sharded x%d, RCCL weight broadcast" % world,
-                       "reverse_walk_precision": args.precision},
+                       "reverse_walk_precision": args.precision,
+                       "handles_per_gpu": len(pipe.engines),
+                       "schedule": "consecutive steps alternate between the handles, each on its own HIP stream (one batch's "
+                                   "decoder / encode phases run under the previous batch's reverse walk)"
+                                   if len(pipe.engines) > 1 else "one step after the other on one stream"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline and args.cpu_sample_tokens > 0 and world == 1:               # (rank 0 at N = 1 only: the other ranks would idle behind it)

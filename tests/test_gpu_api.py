@@ -347,3 +347,26 @@ def test_vgg19_topology():
         worst = max(worst, rel_l1(ex._explain_CNN(X, R), C.analyze(layers, X, Rref)))
     report("api_vgg19", max_rel_l1=worst)
     assert worst < TOL, worst
+
+
+def test_pipeline_two_handles_identical_to_one():
+    """LRPPipeline: batches alternating over two handles / streams give exactly what one handle gives."""
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    from lrp_imagecaptioning_amd.pipeline import LRPPipeline
+    import torch
+    w, rs = _weights(3)
+    kw = dict(decoder="adaptive", cnn_cfg=CFG, img_hw=(HW, HW), L=L, D=D, H=H, E=H, V=V, max_images=2, max_tokens=8, max_caption_len=5)
+    pipe = LRPPipeline(2, **kw)
+    pipe.set_weights(w)
+    one = LRPEngine(**kw)
+    one.set_weights(w)
+    caps = [[5, 9, 17, 1], [8, 3, 1]]
+    idx, tpos = [0, 0, 0, 1, 1], [1, 2, 3, 1, 2]
+    batches = [torch.as_tensor(rs.uniform(-120, 130, size=(2, HW, HW, 3)).astype(np.float32)).cuda() for _ in range(5)]
+    got = [pipe.explain_batch(X, caps, idx, tpos)[0] for X in batches]
+    pipe.synchronize()
+    for X, g in zip(batches, got):
+        one.encode_images(X)
+        one.decoder_forward(caps)
+        want = one.explain_tokens(idx, tpos)[0]
+        assert torch.equal(g, want)
