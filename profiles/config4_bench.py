@@ -37,6 +37,19 @@ def main():
     step()
     n = 3
     ms = timed(lambda: [step() for _ in range(n)]) / n
+    handles = int(os.environ.get("HANDLES", 2))
+    if handles > 1:                                     # two batches in flight (pipeline.py), like bench.py's default
+        from lrp_imagecaptioning_amd.pipeline import LRPPipeline
+        pipe = LRPPipeline(handles, decoder="gridtd", img_hw=(224, 224), L=49, D=2048, H=512, E=512, V=V, max_images=B,
+                           max_tokens=B * T, max_caption_len=T + 1, resnet={"stem": 64, "stacks": RESNET101_STACKS})
+        pipe.set_weights(w)
+        outs = [torch.empty_like(out) for _ in range(handles)]
+        for _ in range(handles):
+            pipe.explain_batch(X, caps, idx, tt, out=outs[pipe._next])
+        pipe.synchronize()
+        n2 = 6
+        ms2 = timed(lambda: [[pipe.explain_batch(X, caps, idx, tt, out=outs[pipe._next]) for _ in range(n2)], pipe.synchronize()]) / n2
+        print("config4 with %d handles in flight: %.2f ms/step = %.1f heat-maps/s" % (handles, ms2, B * T / ms2 * 1e3))
     print("config4 (grid-TD + ResNet-101, B=%d, T=%d): %.2f ms/step = %.1f heat-maps/s; encode %.2f, decoder fwd %.2f, "
           "decoder explain %.2f ms; workspace %.1f GB" % (
               B, T, ms, B * T / ms * 1e3, timed(lambda: eng.encode_images(X)), timed(lambda: eng.decoder_forward(caps)),
