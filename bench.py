@@ -129,7 +129,7 @@ def main():
 
     def step():
         # one pass of the hot path over one batch; consecutive steps go to alternating handles / streams
-        pipe.explain_batch(X, caps, img_idx, tpos, out=outs[pipe._next])
+        pipe.explain_batch(X, caps, img_idx, tpos, out=outs[pipe.next_slot])
 
     for _ in range(args.warmup):
         step()
@@ -152,7 +152,7 @@ def main():
     assert all(bool(torch.isfinite(o).all()) for o in outs)
 
     # dominant kernel, measured live with HIP events on the launch stream (outside the timed region, nothing else in flight)
-    pipe._next = 0
+    pipe.reset()
     eng.profile_enable(True)
     step()
     torch.cuda.synchronize()

@@ -22,6 +22,16 @@ class LRPPipeline(object):
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_handles)]
         self._next = 0
 
+    @property
+    def next_slot(self):
+        """Index of the handle / stream the next `explain_batch` goes to (so the caller can pick that slot's output)."""
+        return self._next
+
+    def reset(self):
+        """Wait for everything in flight and start again at slot 0."""
+        self.synchronize()
+        self._next = 0
+
     def set_weights(self, weights):
         for e in self.engines:
             e.set_weights(weights)

@@ -45,10 +45,10 @@ def main():
         pipe.set_weights(w)
         outs = [torch.empty_like(out) for _ in range(handles)]
         for _ in range(handles):
-            pipe.explain_batch(X, caps, idx, tt, out=outs[pipe._next])
+            pipe.explain_batch(X, caps, idx, tt, out=outs[pipe.next_slot])
         pipe.synchronize()
         n2 = 6
-        ms2 = timed(lambda: [[pipe.explain_batch(X, caps, idx, tt, out=outs[pipe._next]) for _ in range(n2)], pipe.synchronize()]) / n2
+        ms2 = timed(lambda: [[pipe.explain_batch(X, caps, idx, tt, out=outs[pipe.next_slot]) for _ in range(n2)], pipe.synchronize()]) / n2
         print("config4 with %d handles in flight: %.2f ms/step = %.1f heat-maps/s" % (handles, ms2, B * T / ms2 * 1e3))
     print("config4 (grid-TD + ResNet-101, B=%d, T=%d): %.2f ms/step = %.1f heat-maps/s; encode %.2f, decoder fwd %.2f, "
           "decoder explain %.2f ms; workspace %.1f GB" % (
