@@ -14,6 +14,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The library normally travels prebuilt (python __graft_entry__.py); a checkout without it is built once here.
+    The product itself never builds on import — it fails loudly (LrpLibraryMissing)."""
+    try:
+        from lrp_imagecaptioning_amd import _capi
+        if not os.path.exists(_capi.LIB_PATH):
+            from lrp_imagecaptioning_amd.build import build_library
+            build_library()
+    except Exception as e:                                  # (no hipcc: the tests that need the library say so)
+        sys.stderr.write("conftest: could not build liblrp_hip.so: %s\n" % e)
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch
