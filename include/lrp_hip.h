@@ -314,6 +314,12 @@ int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_de
                    const float* lrp_weight_dev, const float* mask_image_features_dev, const float* mask_global_dev,
                    const float* mask_output_dev, const float* mask_lstm_in_dev, const float* mask_lstm_rec_dev,
                    const float* mask_logits_dev, float* grads_dev, float* losses_dev, void* stream);
+/* Optional: the training-mode decoder forward of lrp_train_step ahead of time (it needs neither lrp_weight nor the labels),
+ * e.g. on a second stream under the explanation that produces lrp_weight.  A following lrp_train_step with the same B, T
+ * (and the same cap_in / masks) waits for it and starts at the loss. */
+int lrp_train_forward(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const float* mask_image_features_dev,
+                      const float* mask_global_dev, const float* mask_output_dev, const float* mask_lstm_in_dev,
+                      const float* mask_lstm_rec_dev, void* stream);
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream);
 int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
 

@@ -67,6 +67,7 @@ SYMBOLS = {
     "lrp_train_num_params": (C.c_int32, [_P]),
     "lrp_train_param_info": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lrp_train_step": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "lrp_train_forward": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "lrp_train_apply": (C.c_int, [_P, _P, _P]),
     "lrp_train_get_master": (C.c_int, [_P, _P, _P]),
     "lrp_heatmap_render": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),

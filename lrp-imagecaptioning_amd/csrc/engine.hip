@@ -479,6 +479,17 @@ int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_de
   return h->trainer.step(h->enc, in, &h->ws_bytes);
 }
 
+int lrp_train_forward(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const float* mask_image_features_dev,
+                      const float* mask_global_dev, const float* mask_output_dev, const float* mask_lstm_in_dev,
+                      const float* mask_lstm_rec_dev, void* stream) {
+  if (!h || !cap_in_dev) return fail(LRP_ERR_INVALID, "null argument");
+  Trainer::StepIn in{};
+  in.feat = h->feat(); in.B = B; in.T = T; in.cap_in = cap_in_dev;
+  in.m_if = mask_image_features_dev; in.m_glob = mask_global_dev; in.m_out = mask_output_dev; in.m_lin = mask_lstm_in_dev;
+  in.m_lrec = mask_lstm_rec_dev; in.st = S(stream);
+  return h->trainer.forward(h->enc, in, &h->ws_bytes);
+}
+
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream) {
   if (!h || !grads_dev) return fail(LRP_ERR_INVALID, "null argument");
   return h->trainer.apply(h->enc, h->dec, grads_dev, nullptr, S(stream));

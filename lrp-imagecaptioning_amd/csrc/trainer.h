@@ -42,7 +42,10 @@ struct Trainer {
   DevBuf master, mom, vel;
   std::vector<float> host;                     // staging of the initial weights
   float* host_pinned = nullptr;                // pinned mirror of the slices that are re-packed on the host
-  ~Trainer() { if (host_pinned) (void)hipHostFree(host_pinned); }
+  ~Trainer() {
+    if (host_pinned) (void)hipHostFree(host_pinned);
+    if (ev_fwd) (void)hipEventDestroy(ev_fwd);
+  }
   float lr = 0.f, clip = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
   int64_t iter = 0;
   // forward state (time-major rows (t, b))
@@ -177,24 +180,33 @@ struct Trainer {
   const char* nm_satt() const { return gridtd ? "W_s" : "Ws"; }
   const char* nm_vatt() const { return gridtd ? "W_a" : "V"; }
 
-  int step(Encoder& enc, const StepIn& in, int64_t* total) {
+  // The training-mode decoder forward needs only the features, the captions and the dropout masks — not lrp_weight.
+  // lrp_train_forward may therefore run it early, on another stream, under the explanation that produces lrp_weight
+  // (a chain of small launches under an MFMA-bound walk); lrp_train_step then picks it up (same B, T) and starts at the loss.
+  bool fwd_valid = false;
+  int fwd_B = 0, fwd_T = 0;
+  hipEvent_t ev_fwd = nullptr;
+  int check_step(Encoder& enc, const StepIn& in) {
     if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
-    const int B = in.B, T = in.T;
-    hipStream_t st = in.st;
-    if (B < 1 || B > Bm || T < 2 || T > Tm) return fail(LRP_ERR_INVALID, "B=%d / T=%d outside [1,%d] / [2,%d]", B, T, Bm, Tm);
-    if (enc.encoded < B || enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run (after lrp_train_begin) on the batch first");
+    if (in.B < 1 || in.B > Bm || in.T < 2 || in.T > Tm)
+      return fail(LRP_ERR_INVALID, "B=%d / T=%d outside [1,%d] / [2,%d]", in.B, in.T, Bm, Tm);
+    if (enc.encoded < in.B || enc.features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run (after lrp_train_begin) on the batch first");
     if (in.m_logits && !gridtd) return fail(LRP_ERR_INVALID, "the adaptive model has no Dropout on the logits");
     for (size_t li = 0; li + 1 < enc.layers.size(); ++li)
       if (!enc.layers[li].pool_after && !enc.layers[li].Akeep.p) return fail(LRP_ERR_STATE, "activations were not kept");
-    const size_t TB = (size_t)T * B, BH = (size_t)B * H;
+    return LRP_OK;
+  }
+  int forward(Encoder& enc, const StepIn& in, int64_t* total) {
+    LRP_TRY(check_step(enc, in));
+    const int B = in.B, T = in.T;
+    hipStream_t st = in.st;
+    const size_t TB = (size_t)T * B;
     if ((in.m_lin || in.m_lrec) && !X4.p) {              // allocated on first use
       const size_t cap = (size_t)Bm * Tm;
       LRP_TRY(X4.alloc(4 * cap * 2 * E * 4, total)); LRP_TRY(H4.alloc(4 * cap * H * 4, total)); LRP_TRY(P4.alloc(4 * cap * 2 * E * 4, total));
     }
     const float* feat = in.feat;
-    float* grads = in.grads;
     float *vf = Vf.as<float>(), *pj = proj.as<float>(), *x = Xall.as<float>();
-    auto g = [&](const char* nm) { return grads + off(nm); };
     // ---------------- forward: the per-image statics (M:1343-1352, get_constants M:602-604)
     LRP_TRY(mm(false, false, B * L, H, D, feat, D, W("image_features_W"), H, vf, H, false, st));
     hipLaunchKernelGGL(tr_bias_relu_mask_kernel, dim3(grid_for((size_t)B * L * H)), dim3(256), 0, st, vf, W("image_features_b"), in.m_if,
@@ -209,9 +221,27 @@ struct Trainer {
                        gridtd ? E : 0, gridtd ? 0 : E);
     LRP_TRY(gridtd ? scan_fwd_gridtd(in) : scan_fwd_adaptive(in));
     LRP_HIP_CHECK(hipGetLastError());
-    // ---------------- output layer, two-headed loss, d logits in place
+    LRP_TRY(mm(false, false, (int)TB, V, H, OUTm.as<float>(), H, W("output_W"), V, logits.as<float>(), V, false, st));   // logits - bias
+    if (!ev_fwd) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
+    LRP_HIP_CHECK(hipEventRecord(ev_fwd, st));
+    fwd_valid = true; fwd_B = B; fwd_T = T;
+    return LRP_OK;
+  }
+
+  int step(Encoder& enc, const StepIn& in, int64_t* total) {
+    LRP_TRY(check_step(enc, in));
+    const int B = in.B, T = in.T;
+    hipStream_t st = in.st;
+    const size_t TB = (size_t)T * B, BH = (size_t)B * H;
+    if (fwd_valid && fwd_B == B && fwd_T == T) LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_fwd, 0));    // ran early (lrp_train_forward)
+    else LRP_TRY(forward(enc, in, total));
+    fwd_valid = false;
+    const float* feat = in.feat;
+    float* grads = in.grads;
+    float* vf = Vf.as<float>();
+    auto g = [&](const char* nm) { return grads + off(nm); };
+    // ---------------- two-headed loss, d logits in place
     float* lg = logits.as<float>();
-    LRP_TRY(mm(false, false, (int)TB, V, H, OUTm.as<float>(), H, W("output_W"), V, lg, V, false, st));
     const float scale = 1.f / (float)((size_t)B * (T - 1));
     hipLaunchKernelGGL(tr_loss_kernel, dim3((unsigned)TB), dim3(256), 0, st, lg, W("output_b"), in.lrp_weight, in.m_logits, in.y_idx,
                        part.as<float>(), B, T, V, scale);
@@ -538,6 +568,7 @@ struct Trainer {
   // keras Adam(lr, clipvalue) on the master weights, then the engine's operand copies are rebuilt from them
   int apply(Encoder& enc, Decoder& dec, const float* grads, int64_t* total, hipStream_t st) {
     if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
+    fwd_valid = false;                             // (a forward of the old weights, if any, is stale)
     ++iter;
     const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)b2, (double)iter)) / (1.0 - std::pow((double)b1, (double)iter));
     hipLaunchKernelGGL(tr_adam_kernel, dim3(grid_for(n_total)), dim3(256), 0, st, master.as<float>(), grads, mom.as<float>(),

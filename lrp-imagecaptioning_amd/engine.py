@@ -215,26 +215,21 @@ class LRPEngine(object):
         self.n_images = 0
         return self.train_layout
 
-    def train_step(self, cap_in, y_idx, lrp_weight, masks=None, grads=None):
-        """Gradients of the two-headed loss for the images last encoded.  cap_in / y_idx (B, T) ints (y -1 = no label),
-        lrp_weight (B, T, V).  masks: dict with optional 'image_features' (B, L, H), 'global' (B, E), 'output' (B, T, H),
-        'lstm_in' (T, 4, B, 2E), 'lstm_rec' (T, 4, B, H) (the LSTM cell's per-gate, per-step dropout).
-        Returns (grads flat float32 device tensor, losses (5,) device tensor = total, loss head 1, loss head 2,
-        accuracy head 1, accuracy head 2: the list `train_on_batch` returns)."""
+    def _train_inputs(self, cap_in, masks):
+        """Device copies + checks of what the decoder's training forward reads: cap_in (B, T) and the dropout masks."""
         masks = masks or {}
         ci = self._dev(cap_in, torch.int32)
-        yi = self._dev(y_idx, torch.int32)
+        if ci.dim() != 2:
+            raise ValueError("cap_in must be (B, T)")
         B, T = ci.shape
-        lw = self._dev(lrp_weight).reshape(B, T, self.V)
-        if tuple(yi.shape) != (B, T):
-            raise ValueError("y_idx must have the shape of cap_in")
         # the kernels index the embedding / the logits with these: validate on the host side of the boundary
         if int(ci.min()) < 0 or int(ci.max()) >= self.V:
             raise ValueError("cap_in holds embedding rows outside [0, V)")
-        if int(yi.min()) < -1 or int(yi.max()) >= self.V:
-            raise ValueError("y_idx holds class indices outside [-1, V)")
         if B > self.n_images:
-            raise RuntimeError("encode_images must run on the batch before train_step")
+            raise RuntimeError("encode_images must run on the batch before the fine-tune step")
+        for k in masks:
+            if k not in ("image_features", "global", "output", "lstm_in", "lstm_rec", "logits"):
+                raise ValueError("unknown dropout mask '%s'" % k)
         def m(key, shape):
             v = masks.get(key)
             if v is None:
@@ -243,13 +238,34 @@ class LRPEngine(object):
             if tuple(v.shape) != shape:
                 raise ValueError("mask '%s' must be %s" % (key, shape))
             return v
-        mi, mg, mo = m("image_features", (B, self.L, self.H)), m("global", (B, self.E)), m("output", (B, T, self.H))
         win = 2 * self.H if self.decoder == "gridtd" else 2 * self.E         # language LSTM input [c_hat | h1] / [emb | glob]
-        ml, mr = m("lstm_in", (T, 4, B, win)), m("lstm_rec", (T, 4, B, self.H))
-        mz = m("logits", (B, T, self.V))
-        for k in masks:
-            if k not in ("image_features", "global", "output", "lstm_in", "lstm_rec", "logits"):
-                raise ValueError("unknown dropout mask '%s'" % k)
+        return ci, (m("image_features", (B, self.L, self.H)), m("global", (B, self.E)), m("output", (B, T, self.H)),
+                    m("lstm_in", (T, 4, B, win)), m("lstm_rec", (T, 4, B, self.H)), m("logits", (B, T, self.V)))
+
+    def train_forward(self, cap_in, masks=None):
+        """The training-mode decoder forward of `train_step`, ahead of time on the CURRENT stream (it needs neither
+        lrp_weight nor the labels): issue it on a side stream under the explanation that produces lrp_weight; the next
+        `train_step` with the same (B, T) waits for it and starts at the loss.  Pass the same cap_in / masks to both."""
+        ci, (mi, mg, mo, ml, mr, _) = self._train_inputs(cap_in, masks)
+        B, T = ci.shape
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _capi.check(self._lib.lrp_train_forward(self._h, B, T, p(ci), p(mi), p(mg), p(mo), p(ml), p(mr), self._stream()))
+        self._train_fwd_keep = (ci, mi, mg, mo, ml, mr)                     # alive until the step has consumed them
+
+    def train_step(self, cap_in, y_idx, lrp_weight, masks=None, grads=None):
+        """Gradients of the two-headed loss for the images last encoded.  cap_in / y_idx (B, T) ints (y -1 = no label),
+        lrp_weight (B, T, V).  masks: dict with optional 'image_features' (B, L, H), 'global' (B, E), 'output' (B, T, H),
+        'lstm_in' (T, 4, B, 2E), 'lstm_rec' (T, 4, B, H) (the LSTM cell's per-gate, per-step dropout).
+        Returns (grads flat float32 device tensor, losses (5,) device tensor = total, loss head 1, loss head 2,
+        accuracy head 1, accuracy head 2: the list `train_on_batch` returns)."""
+        ci, (mi, mg, mo, ml, mr, mz) = self._train_inputs(cap_in, masks)
+        yi = self._dev(y_idx, torch.int32)
+        B, T = ci.shape
+        lw = self._dev(lrp_weight).reshape(B, T, self.V)
+        if tuple(yi.shape) != (B, T):
+            raise ValueError("y_idx must have the shape of cap_in")
+        if int(yi.min()) < -1 or int(yi.max()) >= self.V:
+            raise ValueError("y_idx holds class indices outside [-1, V)")
         if grads is None:
             grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
         losses = torch.empty(5, dtype=torch.float32, device=self.device)

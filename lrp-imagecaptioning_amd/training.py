@@ -36,6 +36,7 @@ class TrainingLRPInferenceAdaptive(object):
         self._pg = process_group
         self.layout = self._engine.train_begin(lr=learning_rate, clipvalue=clipvalue)
         self._grads = torch.zeros(self._engine.train_flat_size, dtype=torch.float32, device=self._engine.device)
+        self._side = torch.cuda.Stream(device=self._engine.device)
 
     # -- keras_model.predict_on_batch(X + [zeros])[0]: teacher-forced logits (B, T, V), inference mode
     def predict_on_batch(self, X):
@@ -78,14 +79,21 @@ class TrainingLRPInferenceAdaptive(object):
             y_idx = np.where(y.sum(-1) > 0, y.argmax(-1), -1).astype(np.int32)
         else:
             y_idx = y.astype(np.int32)
+        masks = self._masks(B, T)
+        cap_dev = torch.as_tensor(cap_in, dtype=torch.int32).to(eng.device)
         if lrp_weight is None:
             y_pred = self.predict_on_batch(X)
+            # the training-mode decoder forward needs only the features: run it on a side stream under the explanation
+            cur = torch.cuda.current_stream(eng.device)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                eng.train_forward(cap_dev, masks)
             lrp_weight = self._lrp_layer.call_device(X[1], y_pred, images_encoded=True)
-            if eng.n_images < B:                       # nothing was explained (no positions): the caches are still needed
+            if eng.n_images < B:                       # (cannot happen after predict_on_batch; keeps the caches' owner explicit)
                 eng.encode_images(X[1])
         else:
             eng.encode_images(X[1])
-        grads, losses = eng.train_step(cap_in, y_idx, lrp_weight, self._masks(B, T), grads=self._grads)
+        grads, losses = eng.train_step(cap_dev, y_idx, lrp_weight, masks, grads=self._grads)
         grads, losses = average_gradients(grads, losses, self._pg)    # one bucket: the whole flat gradient
         eng.train_apply(grads)
         return [float(v) for v in losses.cpu().numpy()]

@@ -385,3 +385,24 @@ def test_gradients_match_oracle_vgg16_full_size():
     assert all(errs[k] < 1e-4 for k in dec), {k: errs[k] for k in dec}
     assert errs["block5_conv3_W"] < 1e-4 and errs["block5_conv3_b"] < 1e-4          # (its dZ is the masked head itself)
     assert all(v < 2e-2 for v in errs.values()), errs
+
+
+def test_early_forward_gives_identical_gradients():
+    """lrp_train_forward on a side stream + lrp_train_step == lrp_train_step alone, bit for bit; a forward for another
+    (B, T) is ignored."""
+    w, X, cap_in, y, lw, masks = _case(9)
+    eng = _engine(w, len(X))
+    eng.train_begin()
+    eng.encode_images(X)
+    g_ref, l_ref = eng.train_step(cap_in, y, lw, masks)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.train_forward(cap_in, masks)
+    g1, l1 = eng.train_step(cap_in, y, lw, masks)
+    assert torch.equal(g1, g_ref) and torch.equal(l1, l_ref)
+    with torch.cuda.stream(side):
+        eng.train_forward(cap_in[:, :3], {k: (v[:, :3] if k == "output" else v[:3] if k.startswith("lstm") else v) for k, v in masks.items()})
+    side.synchronize()
+    g2, _ = eng.train_step(cap_in, y, lw, masks)              # different T: the early forward does not apply
+    assert torch.equal(g2, g_ref)
