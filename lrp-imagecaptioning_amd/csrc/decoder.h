@@ -16,6 +16,7 @@
 #include "decoder_batched_kernels.h"
 #include "decoder_kernels.h"
 #include "gradient_kernels.h"
+#include "train_gemm.h"
 
 namespace lrp {
 
@@ -447,18 +448,43 @@ struct Decoder {
                          cap_dev.as<int>(), xh.as<float>(), S_<float>("xt"), i, Tm, E, H, V, sos);
       LRP_HIP_CHECK(hipGetLastError());
       const size_t zslab = (size_t)B_max * 5 * H, pslab = (size_t)B_max * H;
-      LRP_HIP_CHECK((skinny<float, float, float>(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, bcat.as<float>(),
-                                                 zgate.as<float>(), 5 * H, B, Kd, 5 * H, 0, st, KS_GATE, zslab)));
-      hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B), dim3(256), 0, st, zgate.as<float>(), KS_GATE, zslab, ht,
+      // the three products of a step on the fp32 matrix cores (train_gemm.h: 64 x 128 tiles, K split over ~240
+      // workgroups, slices reduced in index order) — LRP_DEC_MFMA_FWD=0: the VALU skinny GEMM with consumer-side slabs
+      const bool mf = mfma_forward();
+      int ksg = KS_GATE, ksp = KS_PROJ;
+      if (mf) {
+        if (!sg_ws.p) { int64_t dummy = 0; LRP_TRY(sg_ws.alloc(SG_WS_FLOATS * sizeof(float), &dummy)); }
+        auto mm = [&](const float* A, long lda, const float* Bm, int N, int K, const float* bias, float* Cc) -> int {
+          SgemmArgs a{};
+          a.A = A; a.lda = lda; a.B = Bm; a.ldb = N; a.C = Cc; a.ldc = N; a.M = B; a.N = N; a.K = K; a.bias = bias;
+          LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
+          return LRP_OK;
+        };
+        LRP_TRY(mm(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, Kd, bcat.as<float>(), zgate.as<float>()));
+        ksg = ksp = 1;
+      } else {
+        LRP_HIP_CHECK((skinny<float, float, float>(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, bcat.as<float>(),
+                                                   zgate.as<float>(), 5 * H, B, Kd, 5 * H, 0, st, KS_GATE, zslab)));
+      }
+      hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B), dim3(256), 0, st, zgate.as<float>(), ksg, zslab, ht,
                          S_<float>("ct"), S_<float>("gt"), S_<float>("it_act"), S_<float>("ft_act"), stt,
                          S_<float>("ot_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
-      LRP_HIP_CHECK((skinny<float, float, float>(ht + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
-                                                 hproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
-      LRP_HIP_CHECK((skinny<float, float, float>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
-                                                 sproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
+      if (mf) {
+        SgemmArgs a{};
+        a.lda = (long)S * H; a.ldb = H; a.ldc = H; a.M = B; a.N = H; a.K = H;
+        a.A = ht + (size_t)(i + 1) * H; a.B = Wg.as<float>(); a.C = hproj.as<float>();
+        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
+        a.A = stt + (size_t)(i + 1) * H; a.B = Ws.as<float>(); a.C = sproj.as<float>();
+        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
+      } else {
+        LRP_HIP_CHECK((skinny<float, float, float>(ht + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
+                                                   hproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
+        LRP_HIP_CHECK((skinny<float, float, float>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
+                                                   sproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
+      }
       hipLaunchKernelGGL(dec_att_scores_kernel, dim3(B, (L + 1 + ATT_ROWS - 1) / ATT_ROWS), dim3(256),
-                         (size_t)2 * H * sizeof(float), st, hproj.as<float>(), sproj.as<float>(), KS_PROJ, pslab,
+                         (size_t)2 * H * sizeof(float), st, hproj.as<float>(), sproj.as<float>(), ksp, pslab,
                          stat.as<float>(), vvec.as<float>(), att_pre.as<float>(), L, H);
       LRP_HIP_CHECK(hipGetLastError());
       hipLaunchKernelGGL(dec_att_finish_kernel, dim3(B), dim3(256), (size_t)(L + 8) * sizeof(float), st,
@@ -791,6 +817,12 @@ struct Decoder {
   // (R_feat 3-10e-6 instead of 0.4-1.2e-6 vs the float64 oracle).  LRP_DEC_TAIL_SPLIT=1 re-enables it.
   static bool tail_split() {
     static const bool v = [] { const char* e = getenv("LRP_DEC_TAIL_SPLIT"); return e && atoi(e) != 0; }();
+    return v;
+  }
+  DevBuf sg_ws;                                        // K-split partials of the forward's matrix-core products
+  static constexpr size_t SG_WS_FLOATS = (size_t)4 << 20;
+  static bool mfma_forward() {
+    static const bool v = [] { const char* e = getenv("LRP_DEC_MFMA_FWD"); return !e || atoi(e) != 0; }();
     return v;
   }
   static bool batched_scan() {            // LRP_DEC_BATCHED=0: one workgroup per unit (dec_explain_adaptive_kernel)

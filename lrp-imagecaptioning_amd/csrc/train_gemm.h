@@ -28,6 +28,7 @@ struct SgemmArgs {
   int gather, gH, gW, dy, dx;   // transA only: row r = (n*gH + y)*gW + x reads row r + dy*gW + dx, zero outside the image
   int taps; long tapC;          // gather with taps = 9: blockIdx.z / ksplit = tap (dy, dx from it), C advances by tapC per tap
   int vecA, vecB;          // 16 B loads allowed (alignment checked on the host)
+  const float* bias;       // optional: + bias[n] on the final result (not with accumulate)
 };
 
 constexpr int SG_BK = 16;
@@ -173,7 +174,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
         const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
         if (col < a.N) {
           float* p = C + (long)row * ldc + col;
-          *p = accum ? *p + acc[i][j][r] : acc[i][j][r];
+          const float v = acc[i][j][r] + ((a.bias && !partial) ? a.bias[col] : 0.f);
+          *p = accum ? *p + v : v;
         }
       }
     }
@@ -182,13 +184,15 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
 
 // C[tap][m][n] (+)= sum_s ws[tap][s][m][n], slices added in index order
 __global__ __launch_bounds__(256) void sgemm_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int M, int N,
-                                                           long ldc, int ksplit, int accumulate, int taps, long tapC) {
+                                                           long ldc, int ksplit, int accumulate, int taps, long tapC,
+                                                           const float* __restrict__ bias) {
   const size_t mn = (size_t)M * N, all = mn * taps;
   for (size_t j = (size_t)blockIdx.x * 256 + threadIdx.x; j < all; j += (size_t)gridDim.x * 256) {
     const size_t tap = j / mn, i = j - tap * mn;
     const float* w = ws + tap * ksplit * mn + i;
     float s = 0.f;
     for (int k = 0; k < ksplit; ++k) s += w[(size_t)k * mn];
+    if (bias) s += bias[i % N];
     float* p = C + tap * tapC + (long)(i / N) * ldc + (i % N);
     *p = accumulate ? *p + s : s;
   }
@@ -249,7 +253,7 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
     const size_t mn = (size_t)a.M * a.N * taps;
     const unsigned blocks = (unsigned)((mn + 255) / 256 < 4096 ? (mn + 255) / 256 : 4096);
     hipLaunchKernelGGL(sgemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, ws, a.C, a.M, a.N, a.ldc, ks, a.accumulate, taps,
-                       a.tapC);
+                       a.tapC, a.bias);
     e = hipGetLastError();
   }
   return e;
