@@ -10,12 +10,22 @@ Multi-GPU: one process per GPU, frozen weights broadcast from rank 0 over RCCL,
 images sharded per rank, no data-path collective (weak scaling).
 
 Prints ONE json line (rank 0).  See DESIGN.md §measurement for the roofline terms.
+
+The line is self-certifying (N = 1): besides the timed default mode (split-bf16 reverse walk) the same invocation
+  * times the exact-fp32 mode on the same batch              -> "fp32_mode"  {value, ms_per_step, roofline}
+  * checks sampled heat-maps of the timed batch, in both modes, against the CPU oracle
+    (outside the timed region)                               -> "parity"     {bf16x3, fp32: worst relative L1}
+  * measures the fabric traffic of the dominant kernel live: two `rocprofv3 --pmc` child passes of this same
+    script (FETCH_SIZE, WRITE_SIZE; started BEFORE this process touches the GPU) -> roofline.traffic
 """
 import argparse
 import json
 import os
 import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -65,6 +75,104 @@ def cpu_baseline(w, V, T, sample_tokens):
                       % (sample_tokens, T, t_tok, t_fwd)}
 
 
+PARITY_SAMPLES = [(0, 1), (0, 10), (31, 10), (13, 5)]        # (image, t) of the timed batch checked against the oracle
+
+
+def algorithmic_bytes_per_walk(n_tokens, n_images):
+    """SURVEY 8d / DESIGN 4.1: per reverse-walk launch S_in (n x H x W x Cout) + S_out (n x H' x W' x Cin) once each, and
+    the gate of every DISTINCT image once (B x H' x W' x Cin; the tokens of an image share it) — 4 B per element (split8
+    operands are the same bytes as fp32).  Returns (total bytes of the 13 launches, launches)."""
+    from lrp_imagecaptioning_amd.synthetic import VGG16_CFG
+    res, r = [], 224
+    for _, cin, cout, pool in VGG16_CFG:
+        res.append(r)
+        r = r // 2 if pool else r
+    tot = 0
+    for li, (_, cin, cout, _) in enumerate(VGG16_CFG):
+        s_in = n_tokens * res[li] ** 2 * cout * 4
+        r_out = res[li - 1] if li else res[0]              # resolution of the layer's input (2x when a pool sits between)
+        s_out = n_tokens * r_out ** 2 * cin * 4
+        gate = n_images * r_out ** 2 * cin * 4             # (image layer: the image itself)
+        tot += s_in + s_out + gate
+    return tot, len(VGG16_CFG)
+
+
+def oracle_heatmaps(w, X, caps, samples):
+    """Float64 oracle (oracle/: decoder pinned by the reference's own outputs, CNN = literal iNNvestigate graph) for
+    the sampled (image, t) pairs of the timed batch: {(b, t): (224, 224, 3) relevance}."""
+    from lrp_imagecaptioning_amd.synthetic import VGG16_CFG
+    from oracle import cnn_lrp_ref as C
+    from oracle.decoder_ref import AdaptiveOracle
+    layers = C.vgg_layers(w, VGG16_CFG)
+    refs, dec = {}, {}
+    for (b, t) in samples:
+        if b not in dec:
+            feat = C.forward(layers, X[b:b + 1]).astype(np.float32)
+            dec[b] = AdaptiveOracle(w, 196, 512, 512, 512)
+            dec[b].forward(feat, caps[b])
+        R, _ = dec[b].explain(t)
+        refs[(b, t)] = C.analyze(layers, X[b:b + 1], R)[0]
+    return refs
+
+
+def rel_l1(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).sum() / np.abs(b).sum())
+
+
+WALK_KERNEL_RE = re.compile(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>")
+
+
+def is_walk_kernel(name, split):
+    """reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5) / fused image layer (6) in the walk's arithmetic"""
+    m = WALK_KERNEL_RE.search(name)
+    return bool(m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == ("1" if split else "0"))
+
+
+def live_pmc_traffic(args):
+    """HBM/fabric bytes per reverse-walk launch, measured in THIS run: two rocprofv3 child passes (FETCH_SIZE and
+    WRITE_SIZE need separate passes: TCC has 4 counter slots, MI355X_MICROARCH.md) of `bench.py --child` = one step of
+    the same workload.  FETCH_SIZE is doubled (gfx950 tallies the 128 B requests of 16 B/lane streams at 64 B).  Must
+    run before this process initialises the GPU (children only; nothing here is exec'ed over a GPU process)."""
+    import csv
+    import glob
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not found"
+    tot = {}
+    n = {}
+    tmp = tempfile.mkdtemp(prefix="lrp_pmc_")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--",
+                   sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0",
+                   "--batch", str(args.batch), "--tokens", str(args.tokens), "--vocab", str(args.vocab),
+                   "--precision", args.precision, "--handles", str(args.handles)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+            seen = set()
+            tot[ctr] = 0.0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == ctr and is_walk_kernel(row["Kernel_Name"], args.precision != "fp32"):
+                    tot[ctr] += float(row["Counter_Value"])
+                    seen.add(row["Dispatch_Id"])
+            n[ctr] = len(seen)
+            if not n[ctr]:
+                return None, "no reverse-walk dispatches in the %s pass" % ctr
+    except Exception as e:                                     # (a profiler that cannot run must not cost the bench line)
+        return None, "live PMC passes failed: %s" % e
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch = 2.0 * tot["FETCH_SIZE"] * 1024 / n["FETCH_SIZE"]
+    write = tot["WRITE_SIZE"] * 1024 / n["WRITE_SIZE"]
+    return {"bytes": int(fetch + write), "fetch_x2": int(fetch), "write": int(write), "launches": n["FETCH_SIZE"]}, \
+        "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this invocation (one step each)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,14 +190,23 @@ def main():
                          "HIP streams (pipeline.py); 1 = strictly one step after the other")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                         "the N>1 control path with several ranks on one GPU)")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the exact-fp32 block of the line")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of sampled heat-maps")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 traffic passes (use the committed summary)")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)    # one plain step under rocprofv3 (live_pmc_traffic)
     args = ap.parse_args()
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    extras = world == 1 and not args.child                  # the self-certifying blocks: rank 0 of a one-GPU run only
+    live_traffic, live_src = (None, None)
+    if extras and not args.no_pmc:
+        live_traffic, live_src = live_pmc_traffic(args)     # children first: this process has not touched the GPU yet
+
+    import torch
     local = local % max(torch.cuda.device_count(), 1)      # (rehearsal: more ranks than GPUs share a device)
     torch.cuda.set_device(local)
     dist = None
@@ -120,66 +237,110 @@ def main():
     # this rank's shard of the global batch (global batch = world * B images)
     lo, hi = shard_range(world * B, world, rank)
     rs = np.random.RandomState(1000 + rank)
-    X = torch.as_tensor(images(rs, hi - lo)).cuda(local)
+    X_host = images(rs, hi - lo)
+    X = torch.as_tensor(X_host).cuda(local)
     caps = captions(rs, hi - lo, T, V)
     img_idx = [b for b in range(B) for _ in range(T)]
     tpos = [t for _ in range(B) for t in range(1, T + 1)]
     outs = [torch.empty((B * T, 224, 224, 3), dtype=torch.float32, device=X.device) for _ in pipe.engines]
-    out = outs[0]
 
     def step():
         # one pass of the hot path over one batch; consecutive steps go to alternating handles / streams
         pipe.explain_batch(X, caps, img_idx, tpos, out=outs[pipe.next_slot])
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=X.device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    def timed_run(n_warm, n_steps):
+        """W untimed + exactly K timed steps, barrier + device synchronise on both sides, MAX over ranks."""
+        for _ in range(n_warm):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=X.device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        assert all(bool(torch.isfinite(o).all()) for o in outs)
+        return dt
 
-    # dominant kernel, measured live with HIP events on the launch stream (outside the timed region, nothing else in flight)
-    pipe.reset()
-    eng.profile_enable(True)
-    step()
-    torch.cuda.synchronize()
-    n_launch, ms, flop = eng.profile_query()
-    eng.profile_enable(False)
-    achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    def dominant_kernel():
+        """reverse-walk launches of ONE step, HIP events on the launch stream (untimed, nothing else in flight)"""
+        pipe.reset()
+        eng.profile_enable(True)
+        step()
+        torch.cuda.synchronize()
+        n_launch, ms, flop = eng.profile_query()
+        eng.profile_enable(False)
+        return n_launch, ms, flop
 
-    split = args.precision != "fp32"
-    traffic, traffic_src = pmc_traffic_per_launch("bf16x3" if split else "fp32")
-    if rank == 0:
-        heatmaps = world * B * T * args.steps
+    def roofline_block(precision, n_launch, ms, flop, traffic, traffic_src):
+        split = precision != "fp32"
+        achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         if split:
-            peak, dtype = PEAK_BF16_MFMA_TFLOPS, "bf16x3"
+            peak = PEAK_BF16_MFMA_TFLOPS
             kname = ("conv_igemm_kernel<..., PREC_BF16X3> (conv-LRP alpha1beta0 backward, 13 launches/step; every fp32 "
                      "product = 3 bf16 MFMAs hi*hi+hi*lo+lo*hi, fp32 accumulate; forward/decoder stay fp32/fp64)")
         else:
-            peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
+            peak = PEAK_F32_MFMA_TFLOPS
             kname = "conv_igemm_kernel<..., PREC_FP32> (conv-LRP alpha1beta0 backward, 13 launches/step)"
+        abytes, alaunch = algorithmic_bytes_per_walk(B * T, B)
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM+MALL bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                 "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
-                "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2)}
+                "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2),
+                "algorithmic_bytes_per_launch": int(abytes / alaunch),
+                "traffic_over_algorithmic_bytes": round(traffic / (abytes / alaunch), 3) if traffic else None}
         if split:
             roof["mfma_flop_per_algorithmic_flop"] = 3
             roof["issued_mfma_frac"] = round(3 * achieved / peak, 4)
             roof["vs_fp32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 3)
+        return roof
+
+    def sampled(precision):
+        """the sampled heat-maps of the timed batch as the last step on handle 0 left them"""
+        return {(b, t): outs[0][b * T + t - 1].cpu().numpy() for (b, t) in PARITY_SAMPLES if b < B and t <= T}
+
+    # ---- the timed region (default arithmetic)
+    dt = timed_run(args.warmup, args.steps)
+    if args.child:
+        return
+    n_launch, ms, flop = dominant_kernel()
+    got = {args.precision: sampled(args.precision)} if extras and not args.no_parity else {}
+
+    # ---- the same batch in exact-fp32 arithmetic (the reference's: TF float32 / numpy float64), same invocation
+    fp32_block = None
+    if extras and not args.no_fp32_mode and args.precision != "fp32":
+        pipe.reset()
+        pipe.set_precision("fp32")
+        k32 = max(2, min(args.steps, 10))
+        dt32 = timed_run(1, k32)
+        nl32, ms32, fl32 = dominant_kernel()
+        if not args.no_parity:
+            got["fp32"] = sampled("fp32")
+        fp32_block = {"value": round(B * T * k32 / dt32, 2), "unit": "heatmaps/s", "steps": k32, "warmup": 1,
+                      "ms_per_step": round(dt32 / k32 * 1e3, 3), "dtype": "f32",
+                      "roofline": roofline_block("fp32", nl32, ms32, fl32, *pmc_traffic_per_launch("fp32"))}
+        pipe.reset()
+        pipe.set_precision(args.precision)
+
+    if live_traffic:
+        traffic, traffic_src = live_traffic["bytes"], live_src
+    else:
+        traffic, traffic_src = pmc_traffic_per_launch("bf16x3" if args.precision != "fp32" else "fp32")
+        if traffic_src and live_src:
+            traffic_src += " (%s)" % live_src
+    if rank == 0:
+        heatmaps = world * B * T * args.steps
+        dtype = "f32" if args.precision == "fp32" else "bf16x3"
         res = {
             "metric": METRIC, "value": round(heatmaps / dt, 2), "unit": "heatmaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -192,10 +353,30 @@ def main():
                        "schedule": "consecutive steps alternate between the handles, each on its own HIP stream (one batch's "
                                    "decoder / encode phases run under the previous batch's reverse walk)"
                                    if len(pipe.engines) > 1 else "one step after the other on one stream"},
-            "roofline": roof,
+            "roofline": roofline_block(args.precision, n_launch, ms, flop, traffic, traffic_src),
         }
-        if not args.no_cpu_baseline and args.cpu_sample_tokens > 0 and world == 1:               # (rank 0 at N = 1 only: the other ranks would idle behind it)
-            res["cpu_baseline"] = cpu_baseline(w_host, V, T, args.cpu_sample_tokens)
+        if live_traffic:
+            res["roofline"]["traffic_detail"] = live_traffic
+        if fp32_block:
+            res["fp32_mode"] = fp32_block
+        if got:
+            # worst relative L1 (BASELINE: sum|R - R_ref| / sum|R_ref| on the raw (224,224,3) relevance, per token) of the
+            # sampled heat-maps of the TIMED batch against the float64 oracle; outside the timed region
+            t0 = time.time()
+            refs = oracle_heatmaps(w_host, X_host, caps, list(next(iter(got.values())).keys()))
+            par = {"metric": "max over samples of sum|R-R_ref|/sum|R_ref|", "tolerance": 1e-4,
+                   "samples": [list(k) for k in refs], "oracle": "oracle/decoder_ref.py + oracle/cnn_lrp_ref.py (float64)",
+                   "oracle_seconds": None}
+            for mode, maps in got.items():
+                par[mode] = max(rel_l1(maps[k], refs[k]) for k in refs)
+            par["oracle_seconds"] = round(time.time() - t0, 1)
+            par["ok"] = all(par[m] < par["tolerance"] for m in got)
+            res["parity"] = par
+        if not args.no_cpu_baseline and args.cpu_sample_tokens > 0:
+            if world == 1:                                       # (rank 0 at N = 1 only: the other ranks would idle behind it)
+                res["cpu_baseline"] = cpu_baseline(w_host, V, T, args.cpu_sample_tokens)
+            else:
+                res["cpu_baseline"] = None                       # reported by the N = 1 line
         print(json.dumps(res))
     if dist:
         dist.barrier()
@@ -203,9 +384,9 @@ def main():
 
 
 def pmc_traffic_per_launch(precision="bf16x3"):
-    """rocprofv3 cannot run inside this process: the per-launch fabric traffic of the reverse-walk
-    conv launches comes from the newest committed PMC summary (profiles/run_profile.sh: separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
+    """Fallback when the live rocprofv3 passes cannot run (no profiler, N > 1): the per-launch fabric traffic of the
+    reverse-walk conv launches from the newest committed PMC summary (profiles/run_profile.sh: separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
     import glob
     # the committed summaries are of the default-precision run; an fp32-mode profile would be r*_pmc_summary_fp32.json
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % ("" if precision == "bf16x3" else "_fp32"))))
@@ -214,13 +395,11 @@ def pmc_traffic_per_launch(precision="bf16x3"):
     d = json.load(open(files[-1]))
     tot = n = 0.0
     for k, v in d.items():
-        # reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5) / fused image layer (6)
-        m = re.search(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>", k)
-        if m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == ("1" if precision == "bf16x3" else "0"):
+        if is_walk_kernel(k, precision == "bf16x3"):
             if "fetch_bytes_per_launch_x2corr" in v and "write_bytes_per_launch" in v:
                 tot += (v["fetch_bytes_per_launch_x2corr"] + v["write_bytes_per_launch"]) * v["launches"]
                 n += v["launches"]
-    return (int(tot / n), os.path.relpath(files[-1], ROOT)) if n else (None, None)
+    return (int(tot / n), "committed: " + os.path.relpath(files[-1], ROOT)) if n else (None, None)
 
 
 def synth_weights_shapes(V):

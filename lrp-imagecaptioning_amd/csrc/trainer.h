@@ -186,6 +186,19 @@ struct Trainer {
   bool fwd_valid = false;
   int fwd_B = 0, fwd_T = 0;
   hipEvent_t ev_fwd = nullptr;
+  // An early forward is only valid for the features / weights it ran on.  lrp_encode_images, lrp_set_features and
+  // lrp_set_weight call this: a following lrp_train_step then runs its own forward (inline) instead of back-propagating
+  // through activations of the OLD batch, and — `st` given — the caller's stream first waits for the side-stream forward,
+  // which may still be reading the feature buffer the caller is about to overwrite.
+  int drop_early_forward(hipStream_t st) {
+    if (!fwd_valid) return LRP_OK;
+    fwd_valid = false;
+    if (ev_fwd) {
+      if (st) LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_fwd, 0));
+      else LRP_HIP_CHECK(hipEventSynchronize(ev_fwd));
+    }
+    return LRP_OK;
+  }
   int check_step(Encoder& enc, const StepIn& in) {
     if (!ready) return fail(LRP_ERR_STATE, "lrp_train_begin must run first");
     if (in.B < 1 || in.B > Bm || in.T < 2 || in.T > Tm)

@@ -370,3 +370,34 @@ def test_pipeline_two_handles_identical_to_one():
         one.decoder_forward(caps)
         want = one.explain_tokens(idx, tpos)[0]
         assert torch.equal(g, want)
+
+
+def test_explicit_device_and_allocation_failure_are_statuses():
+    """LRPEngine(device=k) is a public parameter: every ABI entry makes the handle's device current for the call and
+    restores the caller's (csrc/engine.hip with_handle); a workspace that cannot be allocated comes back as
+    LRP_ERR_NOMEM -> MemoryError, never as an abort, and leaves the process usable."""
+    import torch
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    w, rs = _weights(5)
+    kw = dict(decoder="adaptive", cnn_cfg=CFG, img_hw=(HW, HW), L=L, D=D, H=H, E=H, V=V, max_images=1, max_caption_len=5)
+    with pytest.raises(MemoryError):
+        LRPEngine(max_tokens=2 ** 31 - 1, **kw)               # 2^31 x (16 x 16 x 8) floats: hipMalloc must fail cleanly
+    eng = LRPEngine(max_tokens=4, device=0, **kw)
+    assert eng.device == torch.device("cuda", 0)
+    eng.set_weights(w)
+    X = rs.uniform(-120, 130, size=(1, HW, HW, 3)).astype(np.float32)
+    before = torch.cuda.current_device()
+    eng.encode_images(X)
+    eng.decoder_forward([[5, 9, 1]])
+    out = eng.explain_tokens([0, 0], [1, 2])[0]
+    assert torch.cuda.current_device() == before and bool(torch.isfinite(out).all())
+    if torch.cuda.device_count() > 1:                          # several GPUs in one process: the handle follows cfg.device
+        e1 = LRPEngine(max_tokens=4, device=1, **kw)
+        e1.set_weights(w)
+        with torch.cuda.device(1):
+            X1 = torch.as_tensor(X).cuda()
+        e1.encode_images(X1)                                   # current device stays 0 in this thread
+        e1.decoder_forward([[5, 9, 1]])
+        o1 = e1.explain_tokens([0, 0], [1, 2])[0]
+        assert o1.device.index == 1 and torch.equal(o1.cpu(), out.cpu())
+        assert torch.cuda.current_device() == before

@@ -1,0 +1,205 @@
+"""-m gpu: parity THROUGH THE ENGINE AT THE BENCHMARK CONFIGURATIONS (BASELINE.json configs[1], [3], [4] at one
+GPU's share) — the exact code path `bench.py` / `profiles/config4_bench.py` / `profiles/config5_bench.py` time:
+B = 32 images x 10 words = 320 heat-maps per call, two handles in flight, wide 256 x 256 halo-resident tiles chained
+layer to layer, `row2img` over 320 tokens, multi-GB walk tensors.
+
+Two kinds of check per configuration:
+  (a) sampled (image, token) heat-maps of the big batch against the CPU oracles (decoder oracle pinned by the
+      reference's own outputs; CNN oracle = literal float64 iNNvestigate graph), bar 1e-4 relative L1
+      (BASELINE.json / SURVEY 8d) — explain_image.py:45-56, E:183-189, AB:478-520;
+  (b) batch invariance: EVERY heat-map of the big batch against the same image explained alone (B = 1, n = 10 — the
+      small-tile kernels the other parity tests already pin), bar 1e-5 relative L1.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l1
+from gpu_util import report
+from lrp_imagecaptioning_amd.synthetic import (RESNET101_STACKS, VGG16_CFG, adaptive_weights, captions, gridtd_weights, images,
+                                               resnet_weights, vgg_weights)
+from oracle import cnn_lrp_ref as C
+from oracle import resnet_lrp_ref as RN
+from oracle.decoder_ref import AdaptiveOracle, GridTDOracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4          # BASELINE.json: relative L1 of the raw (224, 224, 3) relevance, per token
+TOL_BATCH = 1e-5    # big batch vs the same image alone
+B, T, V = 32, 10, 10000
+
+
+def _gpu_rel_l1(a, b):
+    """per-heat-map sum|a-b| / sum|b| on the device (a, b: (n, H, W, 3))."""
+    num = (a.double() - b.double()).abs().flatten(1).sum(1)
+    den = b.double().abs().flatten(1).sum(1)
+    return (num / den).cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]
+@pytest.fixture(scope="module")
+def config1():
+    """bench.py's own workload: synth_weights(0, V), images / captions from RandomState(1000 + rank); a second batch for
+    the second handle; oracle heat-maps for a handful of (batch, image, t) samples."""
+    import bench
+    w = bench.synth_weights(0, V)
+    batches = []
+    for seed in (1000, 2000):
+        rs = np.random.RandomState(seed)
+        batches.append((images(rs, B), captions(rs, B, T, V)))
+    samples = [(0, 0, 1), (0, 0, 10), (0, 31, 10), (0, 13, 5), (1, 31, 1), (1, 7, 10)]
+    layers = C.vgg_layers(w, VGG16_CFG)
+    refs = {}
+    cache = {}
+    for (k, b, t) in samples:
+        X, caps = batches[k]
+        if (k, b) not in cache:
+            feat = C.forward(layers, X[b:b + 1]).astype(np.float32)
+            o = AdaptiveOracle(w, 196, 512, 512, 512)
+            o.forward(feat, caps[b])
+            cache[(k, b)] = o
+        Rf, _ = cache[(k, b)].explain(t)
+        refs[(k, b, t)] = C.analyze(layers, X[b:b + 1], Rf)[0]
+    return w, batches, refs
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "fp32"])
+def test_config1_b32_two_handles_matches_oracle_and_small_batch(config1, prec):
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    from lrp_imagecaptioning_amd.pipeline import LRPPipeline
+    w, batches, refs = config1
+    pipe = LRPPipeline(2, decoder="adaptive", V=V, max_images=B, max_tokens=B * T, max_caption_len=T + 1)
+    pipe.set_precision(prec)
+    pipe.set_weights(w)
+    idx = [b for b in range(B) for _ in range(T)]
+    tpos = [t for _ in range(B) for t in range(1, T + 1)]
+    Xd = [torch.as_tensor(X).cuda() for X, _ in batches]
+    outs = [torch.empty((B * T, 224, 224, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    # exactly bench.py's step(): consecutive batches on alternating handles / streams, both in flight together
+    for rep in range(2):                                  # second round: the caches of round one are overwritten in flight
+        for k in range(2):
+            assert pipe.next_slot == k
+            pipe.explain_batch(Xd[k], batches[k][1], idx, tpos, out=outs[k])
+    pipe.synchronize()
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    # (a) sampled heat-maps vs the oracle
+    errs = {}
+    for (k, b, t), ref in refs.items():
+        errs[(k, b, t)] = rel_l1(outs[k][b * T + t - 1].cpu().numpy(), ref)
+    report("config1_b32_oracle_" + prec, max_rel_l1=max(errs.values()), samples=len(errs))
+    assert max(errs.values()) < TOL, errs
+    # (b) every heat-map vs its image explained alone on a B = 1 handle (small-tile kernels)
+    solo = LRPEngine(decoder="adaptive", V=V, max_images=1, max_tokens=T, max_caption_len=T + 1)
+    solo.set_precision(prec)
+    solo.set_weights(w)
+    worst = 0.0
+    for k in range(2):
+        for b in range(B):
+            solo.encode_images(Xd[k][b:b + 1])
+            solo.decoder_forward([batches[k][1][b]])
+            one = solo.explain_tokens([0] * T, list(range(1, T + 1)))[0]
+            worst = max(worst, float(_gpu_rel_l1(outs[k][b * T:(b + 1) * T], one).max()))
+    report("config1_b32_batch_invariance_" + prec, max_rel_l1=worst, heatmaps=2 * B * T)
+    assert worst < TOL_BATCH, worst
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]
+@pytest.mark.parametrize("prec", ["bf16x3"])
+def test_config4_resnet101_gridtd_b32_matches_oracle_and_small_batch(prec):
+    """grid-TD + ResNet-101, 32 images x 10 words per GPU (batch = 128 on 4 GPUs), as profiles/config4_bench.py runs it."""
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    rs = np.random.RandomState(0)
+    w = resnet_weights(rs)
+    w.update(gridtd_weights(rs, 49, 2048, 512, 512, V))
+    X = images(rs, B)
+    caps = captions(rs, B, T, V)
+    kw = dict(decoder="gridtd", img_hw=(224, 224), L=49, D=2048, H=512, E=512, V=V, max_caption_len=T + 1,
+              resnet={"stem": 64, "stacks": RESNET101_STACKS})
+    eng = LRPEngine(max_images=B, max_tokens=B * T, **kw)
+    eng.set_precision(prec)
+    eng.set_weights(w)
+    idx = [b for b in range(B) for _ in range(T)]
+    tpos = [t for _ in range(B) for t in range(1, T + 1)]
+    Xd = torch.as_tensor(X).cuda()
+    eng.encode_images(Xd)
+    eng.decoder_forward(caps)
+    out = eng.explain_tokens(idx, tpos)[0]
+    assert bool(torch.isfinite(out).all())
+    # (a) sampled heat-maps vs the float64 literal graph walk + the grid-TD oracle
+    spec = RN.resnet_spec()
+    errs = {}
+    for (b, t) in [(0, 1), (31, 10), (17, 6)]:
+        feat = RN.forward(w, spec, X[b:b + 1]).astype(np.float32)
+        o = GridTDOracle(w, 49, 2048, 512, 512)
+        o.forward(feat, caps[b])
+        Rf, _ = o.explain(t)
+        ref = RN.analyze(w, spec, X[b:b + 1], Rf.reshape(1, 7, 7, 2048))[0]
+        errs[(b, t)] = rel_l1(out[b * T + t - 1].cpu().numpy(), ref)
+    report("config4_b32_oracle_" + prec, max_rel_l1=max(errs.values()), samples=len(errs))
+    assert max(errs.values()) < TOL, errs
+    # (b) batch invariance
+    solo = LRPEngine(max_images=1, max_tokens=T, **kw)
+    solo.set_precision(prec)
+    solo.set_weights(w)
+    worst = 0.0
+    for b in range(B):
+        solo.encode_images(Xd[b:b + 1])
+        solo.decoder_forward([caps[b]])
+        one = solo.explain_tokens([0] * T, list(range(1, T + 1)))[0]
+        worst = max(worst, float(_gpu_rel_l1(out[b * T:(b + 1) * T], one).max()))
+    report("config4_b32_batch_invariance_" + prec, max_rel_l1=worst, heatmaps=B * T)
+    assert worst < TOL_BATCH, worst
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+def test_config5_lrp_weight_b8_t21_matches_reference_loop_and_small_batch():
+    """The `lrp_weight` tensor of the LRP-inference fine-tune step (M:1641-1691) at config 5's per-GPU size: 8 images,
+    T = 21, every word of every predicted caption explained (<= 168 heat-maps in one explain call): sampled entries vs
+    the reference loop on the oracles, all entries vs the images handled alone."""
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention
+    from lrp_imagecaptioning_amd.lrp_inference import LRPInferenceLayerAdaptive
+    from lrp_imagecaptioning_amd.postprocess import lrp_inference_score
+    Bc, Tc = 8, 21
+    rs = np.random.RandomState(0)
+    w = vgg_weights(rs)
+    w.update(adaptive_weights(rs, 196, 512, 512, 512, V))
+    spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512, vocab_size=V)
+    ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=Tc - 1, max_images=Bc)
+    layer = LRPInferenceLayerAdaptive(ex, "mean")
+    rs = np.random.RandomState(100)
+    X = images(rs, Bc)
+    y = rs.standard_normal((Bc, Tc, V)).astype(np.float32)
+    y[2, 7, 0] = 50.0                                       # image 2 predicts EOS at position 7
+    Xd, yd = torch.as_tensor(X).cuda(), torch.as_tensor(y).cuda()
+    lw = layer.call_device(Xd, yd).clone()
+    assert lw.shape == (Bc, Tc, V) and bool(torch.isfinite(lw).all())
+    words = np.argmax(y, axis=-1) + 1
+    n_maps = int((lw != 1).sum())
+    assert n_maps >= Bc * (Tc - 1) - Tc                     # (a score of exactly 0 is measure-zero)
+    assert bool((lw[2, 7:] == 1).all())                     # nothing at or after EOS
+    # (a) the reference loop (model.py:1657-1689) on the oracles for three entries
+    layers = C.vgg_layers(w, VGG16_CFG)
+    worst = 0.0
+    for (b, i) in [(0, 0), (7, 19), (2, 6)]:
+        cap = [int(c) for c in words[b]]
+        full = cap[:cap.index(1) + 1] if 1 in cap else cap[:Tc - 1] + [1]
+        feat = C.forward(layers, X[b:b + 1]).astype(np.float32)
+        o = AdaptiveOracle(w, 196, 512, 512, 512)
+        o.forward(feat, full)
+        rel = C.analyze(layers, X[b:b + 1], o.explain(i + 1)[0])
+        want = 1 + lrp_inference_score(rel, "mean")
+        got = float(lw[b, i, cap[i]])
+        worst = max(worst, abs(got - want) / abs(want - 1))
+    report("config5_lrp_weight_oracle", max_rel_err_of_score=worst)
+    assert worst < 2e-3, worst                              # (a score is a mean of +/- terms: looser than the map's L1 bar)
+    # (b) every image alone gives the same rows
+    ex1 = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=Tc - 1, max_images=1)
+    layer1 = LRPInferenceLayerAdaptive(ex1, "mean")
+    dmax = 0.0
+    for b in range(Bc):
+        one = layer1.call_device(Xd[b:b + 1], yd[b:b + 1])
+        m = lw[b:b + 1] != 1
+        assert bool(((one != 1) == m).all())
+        d = ((one[m] - lw[b:b + 1][m]).abs() / (lw[b:b + 1][m] - 1).abs()).max()
+        dmax = max(dmax, float(d))
+    report("config5_lrp_weight_batch_invariance", max_rel_err_of_score=dmax)
+    assert dmax < 1e-3, dmax

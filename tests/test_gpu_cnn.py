@@ -95,3 +95,49 @@ def test_state_errors():
         eng.set_weights({"c1_W": np.zeros((3, 3, 3, 9), np.float32)})
     with pytest.raises(NotImplementedError):
         LRPEngine(decoder="transformer")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_maxpool_exact_ties_follow_first_in_scan_order(prec):
+    """Known-answer case for the one semantics SURVEY 7 leaves 'believed equal': the routing of relevance through a
+    2x2 max-pool (RA:470-480 -> IL:138-157, tf.gradients of MaxPooling2D) when a window holds EXACT positive ties or
+    is all zero after the ReLU.  Small-integer images / weights / biases make every activation an exactly
+    representable integer in float64 (oracle), fp32 and split-bf16 alike, so the ties are the same ties on both
+    sides; the oracle routes to the first maximum in window scan order (torch max_pool2d == the rule the
+    restatement documents), the HIP path must agree element for element."""
+    cfg = [("c1", 3, 8, True), ("c2", 8, 8, True), ("c3", 8, 16, False)]
+    hw, Bn = 16, 2
+    rs = np.random.RandomState(42)
+    w = {}
+    for name, cin, cout, _ in cfg:
+        w[name + "_W"] = rs.randint(-1, 2, size=(3, 3, cin, cout)).astype(np.float32)
+        w[name + "_b"] = rs.randint(-2, 3, size=(cout,)).astype(np.float32)
+    X = rs.randint(-2, 3, size=(Bn, hw, hw, 3)).astype(np.float32)
+    X[1, :8] = 0.0                                              # a flat region: whole windows tie (or are all zero)
+    layers = C.vgg_layers(w, cfg)
+    eng, side = _engine(cfg, hw, Bn, 2 * Bn, w)
+    eng.set_precision(prec)
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(Bn, side, side, -1)
+    feat_ref = C.forward(layers, X)
+    assert np.array_equal(feat, feat_ref.astype(np.float32))   # integers: exact
+    n_tie = n_zero = 0
+    # the case really contains what it is meant to test: count tied / all-zero windows in front of every pool
+    inputs = C.forward(layers, X, return_inputs=True)[1]
+    for a in [C._nhwc(x).numpy() for L, x in zip(layers, inputs) if L[0] == "pool"]:      # (N, H, W, C), post-ReLU
+        win = a.reshape(a.shape[0], a.shape[1] // 2, 2, a.shape[2] // 2, 2, a.shape[3]).transpose(0, 1, 3, 5, 2, 4)
+        win = win.reshape(win.shape[:4] + (4,))
+        mx = win.max(-1, keepdims=True)
+        n_tie += int((((win == mx).sum(-1) > 1) & (mx[..., 0] > 0)).sum())
+        n_zero += int((mx[..., 0] == 0).sum())
+    assert n_tie > 50 and n_zero > 50, (n_tie, n_zero)
+    idx = [0, 1, 1, 0]
+    R = (rs.standard_normal((4,) + feat_ref.shape[1:]) * (feat_ref[idx] + 1.0)).astype(np.float32)
+    out = eng.cnn_explain(idx, R).cpu().numpy()
+    ref = C.analyze(layers, X[idx], R)
+    errs = [rel_l1(out[i], ref[i]) for i in range(4)]
+    report("cnn_pool_ties_" + prec, max_rel_l1=max(errs), ties=n_tie, zero_windows=n_zero)
+    assert max(errs) < 1e-5, errs
+    # element for element: relevance lands on exactly the pixels the oracle routes it to
+    assert np.array_equal(out != 0, ref != 0)
+

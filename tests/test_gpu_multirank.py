@@ -1,0 +1,56 @@
+"""-m gpu: the N > 1 control path on the one GPU of the box — two ranks under `torch.distributed.run` sharing the card
+over `gloo` (the RCCL form of the same calls needs a multi-GPU node: the driver's scaling run).  What this pins: the
+launch contract of bench.py (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), the weight broadcast -> lrp_set_weight_dev
+path, image sharding, barrier + MAX-over-ranks timing, ONE JSON line from rank 0; and for the fine-tune step the
+gradient all-reduce leaving bit-identical master weights on every rank.
+
+The ranks are fresh child processes (subprocess): the pytest process, which has initialised the GPU, is never
+exec'ed over."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(script_args, extra_env=None, timeout=900):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, text=True)
+    assert r.returncode == 0, "rc %d\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    return r.stdout
+
+
+def test_bench_two_ranks_one_gpu_gloo():
+    out = _torchrun(["bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                       # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["heatmaps_per_step"] == 640           # 2 ranks x 32 images x 10 words
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["roofline"]["launches"] == 13 and d["roofline"]["achieved"] > 0
+    assert abs(d["value"] - 640 / d["ms_per_step"] * 1e3) / d["value"] < 1e-3
+
+
+def test_finetune_step_two_ranks_identical_weights():
+    out = _torchrun(["profiles/config5_bench.py"], {"BACKEND": "gloo", "B": "2", "T": "12"})
+    assert "weights identical on every rank" in out, out[-2000:]
+    assert "data parallel x2 (gloo)" in out

@@ -406,3 +406,33 @@ def test_early_forward_gives_identical_gradients():
     side.synchronize()
     g2, _ = eng.train_step(cap_in, y, lw, masks)              # different T: the early forward does not apply
     assert torch.equal(g2, g_ref)
+
+
+def test_early_forward_is_dropped_by_a_new_encode_or_weight():
+    """lrp_train_forward(batch 0) followed by lrp_encode_images(batch 1) — e.g. a loop whose explanation raised between
+    the two — must NOT let lrp_train_step(batch 1) back-propagate through batch 0's activations: same (B, T), new
+    images, the result has to be the fresh step's, bit for bit.  The same for lrp_set_features and lrp_set_weight."""
+    w, X, cap_in, y, lw, masks = _case(9)
+    rs = np.random.RandomState(77)
+    X1 = (rs.uniform(0, 255, size=X.shape) - 110).astype(np.float32) / 64
+    eng = _engine(w, len(X))
+    eng.train_begin()
+    eng.encode_images(X1)
+    g_ref, l_ref = eng.train_step(cap_in, y, lw, masks)
+    g_ref, l_ref = g_ref.clone(), l_ref.clone()
+    side = torch.cuda.Stream()
+    for how in ("encode", "features", "weight"):
+        eng.encode_images(X)                                   # the OLD batch ...
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            eng.train_forward(cap_in, masks)                   # ... gets an early forward on the side stream
+        if how == "encode":
+            eng.encode_images(X1)                              # new batch, same (B, T)
+        elif how == "features":
+            eng.set_features(eng.get_features().clone())       # drops the forward (the step itself needs a full encode)
+            eng.encode_images(X1)
+        else:
+            eng.set_weights({"c4_b": w["c4_b"]})               # same values: only the invalidation is under test
+            eng.encode_images(X1)
+        g, l = eng.train_step(cap_in, y, lw, masks)
+        assert torch.equal(g, g_ref) and torch.equal(l, l_ref), how
