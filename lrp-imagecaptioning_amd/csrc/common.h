@@ -60,6 +60,7 @@ struct DevBuf {
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) {
       p = nullptr;
+      (void)hipGetLastError();                         // clear the sticky error: the next launch check must not report this one
       return fail(LRP_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
     }
     bytes = n;
