@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 2
+#define LRP_ABI_VERSION 3
 
 enum {
   LRP_OK = 0,
@@ -103,7 +103,10 @@ int lrp_destroy(lrp_handle* h);
  * "lang_b","W_va","W_ha","W_a","W_x","W_h","W_s". */
 int lrp_set_weight(lrp_handle* h, const char* name, const float* data_host,
                    int32_t ndim, const int64_t* shape);
-/* Same, from device memory on rank-local HBM (used after an RCCL broadcast). */
+/* Same, from device memory on rank-local HBM (used after an RCCL broadcast).  ABI v3: packed by device kernels — a
+ * device-to-device copy of the array plus the pack / split kernels on `stream`; no host round trip and no stream
+ * synchronisation (only ResNet encoder units, whose conv + BatchNorm folding is a host packer, are staged through
+ * the host).  Host-set and device-set weights may be mixed; the last setter of a name wins. */
 int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev,
                        int32_t ndim, const int64_t* shape, void* stream);
 
@@ -176,6 +179,13 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host,
 int lrp_decoder_gen_begin(lrp_handle* h, int32_t B, void* stream);
 int lrp_decoder_gen_step(lrp_handle* h, int32_t B, const int32_t* parent_host, const int32_t* word_host, int32_t step,
                          double* logits_dev, void* stream);
+/* ABI v3.  The ranking step of the search on the device: `_log_softmax` (explainers.py:45-48) followed by
+ * `np.argpartition(preds, -beam_size)[:, -beam_size:]` (explainers.py:76-78; inference.py:205-214) for `rows` rows of
+ * un-normalised scores — only k (id, log p) pairs per hypothesis cross PCIe per search step, not the (beams, V) logits.
+ * logits_dev (rows, V) float64; ids_dev (rows, k) int32 = model columns (tokenizer id - 1) by descending probability,
+ * ties to the lower column; logp_dev (rows, k) float64.  1 <= k <= min(V, 32). */
+int lrp_op_log_softmax_topk(const double* logits_dev, int32_t rows, int32_t V, int32_t k, int32_t* ids_dev,
+                            double* logp_dev, void* stream);
 
 /* ---- gradient baselines on the same caches -------------------------------------------------
  * lrp_decoder_gradient == ExplainImgCaptioning{AdaptiveAttention,GridTD}Gradient._lstm_decoder_backward(t)

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrp_hip.so")
 
-LRP_ABI_VERSION = 2
+LRP_ABI_VERSION = 3
 LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANGE, LRP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
 LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
@@ -56,6 +56,7 @@ SYMBOLS = {
     "lrp_op_add_lrp": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
     "lrp_decoder_gen_begin": (C.c_int, [_P, C.c_int32, _P]),
     "lrp_decoder_gen_step": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P]),
+    "lrp_op_log_softmax_topk": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "lrp_decoder_gradient": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "lrp_cnn_walk": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P]),
     "lrp_op_avgpool_lrp": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -164,6 +164,26 @@ __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restr
     dst[i] = (pos && !(v >= 0.f)) ? 0.f : v;
   }
 }
+// Device twin of the image-layer packers of Encoder::set_conv_weight (li == 0): w (3,3,3,cout) HWIO ->
+//   fwd  [.][64]  rows [0,cout): w against both halves of the im2col row (x+ patch | x- patch) = a_1;
+//                 rows [cout,2cout): w+ | w- = Z_1 (RR:256-260)
+//   bwd  [.][Kb]  row t*6+c = w+[t][c][:], row t*6+3+c = w-[t][c][:]   (tap-expanded channel reduction, conv_igemm.h)
+//   full [.][Kb]  row t*6+c = w[t][c][:]                               (gradient baselines)
+// One thread per (k = tap*3 + c, co); the buffers were zeroed at allocation, padding is never written.
+__global__ __launch_bounds__(256) void pack_image_layer_dev_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                                                   float* __restrict__ bwd, float* __restrict__ full, int cout, int Kb) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 27 * cout) return;
+  const int k = i / cout, co = i - k * cout, t = k / 3, c = k - 3 * t;
+  const float v = w[i], vp = v >= 0.f ? v : 0.f, vn = v < 0.f ? v : 0.f;
+  fwd[(size_t)co * 64 + k] = v;
+  fwd[(size_t)co * 64 + 32 + k] = v;
+  fwd[(size_t)(cout + co) * 64 + k] = vp;
+  fwd[(size_t)(cout + co) * 64 + 32 + k] = vn;
+  bwd[(size_t)(t * 6 + c) * Kb + co] = vp;
+  bwd[(size_t)(t * 6 + 3 + c) * Kb + co] = vn;
+  full[(size_t)(t * 6 + c) * Kb + co] = v;
+}
 // split8-packed [64][K] -> fragment-major copy for the weights-in-registers kernel (pack_frag64)
 __global__ __launch_bounds__(256) void pack_frag64_dev_kernel(const float* __restrict__ src, float* __restrict__ dst, int CP) {
   const int K = 9 * CP, cpt = CP / 32;

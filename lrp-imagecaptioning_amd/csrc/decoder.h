@@ -29,6 +29,9 @@ struct Decoder {
   int kind = 0, L = 0, D = 0, H = 0, E = 0, V = 0, Tm = 0, B_max = 0, NT_max = 0, sos = 2, eos = 1;
   std::map<std::string, std::vector<float>> raw;            // Keras-layout weights until finalize()
   std::map<std::string, std::vector<int64_t>> raw_shape;
+  // lrp_set_weight_dev: the Keras-layout matrices stay on the device (no host copy exists); once any weight arrived this
+  // way finalize() builds every operand copy with the device packers (repack_device) and uploads host-set stragglers
+  std::map<std::string, DevBuf> raw_dev;
   bool finalized = false;
   // packed device weights
   DevBuf w_if_dual, w_v, zero_bias, b_if, Wcat, bcat, Wg, Ws, vvec, Wglob, bglob, Wout, bout, emb, WgT, WglobT, WifT;
@@ -130,7 +133,7 @@ struct Decoder {
     return LRP_OK;
   }
 
-  int set_weight(const std::string& nm, const float* data, int ndim, const int64_t* shape, int64_t*) {
+  bool known_weight(const std::string& nm) const {
     static const char* adaptive_names[] = {"image_features_W", "image_features_b", "global_W", "global_b", "embedding",
                                            "lstm_Wi", "lstm_Wh", "lstm_b", "Wv", "Wg", "V", "Wx", "Wh", "Ws",
                                            "output_W", "output_b"};
@@ -140,16 +143,35 @@ struct Decoder {
     bool known = false;
     if (kind == LRP_DEC_ADAPTIVE) { for (const char* k : adaptive_names) known |= nm == k; }
     else { for (const char* k : gridtd_names) known |= nm == k; }
-    if (!known) return fail(LRP_ERR_INVALID, "unknown weight name '%s'", nm.c_str());
+    return known;
+  }
+  int weight_set_common(const std::string& nm, int ndim, const int64_t* shape, size_t* n_out) {
+    if (!known_weight(nm)) return fail(LRP_ERR_INVALID, "unknown weight name '%s'", nm.c_str());
     if (raw_stale)
       return fail(LRP_ERR_STATE, "the fine-tune step owns the weights of this handle (read them with lrp_train_get_master)");
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-    raw[nm].assign(data, data + n);
     raw_shape[nm].assign(shape, shape + ndim);
     finalized = false;
     bx_ready = false;                                  // the scan's / gradient path's weight packs are derived too
     grad_ready = false;
+    *n_out = n;
+    return LRP_OK;
+  }
+  int set_weight(const std::string& nm, const float* data, int ndim, const int64_t* shape, int64_t*) {
+    size_t n = 0;
+    LRP_TRY(weight_set_common(nm, ndim, shape, &n));
+    raw[nm].assign(data, data + n);
+    raw_dev.erase(nm);                                 // (a device copy of the old value, if any, is stale)
+    return LRP_OK;
+  }
+  int set_weight_dev(const std::string& nm, const float* data_dev, int ndim, const int64_t* shape, int64_t* total, hipStream_t st) {
+    size_t n = 0;
+    LRP_TRY(weight_set_common(nm, ndim, shape, &n));
+    DevBuf& d = raw_dev[nm];
+    if (d.bytes != n * sizeof(float)) LRP_TRY(d.alloc(n * sizeof(float), total));
+    LRP_HIP_CHECK(hipMemcpyAsync(d.p, data_dev, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    raw.erase(nm);
     return LRP_OK;
   }
 
@@ -164,11 +186,18 @@ struct Decoder {
   }
   int refresh_from_device(const std::function<const float*(const char*)>& Wd, hipStream_t st) {
     if (!finalized) return 1;
-    if (!raw_stale) {                                  // last moment the host copies are current: build every lazily made pack
+    if (!raw_stale) {                                  // last moment the set weights are current: build every lazily made pack
       int64_t dummy = 0;
-      LRP_TRY(bx_prepare(&dummy));
-      if (!((H | E | D) & 3)) LRP_TRY(grad_prepare(&dummy));
+      LRP_TRY(bx_prepare(&dummy, st));
+      if (!((H | E | D) & 3)) LRP_TRY(grad_prepare(&dummy, st));
     }
+    LRP_TRY(repack_device(Wd, st));
+    raw_stale = true;
+    return LRP_OK;
+  }
+  // every derived operand copy (those that exist: the scan / gradient packs only once prepared) from Keras-layout DEVICE
+  // matrices: strided D2D copies, tiled transposes, the split kernel.  Buffers must exist with zeroed padding.
+  int repack_device(const std::function<const float*(const char*)>& Wd, hipStream_t st) {
     const bool td = kind == LRP_DEC_GRIDTD;
     const float *Wif = Wd("image_features_W"), *Wgl = Wd("global_W");
     const int KD = conv_cinp(D), KH = conv_cinp(H), K4 = conv_cinp(4 * H);
@@ -228,7 +257,6 @@ struct Decoder {
       LRP_HIP_CHECK(cp2d(st, Wif, H, D, H, gWif.as<float>(), KH));
     }
     LRP_HIP_CHECK(hipGetLastError());
-    raw_stale = true;
     return LRP_OK;
   }
   bool raw_stale = false;                                // host copies in `raw` are older than the device operands
@@ -341,8 +369,63 @@ struct Decoder {
     return LRP_OK;
   }
 
-  int finalize(int64_t* total) {
+  // lrp_set_weight_dev path: shapes checked like the host path, operand buffers allocated zeroed, then repack_device
+  std::function<const float*(const char*)> raw_dev_lookup() {
+    return [this](const char* nm) -> const float* { return raw_dev.at(nm).as<float>(); };
+  }
+  static int zalloc(DevBuf& d, size_t floats, int64_t* total, hipStream_t st) {
+    LRP_TRY(d.alloc(floats * sizeof(float), total));
+    LRP_HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes, st));
+    return LRP_OK;
+  }
+  int finalize_device(int64_t* total, hipStream_t st) {
+    const bool td = kind == LRP_DEC_GRIDTD;
+    const int K1 = td ? H + 2 * E : 2 * E;              // input width of the (first) LSTM
+    LRP_TRY(need("image_features_W", {D, H})); LRP_TRY(need("image_features_b", {H}));
+    LRP_TRY(need("global_W", {D, E})); LRP_TRY(need("global_b", {E}));
+    LRP_TRY(need("embedding", {V, E})); LRP_TRY(need("output_W", {H, V})); LRP_TRY(need("output_b", {V}));
+    if (td) {
+      LRP_TRY(need("td_Wi", {K1, 4 * H})); LRP_TRY(need("td_Wh", {H, 4 * H})); LRP_TRY(need("td_b", {4 * H}));
+      LRP_TRY(need("lang_Wi", {2 * H, 4 * H})); LRP_TRY(need("lang_Wh", {H, 4 * H})); LRP_TRY(need("lang_b", {4 * H}));
+      LRP_TRY(need("W_va", {H, H})); LRP_TRY(need("W_ha", {H, H})); LRP_TRY(need("W_a", {H})); LRP_TRY(need("W_x", {K1, H}));
+      LRP_TRY(need("W_h", {H, H})); LRP_TRY(need("W_s", {H, H}));
+    } else {
+      LRP_TRY(need("lstm_Wi", {K1, 4 * H})); LRP_TRY(need("lstm_Wh", {H, 4 * H})); LRP_TRY(need("lstm_b", {4 * H}));
+      LRP_TRY(need("Wv", {H, H})); LRP_TRY(need("Wg", {H, H})); LRP_TRY(need("V", {H}));
+      LRP_TRY(need("Wx", {K1, H})); LRP_TRY(need("Wh", {H, H})); LRP_TRY(need("Ws", {H, H}));
+    }
+    for (auto& kv : raw) {                             // weights that were set from the host: one upload each
+      if (raw_dev.count(kv.first)) continue;
+      DevBuf& d = raw_dev[kv.first];
+      LRP_TRY(d.alloc(kv.second.size() * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpyAsync(d.p, kv.second.data(), kv.second.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    }
+    const size_t KD = conv_cinp(D), KH = conv_cinp(H);
+    LRP_TRY(zalloc(w_if_dual, (size_t)conv_npad(2 * H) * KD, total, st));
+    LRP_TRY(zalloc(w_v, (size_t)conv_npad(H) * KH, total, st));
+    LRP_TRY(zalloc(zero_bias, (size_t)std::max(H, E), total, st));
+    LRP_TRY(zalloc(b_if, H, total, st)); LRP_TRY(zalloc(Wglob, (size_t)D * E, total, st)); LRP_TRY(zalloc(bglob, E, total, st));
+    LRP_TRY(zalloc(Wout, (size_t)H * V, total, st)); LRP_TRY(zalloc(bout, V, total, st)); LRP_TRY(zalloc(emb, (size_t)V * E, total, st));
+    LRP_TRY(zalloc(WglobT, (size_t)E * D, total, st)); LRP_TRY(zalloc(WifT, (size_t)H * D, total, st));
+    LRP_TRY(zalloc(w_ifT_pk, (size_t)conv_npad(D) * KH, total, st)); LRP_TRY(zalloc(w_ifT_pks, (size_t)conv_npad(D) * KH, total, st));
+    LRP_TRY(zalloc(Wcat, (size_t)(K1 + H) * 5 * H, total, st)); LRP_TRY(zalloc(bcat, (size_t)5 * H, total, st));
+    LRP_TRY(zalloc(WgT, (size_t)H * (K1 + H), total, st));
+    if (td) {
+      LRP_TRY(zalloc(Wcat2, (size_t)3 * H * 4 * H, total, st)); LRP_TRY(zalloc(bcat2, (size_t)4 * H, total, st));
+      LRP_TRY(zalloc(Wg2T, (size_t)H * 3 * H, total, st));
+    }
+    LRP_TRY(zalloc(Wg, (size_t)H * H, total, st)); LRP_TRY(zalloc(Ws, (size_t)H * H, total, st)); LRP_TRY(zalloc(vvec, H, total, st));
+    finalized = true;
+    return repack_device(raw_dev_lookup(), st);
+  }
+  // (the scan / gradient-path packs in device mode: allocate zeroed, mark ready, let repack_device fill everything)
+  int pack_alloc_device(DevBuf& d, int rows, int K, int64_t* total, hipStream_t st) {
+    return zalloc(d, (size_t)conv_npad(rows) * conv_cinp(K), total, st);
+  }
+
+  int finalize(int64_t* total, hipStream_t st = nullptr) {
     if (finalized) return LRP_OK;
+    if (!raw_dev.empty()) return finalize_device(total, st);
     if (kind == LRP_DEC_GRIDTD) return finalize_gridtd(total);
     LRP_TRY(finalize_common("Wv", total));
     LRP_TRY(need("lstm_Wi", {2 * E, 4 * H})); LRP_TRY(need("lstm_Wh", {H, 4 * H})); LRP_TRY(need("lstm_b", {4 * H}));
@@ -376,7 +459,7 @@ struct Decoder {
   // _forward_beam_search for B images (E:370-436 / E:1092-1178)
   int forward(const float* feat_dev, const int32_t* caps, const int32_t* lens, int B, hipStream_t st) {
     int64_t dummy = 0;
-    LRP_TRY(finalize(&dummy));
+    LRP_TRY(finalize(&dummy, st));
     if (B > B_max) return fail(LRP_ERR_INVALID, "B=%d > max_images=%d", B, B_max);
     int Tmax = 0;
     for (int b = 0; b < B; ++b) {
@@ -503,7 +586,7 @@ struct Decoder {
   int gen_rows = 0;
   int gen_begin(const float* feat_dev, int B, hipStream_t st) {
     int64_t dummy = 0;
-    LRP_TRY(finalize(&dummy));
+    LRP_TRY(finalize(&dummy, st));
     if (B < 1 || B > B_max) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, B_max);
     if (!gen_pinned) {
       LRP_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&gen_pinned), (size_t)B_max * 2 * sizeof(int)));
@@ -616,7 +699,7 @@ struct Decoder {
     a.Tm = Tm; a.L = L; a.D = D; a.H = H; a.E = E; a.V = V;
     if (batched_scan() && (H & 3) == 0 && t_host) {
       int64_t dummy = 0;
-      LRP_TRY(bx_prepare(&dummy));
+      LRP_TRY(bx_prepare(&dummy, st));
       int t_max = 0;
       for (int i = 0; i < n; ++i) t_max = std::max(t_max, (int)t_host[i]);
       GbxArgs x{};
@@ -689,23 +772,35 @@ struct Decoder {
     }
     return upload(dst, pk, total);
   }
-  int grad_prepare(int64_t* total) {
+  int grad_prepare(int64_t* total, hipStream_t st = nullptr) {
     if (grad_ready) return LRP_OK;
     if ((H & 3) || (E & 3) || (D & 3)) return fail(LRP_ERR_UNSUPPORTED, "gradient path: H, E, D must be multiples of 4");
     const size_t NT = NT_max;
+    const bool dev = !raw_dev.empty();                 // weights live on the device: allocate here, repack_device fills
     if (kind == LRP_DEC_ADAPTIVE) {
-      LRP_TRY(pack_rows({{"lstm_Wh", H}, {"lstm_Wi", 2 * E}}, 4 * H, gW1, total));
+      if (dev) LRP_TRY(pack_alloc_device(gW1, H + 2 * E, 4 * H, total, st));
+      else LRP_TRY(pack_rows({{"lstm_Wh", H}, {"lstm_Wi", 2 * E}}, 4 * H, gW1, total));
       LRP_TRY(g_out1.alloc(NT * (H + 2 * E) * 4, total));
     } else {
-      LRP_TRY(pack_rows({{"td_Wh", H}, {"td_Wi", H + 2 * E}}, 4 * H, gW1, total));
-      LRP_TRY(pack_rows({{"lang_Wh", H}, {"lang_Wi", 2 * H}}, 4 * H, gW2, total));
+      if (dev) {
+        LRP_TRY(pack_alloc_device(gW1, 2 * H + 2 * E, 4 * H, total, st));
+        LRP_TRY(pack_alloc_device(gW2, 3 * H, 4 * H, total, st));
+      } else {
+        LRP_TRY(pack_rows({{"td_Wh", H}, {"td_Wi", H + 2 * E}}, 4 * H, gW1, total));
+        LRP_TRY(pack_rows({{"lang_Wh", H}, {"lang_Wi", 2 * H}}, 4 * H, gW2, total));
+      }
       LRP_TRY(g_out1.alloc(NT * (2 * H + 2 * E) * 4, total));
       LRP_TRY(g_out2.alloc(NT * 3 * H * 4, total));
       LRP_TRY(g_dc2.alloc(NT * H * 4, total));
       LRP_TRY(g_dctx.alloc(NT * Tm * H * 4, total));
     }
-    LRP_TRY(pack_rows({{"global_W", D}}, E, gWglob, total));
-    LRP_TRY(pack_rows({{"image_features_W", D}}, H, gWif, total));
+    if (dev) {
+      LRP_TRY(pack_alloc_device(gWglob, D, E, total, st));
+      LRP_TRY(pack_alloc_device(gWif, D, H, total, st));
+    } else {
+      LRP_TRY(pack_rows({{"global_W", D}}, E, gWglob, total));
+      LRP_TRY(pack_rows({{"image_features_W", D}}, H, gWif, total));
+    }
     LRP_TRY(g_seed.alloc(NT * H * 4, total));
     LRP_TRY(g_dc1.alloc(NT * H * 4, total));
     LRP_TRY(g_dg.alloc(NT * 4 * H * 4, total));
@@ -714,6 +809,7 @@ struct Decoder {
     LRP_TRY(g_davg.alloc(NT * D * 4, total));
     LRP_TRY(g_tailA.alloc(NT * L * H * 4, total));
     grad_ready = true;
+    if (dev && finalized) LRP_TRY(repack_device(raw_dev_lookup(), st));
     return LRP_OK;
   }
   // out[M][N] = in[M][K] . W^T   (W packed by pack_rows)
@@ -727,7 +823,7 @@ struct Decoder {
   // n units (img_dev[u], t_dev[u]); t_max = largest t among them.  dfeat_dev (n, L, D) fp32, rwords_dev (n, Tm) fp64 or null.
   int gradient(int n, const int* img_dev, const int* t_dev, int t_max, float* dfeat_dev, double* rwords_dev, int64_t* total,
                hipStream_t st) {
-    LRP_TRY(grad_prepare(total));
+    LRP_TRY(grad_prepare(total, st));
     const bool td = kind == LRP_DEC_GRIDTD;
     float* seed = g_seed.as<float>();
     double* dwords = rwords_dev ? rwords_dev : g_dwords.as<double>();
@@ -829,15 +925,22 @@ struct Decoder {
     const char* e = getenv("LRP_DEC_BATCHED");
     return !e || atoi(e) != 0;
   }
-  int bx_prepare(int64_t* total) {
+  int bx_prepare(int64_t* total, hipStream_t st = nullptr) {
     if (bx_ready) return LRP_OK;
     const size_t NT = NT_max;
+    const bool dev = !raw_dev.empty();
     if (kind == LRP_DEC_ADAPTIVE) {
-      LRP_TRY(pack_matrix(gate_g_block("lstm_Wi", "lstm_Wh", 2 * E), 2 * E + H, H, bxWg1, total));
+      if (dev) LRP_TRY(pack_alloc_device(bxWg1, 2 * E + H, H, total, st));
+      else LRP_TRY(pack_matrix(gate_g_block("lstm_Wi", "lstm_Wh", 2 * E), 2 * E + H, H, bxWg1, total));
       LRP_TRY(bx_acc32.alloc(NT * (2 * E + H) * 4, total));
     } else {
-      LRP_TRY(pack_matrix(gate_g_block("td_Wi", "td_Wh", H + 2 * E), 2 * H + 2 * E, H, bxWg1, total));
-      LRP_TRY(pack_matrix(gate_g_block("lang_Wi", "lang_Wh", 2 * H), 3 * H, H, bxWg2, total));
+      if (dev) {
+        LRP_TRY(pack_alloc_device(bxWg1, 2 * H + 2 * E, H, total, st));
+        LRP_TRY(pack_alloc_device(bxWg2, 3 * H, H, total, st));
+      } else {
+        LRP_TRY(pack_matrix(gate_g_block("td_Wi", "td_Wh", H + 2 * E), 2 * H + 2 * E, H, bxWg1, total));
+        LRP_TRY(pack_matrix(gate_g_block("lang_Wi", "lang_Wh", 2 * H), 3 * H, H, bxWg2, total));
+      }
       LRP_TRY(bx_acc32.alloc(NT * (size_t)std::max(2 * H + 2 * E, 3 * H) * 4, total));
       for (DevBuf& d : bx_g) LRP_TRY(d.alloc(NT * H * 8, total));
     }
@@ -846,6 +949,7 @@ struct Decoder {
     LRP_TRY(bx_rglob.alloc(NT * E * 8, total));
     LRP_TRY(bx_q32.alloc(NT * H * 4, total));
     bx_ready = true;
+    if (dev && finalized) LRP_TRY(repack_device(raw_dev_lookup(), st));
     return LRP_OK;
   }
 
@@ -871,7 +975,7 @@ struct Decoder {
     if (batched_scan() && (H & 3) == 0 && t_host) {
       // step-synchronous scan: per step one pointwise kernel, ONE GEMM over all units, one routing kernel
       int64_t dummy = 0;
-      LRP_TRY(bx_prepare(&dummy));
+      LRP_TRY(bx_prepare(&dummy, st));
       int t_max = 0;
       for (int i = 0; i < n; ++i) t_max = std::max(t_max, (int)t_host[i]);
       BxArgs x{};

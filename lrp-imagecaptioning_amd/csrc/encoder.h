@@ -34,6 +34,7 @@ struct ConvLayer {
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
   DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
   std::vector<float> raw_w, raw_b;   // host copies as set (HWIO / (cout,)): the fine-tune step's master weights start here
+  DevBuf raw_w_dev, raw_b_dev;       // the same when the weights arrived through lrp_set_weight_dev (no host copy exists then)
   DevBuf Akeep;    // fine-tune step only: a_l of the layers whose output is the next conv's input (no pool after); the
                    // LRP path turns that storage into the gate in place
   size_t act_elems() const { return (size_t)H * W * cout; }
@@ -178,6 +179,7 @@ struct Encoder {
     ConvLayer& L = layers[li];
     const size_t nW = (size_t)9 * L.cin * L.cout;
     if (w != L.raw_w.data()) L.raw_w.assign(w, w + nW);
+    L.raw_w_dev.release();
     std::vector<float> wp(nW), wn(nW);
     for (size_t i = 0; i < nW; ++i) { wp[i] = w[i] >= 0.f ? w[i] : 0.f; wn[i] = w[i] < 0.f ? w[i] : 0.f; }
     std::vector<float> pk;
@@ -270,11 +272,44 @@ struct Encoder {
     return LRP_OK;
   }
 
-  // Same operand copies as set_conv_weight, rebuilt in place from device weights (fine-tune step; li >= 1, buffers exist).
-  // tmp: scratch of at least conv_npad(cout) * 9 * conv_cinp(cin) floats.
-  int repack_conv_from_device(int li, const float* w_dev, const float* b_dev, float* tmp, hipStream_t st) {
+  // ---- operand copies built ON THE DEVICE from device weights: lrp_set_weight_dev (the multi-GPU start-up path: the
+  // bundle arrives over RCCL/xGMI and never visits the host) and the fine-tune step (weights change every iteration).
+  DevBuf pack_tmp;                                     // scratch of the device packers (largest forward matrix)
+  int alloc_conv_operands(int li, int64_t* total, hipStream_t st) {
     ConvLayer& L = layers[li];
-    if (li < 1 || !L.have_w || !L.have_b) return fail(LRP_ERR_STATE, "layer %d has no operand copies to rebuild", li);
+    auto mk = [&](DevBuf& d, size_t floats) -> int {
+      if (d.p && d.bytes == floats * sizeof(float)) return LRP_OK;
+      LRP_TRY(d.alloc(floats * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes, st));          // padding rows / columns stay zero
+      return LRP_OK;
+    };
+    if (li == 0) {
+      const size_t nb = (size_t)conv_npad(IMG_T_COLS) * conv_cinp(L.cout);
+      LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * 64));
+      LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb));
+      return LRP_OK;
+    }
+    const size_t Kf = (size_t)9 * conv_cinp(L.cin), Kb = (size_t)9 * conv_cinp(L.cout);
+    const size_t nf = (size_t)conv_npad(L.cout) * Kf, nb = (size_t)conv_npad(L.cin) * Kb;
+    LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf));
+    LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
+    LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb));
+    if (conv_npad(L.cin) == 64) LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb));
+    if (pack_tmp.bytes < nf * sizeof(float)) LRP_TRY(pack_tmp.alloc(nf * sizeof(float), total));
+    return LRP_OK;
+  }
+  // every operand copy of layer li from w_dev (HWIO, device); the buffers exist (set_conv_weight or alloc_conv_operands)
+  int repack_conv_weight_from_device(int li, const float* w_dev, float* tmp, hipStream_t st) {
+    ConvLayer& L = layers[li];
+    if (li == 0) {
+      const int Npb = conv_npad(IMG_T_COLS), Kb = conv_cinp(L.cout);
+      hipLaunchKernelGGL(pack_image_layer_dev_kernel, dim3((27 * L.cout + 255) / 256), dim3(256), 0, st, w_dev, L.w_fwd.as<float>(),
+                         L.w_bwd.as<float>(), L.w_bwd_full.as<float>(), L.cout, Kb);
+      const size_t nb = (size_t)Npb * Kb;
+      hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb / 8);
+      LRP_HIP_CHECK(hipGetLastError());
+      return LRP_OK;
+    }
     const int CPi = conv_cinp(L.cin), CPo = conv_cinp(L.cout);
     const int Np2 = conv_npad(2 * L.cout), Npa = conv_npad(L.cout), Npb = conv_npad(L.cin);
     auto pack = [&](float* dst, int bwd, int rows, int dual, int pos) {
@@ -299,14 +334,51 @@ struct Encoder {
                          L.w_bwd_frag.as<float>(), CPo);
     pack(L.w_bwd_full.as<float>(), 1, Npb, 0, 0);
     LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+  // fine-tune step: layer li (weights and bias) from the trainer's master buffer
+  int repack_conv_from_device(int li, const float* w_dev, const float* b_dev, float* tmp, hipStream_t st) {
+    ConvLayer& L = layers[li];
+    if (!L.have_w || !L.have_b) return fail(LRP_ERR_STATE, "layer %d has no operand copies to rebuild", li);
+    LRP_TRY(repack_conv_weight_from_device(li, w_dev, tmp, st));
     LRP_HIP_CHECK(hipMemcpyAsync(L.bias.p, b_dev, (size_t)L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     L.raw_w.clear(); L.raw_b.clear();               // stale from here on (the trainer's master buffer is the truth)
+    L.raw_w_dev.release(); L.raw_b_dev.release();
+    return LRP_OK;
+  }
+  // lrp_set_weight_dev: "<name>_W" / "<name>_b" from device memory — D2D copy, then the device packers; no host round trip
+  int set_conv_weight_dev(int li, const float* w_dev, int64_t* total, hipStream_t st) {
+    ConvLayer& L = layers[li];
+    const size_t nW = (size_t)9 * L.cin * L.cout;
+    if (gates_pending) {                               // the side stream may still read the operand copies we replace
+      LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));
+      gates_pending = false;
+    }
+    if (!L.raw_w_dev.p) LRP_TRY(L.raw_w_dev.alloc(nW * sizeof(float), total));
+    LRP_HIP_CHECK(hipMemcpyAsync(L.raw_w_dev.p, w_dev, nW * sizeof(float), hipMemcpyDeviceToDevice, st));
+    L.raw_w.clear();
+    LRP_TRY(alloc_conv_operands(li, total, st));
+    LRP_TRY(repack_conv_weight_from_device(li, L.raw_w_dev.as<float>(), pack_tmp.as<float>(), st));
+    L.have_w = true;
+    encoded = 0;                                       // caches belong to the old weights
+    return LRP_OK;
+  }
+  int set_conv_bias_dev(int li, const float* b_dev, int64_t* total, hipStream_t st) {
+    ConvLayer& L = layers[li];
+    if (!L.raw_b_dev.p) LRP_TRY(L.raw_b_dev.alloc((size_t)L.cout * sizeof(float), total));
+    if (!L.bias.p) LRP_TRY(L.bias.alloc((size_t)L.cout * sizeof(float), total));
+    LRP_HIP_CHECK(hipMemcpyAsync(L.raw_b_dev.p, b_dev, (size_t)L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    LRP_HIP_CHECK(hipMemcpyAsync(L.bias.p, b_dev, (size_t)L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    L.raw_b.clear();
+    L.have_b = true;
+    encoded = 0;
     return LRP_OK;
   }
 
   int set_conv_bias(int li, const float* b, int64_t* total) {
     ConvLayer& L = layers[li];
     if (b != L.raw_b.data()) L.raw_b.assign(b, b + L.cout);
+    L.raw_b_dev.release();
     LRP_TRY(L.bias.alloc((size_t)L.cout * sizeof(float), total));
     LRP_HIP_CHECK(hipMemcpy(L.bias.p, b, (size_t)L.cout * sizeof(float), hipMemcpyHostToDevice));
     L.have_b = true;

@@ -183,12 +183,36 @@ int lrp_set_weight(lrp_handle* h, const char* name, const float* data_host, int3
 int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev, int32_t ndim, const int64_t* shape,
                        void* stream) {
   return with_handle(h, [&]() -> int {
-    if (!h || !data_dev || !shape || ndim < 1 || ndim > 4) return fail(LRP_ERR_INVALID, "bad lrp_set_weight_dev arguments");
+    if (!h || !name || !data_dev || !shape || ndim < 1 || ndim > 4) return fail(LRP_ERR_INVALID, "bad lrp_set_weight_dev arguments");
+    LRP_TRY(h->trainer.drop_early_forward(nullptr));
+    const std::string nm(name);
+    hipStream_t st = S(stream);
+    // The multi-GPU start-up path: the bundle arrives in HBM over RCCL/xGMI and stays there — D2D copy of the Keras-layout
+    // array, then the device packers (cnn_kernels.h pack_*_dev, Decoder::repack_device) build every operand copy.  No
+    // device-to-host copy, no stream synchronisation.
+    if (!h->resnet) {
+      if (nm.size() > 2 && (nm.compare(nm.size() - 2, 2, "_W") == 0 || nm.compare(nm.size() - 2, 2, "_b") == 0)) {
+        const int li = h->enc.find_layer(nm.substr(0, nm.size() - 2));
+        if (li >= 0) {
+          const ConvLayer& L = h->enc.layers[li];
+          if (nm.back() == 'W') {
+            if (ndim != 4 || shape[0] != 3 || shape[1] != 3 || shape[2] != L.cin || shape[3] != L.cout)
+              return fail(LRP_ERR_INVALID, "%s: expected HWIO (3,3,%d,%d)", name, L.cin, L.cout);
+            return h->enc.set_conv_weight_dev(li, data_dev, &h->ws_bytes, st);
+          }
+          if (ndim != 1 || shape[0] != L.cout) return fail(LRP_ERR_INVALID, "%s: expected (%d,)", name, L.cout);
+          return h->enc.set_conv_bias_dev(li, data_dev, &h->ws_bytes, st);
+        }
+      }
+      return h->dec.set_weight_dev(nm, data_dev, ndim, shape, &h->ws_bytes, st);
+    }
+    if (h->dec.known_weight(nm)) return h->dec.set_weight_dev(nm, data_dev, ndim, shape, &h->ws_bytes, st);
+    // ResNet encoder units (conv + BatchNorm folding is a host packer): staged through the host, once per weight
     size_t n = 1;
     for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
     std::vector<float> host(n);
-    LRP_HIP_CHECK(hipMemcpyAsync(host.data(), data_dev, n * sizeof(float), hipMemcpyDeviceToHost, S(stream)));
-    LRP_HIP_CHECK(hipStreamSynchronize(S(stream)));
+    LRP_HIP_CHECK(hipMemcpyAsync(host.data(), data_dev, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    LRP_HIP_CHECK(hipStreamSynchronize(st));
     return set_weight_host(h, name, host.data(), ndim, shape);
   });
 }
@@ -632,6 +656,17 @@ int lrp_heatmap_scores(const float* R_img_dev, double* scores_dev, int32_t n, in
     if (n < 1 || npix < 1 || C < 1) return fail(LRP_ERR_INVALID, "n, npix, C must be positive");
     if (mode < 0 || mode > 2) return fail(LRP_ERR_UNSUPPORTED, "the lrp inference mode is not available");
     hipLaunchKernelGGL(heatmap_score_kernel, dim3(n), dim3(256), 0, S(stream), R_img_dev, scores_dev, npix, C, mode);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  });
+}
+
+int lrp_op_log_softmax_topk(const double* logits_dev, int32_t rows, int32_t V, int32_t k, int32_t* ids_dev, double* logp_dev,
+                            void* stream) {
+  return guarded([&]() -> int {
+    if (!logits_dev || !ids_dev || !logp_dev) return fail(LRP_ERR_INVALID, "null argument");
+    if (rows < 1 || V < 1 || k < 1 || k > V || k > TOPK_MAX) return fail(LRP_ERR_INVALID, "need rows >= 1 and 1 <= k <= min(V, %d)", TOPK_MAX);
+    hipLaunchKernelGGL(log_softmax_topk_kernel, dim3(rows), dim3(256), 0, S(stream), logits_dev, V, k, ids_dev, logp_dev);
     LRP_HIP_CHECK(hipGetLastError());
     return LRP_OK;
   });

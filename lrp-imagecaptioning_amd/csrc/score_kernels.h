@@ -181,4 +181,67 @@ __global__ __launch_bounds__(256) void preprocess_caffe_kernel(const unsigned ch
   }
 }
 
+// ---- caption generation: log-soft-max + top-k of one row of un-normalised scores per workgroup, so that a
+// beam-search step moves only k (id, log p) pairs per hypothesis over PCIe instead of the (beams, V) logits.
+// Reference: `_log_softmax` E:45-48 followed by `np.argpartition(preds, -beam_size)[:, -beam_size:]` E:76-78
+// (models/explainers.py) / inference.py:205-214.  logits (rows, V) float64 (what lrp_decoder_gen_step writes);
+// ids (rows, k) int32 = model columns (tokenizer id - 1, E:92) in descending order of probability, ties to the
+// lower column; logp (rows, k) float64 = x - max - log(sum(exp(x - max))).  HBM/L2-bound: k + 2 passes over 8 V bytes.
+constexpr int TOPK_MAX = 32;
+__global__ __launch_bounds__(256) void log_softmax_topk_kernel(const double* __restrict__ logits, int V, int k,
+                                                                int* __restrict__ ids, double* __restrict__ logp) {
+  __shared__ double red[256];
+  __shared__ int redi[256];
+  __shared__ int chosen[TOPK_MAX];
+  const int tid = threadIdx.x;
+  const double* x = logits + (size_t)blockIdx.x * V;
+  double m = -1.0 / 0.0;
+  for (int i = tid; i < V; i += 256) m = fmax(m, x[i]);
+  red[tid] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  double sum = 0.0;
+  for (int i = tid; i < V; i += 256) sum += exp(x[i] - m);
+  red[tid] = sum;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {                  // fixed tree: the same bits run to run
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double lse = log(red[0]);
+  __syncthreads();
+  for (int j = 0; j < k; ++j) {
+    double best = -1.0 / 0.0;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+      bool taken = false;
+      for (int q = 0; q < j; ++q) taken |= chosen[q] == i;
+      const double v = x[i];
+      if (!taken && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+    }
+    red[tid] = best;
+    redi[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double o = red[tid + s];
+        const int oi = redi[tid + s];
+        if (o > red[tid] || (o == red[tid] && oi < redi[tid])) { red[tid] = o; redi[tid] = oi; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      chosen[j] = redi[0];
+      ids[(size_t)blockIdx.x * k + j] = redi[0];
+      logp[(size_t)blockIdx.x * k + j] = red[0] - m - lse;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace lrp

@@ -102,24 +102,33 @@ struct Trainer {
     }
     add("output_W", {H, V}); add("output_b", {V});
     host.assign(n_total, 0.f);
+    // initial master weights: the host copies of lrp_set_weight, or — for weights that arrived through
+    // lrp_set_weight_dev — a device-to-device copy after the upload below
+    std::vector<std::pair<size_t, const DevBuf*>> from_dev;
+    auto take = [&](size_t pi, const std::vector<float>& hostv, const DevBuf* devv, const char* what) -> int {
+      if (hostv.size() == params[pi].n) std::copy(hostv.begin(), hostv.end(), host.begin() + params[pi].off);
+      else if (devv && devv->p && devv->bytes == params[pi].n * 4) from_dev.push_back({pi, devv});
+      else return fail(LRP_ERR_STATE, "weight '%s' is not set (or has the wrong size)", what);
+      return LRP_OK;
+    };
     size_t pi = 0;
     for (const ConvLayer& Ly : enc.layers) {
-      if (Ly.raw_w.size() != params[pi].n || Ly.raw_b.size() != params[pi + 1].n)
-        return fail(LRP_ERR_STATE, "encoder weights of '%s' are not set", Ly.name.c_str());
-      std::copy(Ly.raw_w.begin(), Ly.raw_w.end(), host.begin() + params[pi].off);
-      std::copy(Ly.raw_b.begin(), Ly.raw_b.end(), host.begin() + params[pi + 1].off);
+      LRP_TRY(take(pi, Ly.raw_w, &Ly.raw_w_dev, params[pi].name.c_str()));
+      LRP_TRY(take(pi + 1, Ly.raw_b, &Ly.raw_b_dev, params[pi + 1].name.c_str()));
       pi += 2;
     }
+    static const std::vector<float> none;
     for (; pi < params.size(); ++pi) {
       auto it = dec.raw.find(params[pi].name);
-      if (it == dec.raw.end() || it->second.size() != params[pi].n)
-        return fail(LRP_ERR_STATE, "decoder weight '%s' is not set (or has the wrong size)", params[pi].name.c_str());
-      std::copy(it->second.begin(), it->second.end(), host.begin() + params[pi].off);
+      auto jt = dec.raw_dev.find(params[pi].name);
+      LRP_TRY(take(pi, it != dec.raw.end() ? it->second : none, jt != dec.raw_dev.end() ? &jt->second : nullptr, params[pi].name.c_str()));
     }
     if (host_pinned) { (void)hipHostFree(host_pinned); host_pinned = nullptr; }
     if (hipHostMalloc(reinterpret_cast<void**>(&host_pinned), n_total * 4) != hipSuccess) return fail(LRP_ERR_NOMEM, "hipHostMalloc failed");
     LRP_TRY(master.alloc(n_total * 4, total)); LRP_TRY(mom.alloc(n_total * 4, total)); LRP_TRY(vel.alloc(n_total * 4, total));
     LRP_HIP_CHECK(hipMemcpy(master.p, host.data(), n_total * 4, hipMemcpyHostToDevice));
+    for (auto& fd : from_dev)
+      LRP_HIP_CHECK(hipMemcpy(master.as<float>() + params[fd.first].off, fd.second->p, params[fd.first].n * 4, hipMemcpyDeviceToDevice));
     LRP_HIP_CHECK(hipMemset(mom.p, 0, n_total * 4));
     LRP_HIP_CHECK(hipMemset(vel.p, 0, n_total * 4));
     lr = lr_; clip = clip_; b1 = b1_; b2 = b2_; eps = eps_; iter = 0;
@@ -590,30 +599,27 @@ struct Trainer {
     return sync_engine(enc, dec, total, st);
   }
 
-  // Operand copies are rebuilt on the device: the encoder's by cnn_kernels.h pack_*_dev, the decoder's by
-  // Decoder::refresh_from_device.  Only the image layer (1.7 K weights) goes through its host packer — and the decoder
-  // once, if no forward has built its buffers yet (refresh returns 1).
+  // Operand copies are rebuilt on the device: the encoder's by cnn_kernels.h pack_*_dev (image layer included), the
+  // decoder's by Decoder::refresh_from_device.  Only a decoder that no forward has finalised yet (refresh returns 1)
+  // is handed its weights through the host, once.
   int sync_engine(Encoder& enc, Decoder& dec, int64_t* total, hipStream_t st) {
     if (enc.gates_pending) {                       // the side stream may still read the operand copies we replace
       LRP_HIP_CHECK(hipStreamWaitEvent(st, enc.ev_gates, 0));
       enc.gates_pending = false;
     }
-    for (size_t li = 1; li < enc.layers.size(); ++li)
+    for (size_t li = 0; li < enc.layers.size(); ++li)
       LRP_TRY(enc.repack_conv_from_device((int)li, master.as<float>() + params[2 * li].off, master.as<float>() + params[2 * li + 1].off,
                                           ws.as<float>(), st));
-    const size_t dec0 = params[2 * enc.layers.size()].off, l0 = params[2].off;     // [0, l0): image layer; [dec0, n): decoder
+    const size_t dec0 = params[2 * enc.layers.size()].off;                         // [dec0, n): decoder
     std::function<const float*(const char*)> Wd = [&](const char* nm) -> const float* { return W(nm); };
     const int drc = dec.refresh_from_device(Wd, st);   // 1: the decoder has not built its operand copies yet
     if (drc != LRP_OK && drc != 1) return drc;
-    LRP_HIP_CHECK(hipMemcpyAsync(host_pinned, master.p, l0 * 4, hipMemcpyDeviceToHost, st));
-    if (drc == 1)
+    if (drc == 1) {                                // no forward has finalised the decoder yet: hand it the weights once
       LRP_HIP_CHECK(hipMemcpyAsync(host_pinned + dec0, master.as<float>() + dec0, (n_total - dec0) * 4, hipMemcpyDeviceToHost, st));
-    LRP_HIP_CHECK(hipStreamSynchronize(st));
-    LRP_TRY(enc.set_conv_weight(0, host_pinned + params[0].off, total));
-    LRP_TRY(enc.set_conv_bias(0, host_pinned + params[1].off, total));
-    if (drc == 1)
+      LRP_HIP_CHECK(hipStreamSynchronize(st));
       for (size_t pi = 2 * enc.layers.size(); pi < params.size(); ++pi)
         LRP_TRY(dec.set_weight(params[pi].name, host_pinned + params[pi].off, (int)params[pi].shape.size(), params[pi].shape.data(), total));
+    }
     enc.encoded = 0;                               // caches belong to the old weights
     return LRP_OK;
   }

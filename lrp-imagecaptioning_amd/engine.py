@@ -309,6 +309,12 @@ class LRPEngine(object):
         _capi.check(self._lib.lrp_decoder_gen_step(self._h, n, ppi, wwi, int(step), C.c_void_p(out.data_ptr()), self._stream()))
         return out
 
+    def log_softmax_topk(self, logits, k):
+        """`_log_softmax` + `np.argpartition(preds, -k)[:, -k:]` (explainers.py:45-48, :76-78) on the device for the
+        (rows, V) float64 logits of `gen_step`: (ids (rows, k) int32 model columns, logp (rows, k) float64), both by
+        descending probability.  Only these k pairs per row have to cross PCIe."""
+        return log_softmax_topk(logits, k)
+
     # ------------------------------------------------------------------ gradient baselines (SURVEY 8f-3)
     WALKS = {"lrp": 0, "gradient": 1, "input_x_gradient": 2, "guided_backprop": 3}
 
@@ -481,6 +487,20 @@ def op_avgpool_lrp(x, R, k):
     p = lambda t: C.c_void_p(t.data_ptr())
     _capi.check(lib.lrp_op_avgpool_lrp(p(x), p(R), p(out), NB, H, W, Cc, int(k), _cur_stream(x.device)))
     return out
+
+
+def log_softmax_topk(logits, k):
+    """lrp_op_log_softmax_topk: logits (rows, V) float64 device tensor -> (ids int32 (rows, k), logp float64 (rows, k))."""
+    lib = _capi.load()
+    x = logits.contiguous()
+    if x.dtype != torch.float64 or x.dim() != 2:
+        raise ValueError("expected a (rows, V) float64 tensor")
+    rows, V = x.shape
+    ids = torch.empty((rows, k), dtype=torch.int32, device=x.device)
+    lp = torch.empty((rows, k), dtype=torch.float64, device=x.device)
+    _capi.check(lib.lrp_op_log_softmax_topk(C.c_void_p(x.data_ptr()), rows, V, int(k), C.c_void_p(ids.data_ptr()),
+                                            C.c_void_p(lp.data_ptr()), _cur_stream(x.device)))
+    return ids, lp
 
 
 _LUT_CACHE = {}

@@ -190,19 +190,24 @@ class ExplainImgCaptioningAttentionModel(object):
         return out, pairs, att, rw, R
 
     def _beam_search(self, X, beam_size=3):
-        """Caption generation (E:51-120; the batched form of inference.py:178-253: with room for several images'
-        beams — max_images >= images x beam_size — one decoder step serves all of them).  Upstream of the LRP path (captions are an input to it); provided so harnesses
-        run end to end.  The hypotheses' decoder state stays on the device (lrp_decoder_gen_begin / _gen_step): one
-        decoder step per search step for all beams, where the reference re-runs the whole captioner on every partial
-        caption (E:71).  Beam bookkeeping as in `_beam_search_replay`."""
+        """Caption generation (E:51-120; the batched form of inference.py:178-253).  Upstream of the LRP path (captions
+        are an input to it); provided so harnesses run end to end.
+          * bookkeeping = `beam.search`: the reference's two bounded heaps, EOS handling and final pick, pinned against
+            the reference's own `_beam_search` on canned scores (tests/test_beam.py);
+          * scores: the hypotheses' decoder state stays on the device (lrp_decoder_gen_begin / _gen_step: one decoder
+            step per search step for ALL beams of ALL images that fit the handle — max_images >= images x beam_size —
+            where the reference re-runs the whole captioner on every partial caption, E:71), and so does the ranking
+            (lrp_op_log_softmax_topk): per step only beam_size (id, log p) pairs per hypothesis come to the host.
+        Returns, per image, up to beam_size captions, element [0] = the reference's answer (one image: that list)."""
+        from . import beam
         _, imgs_input = X
         imgs_input = np.asarray(imgs_input, dtype=np.float32)
         EOS = self._preprocessor.EOS_TOKEN_LABEL_ENCODED
         eng = self._engine
-        if beam_size > eng.max_images:
+        k = beam_size
+        if k > eng.max_images:
             return self._beam_search_replay(X, beam_size)          # not enough feature slots for one row per beam
         results = []
-        k = beam_size
         group = max(1, eng.max_images // k)      # images searched together: one decoder step serves all their beams
         for lo in range(0, len(imgs_input), group):
             imgs = imgs_input[lo:lo + group]
@@ -211,87 +216,42 @@ class ExplainImgCaptioningAttentionModel(object):
             feat = eng.get_features()[:G]
             eng.set_features(feat.repeat_interleave(k, dim=0).contiguous())    # one row (feature slot) per (image, beam)
             eng.gen_begin(G * k)
-            beams = [[([], 0.0)] for _ in range(G)]      # per image: (word ids so far, log prob); beam j lives in row i*k + j
-            rows = [[0] for _ in range(G)]
-            complete = [[] for _ in range(G)]
-            for s in range(self._max_caption_length):
-                if s == 0:
-                    logits = eng.gen_step(0)
-                else:
-                    parent, word = [], []
-                    for i in range(G):
-                        pr = rows[i] + [rows[i][0]] * (k - len(rows[i]))
-                        parent += [i * k + r for r in pr]
-                        word += [b[0][-1] for b in beams[i]] + [beams[i][0][0][-1]] * (k - len(beams[i]))
-                    logits = eng.gen_step(s, parent, word)
-                logits = logits.cpu().numpy()
-                for i in range(G):
-                    cand = []
-                    for r, (words, lp) in enumerate(beams[i]):
-                        lg = logits[i * k + r]
-                        logp = lg - lg.max()
-                        logp = logp - np.log(np.exp(logp).sum())
-                        top = np.argpartition(logp, -k)[-k:]
-                        for c in top:
-                            w = int(c) + 1                      # model column -> tokenizer id (E:92)
-                            if w == EOS:
-                                complete[i].append((words, lp + float(logp[c])))
-                            cand.append((words + [w], lp + float(logp[c]), r))
-                    cand.sort(key=lambda c: -c[1])
-                    keep = [c for c in cand if c[0][-1] != EOS][:k] or cand[:k]
-                    beams[i] = [(c[0], c[1]) for c in keep]
-                    rows[i] = [c[2] for c in keep]
-            for i in range(G):
-                complete[i].sort(key=lambda c: -c[1])
-                beams[i].sort(key=lambda c: -c[1])
-                out = []
-                for j in range(k):
-                    if j < len(complete[i]):
-                        out.append(complete[i][j][0] + [EOS])
-                    elif j < len(beams[i]):
-                        out.append(beams[i][j][0] + [EOS])
-                results.append(out)
+
+            def step(s, parent, word):
+                logits = eng.gen_step(s, parent, word)                          # (G * k, V) float64, stays on the device
+                ids, logp = eng.log_softmax_topk(logits, k)
+                return ids.cpu().numpy(), logp.cpu().numpy()
+            results += beam.search(step, G, k, self._max_caption_length, EOS)
         self.caption = None
         self._state_cache = {}
         return results[0] if len(results) == 1 else results
 
     def _beam_search_replay(self, X, beam_size=3):
-        """The same search on top of the teacher-forced decoder replay (every step re-plays the current beams from
-        scratch, like the reference's predict_on_batch loop): kept as the cross-check of `_beam_search`."""
+        """The same search with the scores taken from the teacher-forced decoder replay (every step re-plays the live
+        hypotheses from scratch, like the reference's predict_on_batch loop) and ranked on the host: the cross-check of
+        `_beam_search`'s incremental device state and device-side ranking."""
+        from . import beam
         _, imgs_input = X
         imgs_input = np.asarray(imgs_input, dtype=np.float32)
-        EOS, SOS = self._preprocessor.EOS_TOKEN_LABEL_ENCODED, self._preprocessor.SOS_TOKEN_LABEL_ENCODED
+        EOS = self._preprocessor.EOS_TOKEN_LABEL_ENCODED
+        eng = self._engine
+        k = beam_size
         results = []
         for img in imgs_input:
-            eng = self._engine
-            beams = [([], 0.0)]                  # (word ids so far, log prob)
-            complete = []
             eng.encode_images(img[None])
-            for s in range(self._max_caption_length):
-                cand = []
-                for words, lp in beams:
-                    eng.decoder_forward([words + [EOS]])
-                    logits = eng.read_state("caption_preds")[0, s].cpu().numpy()
-                    logp = logits - logits.max()
-                    logp = logp - np.log(np.exp(logp).sum())
-                    top = np.argpartition(logp, -beam_size)[-beam_size:]
-                    for k in top:
-                        w = int(k) + 1                      # model column -> tokenizer id (E:92)
-                        if w == EOS:
-                            complete.append((words, lp + float(logp[k])))
-                        cand.append((words + [w], lp + float(logp[k])))
-                cand.sort(key=lambda c: -c[1])
-                beams = [c for c in cand if c[0][-1] != EOS][:beam_size] or cand[:beam_size]
-            complete.sort(key=lambda c: -c[1])
-            beams.sort(key=lambda c: -c[1])
-            out = []
-            for i in range(beam_size):
-                if i < len(complete):
-                    out.append(complete[i][0] + [EOS])
-                elif i < len(beams):
-                    out.append(beams[i][0] + [EOS])
-            results.append(out)
+            hist = {}
+
+            def step(s, parent, word):
+                nonlocal hist
+                hist = {r: [] for r in range(k)} if s == 0 else {r: hist[parent[r]] + [int(word[r])] for r in range(k)}
+                rows = []
+                for r in range(k):
+                    eng.decoder_forward([hist[r] + [EOS]])
+                    rows.append(eng.read_state("caption_preds")[0, s].cpu().numpy())
+                return beam.topk_log_softmax(np.stack(rows), k)
+            results += beam.search(step, 1, k, self._max_caption_length, EOS)
         self.caption = None
+        self._state_cache = {}
         return results[0] if len(results) == 1 else results
 
 

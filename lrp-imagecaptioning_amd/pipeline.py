@@ -20,6 +20,7 @@ class LRPPipeline(object):
         self.engines = [LRPEngine(**engine_kwargs) for _ in range(n_handles)]
         dev = self.engines[0].device
         self.streams = [torch.cuda.Stream(device=dev) for _ in range(n_handles)]
+        self._done = [None] * n_handles          # event after the last batch issued on each slot
         self._next = 0
 
     @property
@@ -46,16 +47,33 @@ class LRPPipeline(object):
 
     def explain_batch(self, images, captions, img_idx, tpos, out=None):
         """One step (encode -> decoder replay -> per-token heat-maps) on the next handle's stream; returns
-        (out, slot).  The caller's tensors must stay alive until `synchronize()` (or a wait on `streams[slot]`)."""
+        (out, slot).  The result is complete on `streams[slot]` only: before reading it on another stream call
+        `wait(slot)` (stream-side wait on the batch's event, no host block) or `synchronize()`.  A result tensor
+        allocated here (out=None) is registered with the caller's stream, so the caching allocator does not hand its
+        memory out again while the caller still uses it.  The caller's input tensors must stay alive until then."""
         k = self._next
         self._next = (k + 1) % len(self.engines)
         eng, st = self.engines[k], self.streams[k]
-        st.wait_stream(torch.cuda.current_stream(eng.device))        # inputs produced on the caller's stream
+        caller = torch.cuda.current_stream(eng.device)
+        st.wait_stream(caller)                                        # inputs produced on the caller's stream
         with torch.cuda.stream(st):
             eng.encode_images(images)
             eng.decoder_forward(captions)
             res = eng.explain_tokens(img_idx, tpos, out=out)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._done[k] = ev
+        if out is None:
+            res[0].record_stream(caller)
         return res[0], k
+
+    def wait(self, slot=None):
+        """Make the CURRENT stream wait for the last batch of `slot` (default: of every slot) — what a consumer on
+        another stream needs before touching the result; the host does not block."""
+        cur = torch.cuda.current_stream(self.engines[0].device)
+        for k in (range(len(self.engines)) if slot is None else [slot]):
+            if self._done[k] is not None:
+                cur.wait_event(self._done[k])
 
     def synchronize(self):
         for st in self.streams:

@@ -158,3 +158,22 @@ def resnet_weights(rs, stacks=RESNET101_STACKS, stem=64, bias_std=0.05):
         w[name + "_bn_mean"] = (rs.standard_normal(cout) * 0.3).astype(np.float32)
         w[name + "_bn_var"] = rs.uniform(0.5, 1.5, size=cout).astype(np.float32)
     return w
+
+
+# --------------------------------------------------------------------------- canned scores for the beam-search fixture
+def canned_score_table(seed, V, n_images, positions=8):
+    """Seeded tables of a deterministic stand-in for the captioner's next-word scores (tests/golden/beam_*.npz: the
+    reference's own `_beam_search` is run on them, tests/test_beam.py runs ours)."""
+    rs = np.random.RandomState(seed)
+    return {"M": rs.standard_normal((V + 1, V)).astype(np.float32), "P": rs.standard_normal((positions, V)).astype(np.float32),
+            "I": (rs.standard_normal((n_images, V)) * 0.7).astype(np.float32)}
+
+
+def canned_next_word_scores(table, image, words):
+    """Un-normalised float32 scores (V,) of the word after `words` (tokenizer ids so far, SOS excluded) for `image`."""
+    last = words[-1] if len(words) else 0
+    prev = words[-2] if len(words) > 1 else 0
+    P = table["P"]
+    sc = (table["M"][last] + np.float32(0.37) * table["M"][prev] + P[len(words) % len(P)] + table["I"][image]).astype(np.float32)
+    sc[0] += np.float32(0.8 * len(words) - 2.5)          # EOS (tokenizer id 1 = column 0): unlikely early, likely late
+    return sc

@@ -401,3 +401,117 @@ def test_explicit_device_and_allocation_failure_are_statuses():
         o1 = e1.explain_tokens([0, 0], [1, 2])[0]
         assert o1.device.index == 1 and torch.equal(o1.cpu(), out.cpu())
         assert torch.cuda.current_device() == before
+
+
+@pytest.mark.parametrize("kind", ["adaptive", "gridtd"])
+def test_weights_set_from_device_match_host_set(kind):
+    """lrp_set_weight_dev (the multi-GPU start-up path: the bundle arrives in HBM over RCCL and is packed by device
+    kernels, no host round trip) must leave the handle in exactly the state lrp_set_weight does: heat-maps, decoder
+    LRP, gradient baselines and the fine-tune step's first gradients bit for bit — also when some weights come from the
+    host and some from the device."""
+    import torch
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    from lrp_imagecaptioning_amd.synthetic import gridtd_weights
+    rs = np.random.RandomState(12)
+    w = vgg_weights(rs, CFG, bias_std=0.3)
+    w.update((adaptive_weights if kind == "adaptive" else gridtd_weights)(rs, L, D, H, H, V))
+    kw = dict(decoder=kind, cnn_cfg=CFG, img_hw=(HW, HW), L=L, D=D, H=H, E=H, V=V, max_images=2, max_tokens=6, max_caption_len=5)
+    X = rs.uniform(-120, 130, size=(2, HW, HW, 3)).astype(np.float32)
+    caps = [[5, 9, 17, 1], [8, 3, 1]]
+    idx, tpos = [0, 0, 0, 1, 1], [1, 2, 3, 1, 2]
+
+    def run(eng):
+        eng.encode_images(X)
+        eng.decoder_forward(caps)
+        out, R, att, rw = eng.explain_tokens(idx, tpos, want_R_feat=True, want_attention=True, want_r_words=True)
+        d, drw = eng.decoder_gradient(idx, tpos)
+        g = eng.cnn_walk(idx, d, "gradient")
+        return [t.clone() for t in (out, R, att, rw, d, drw, g)]
+
+    host = LRPEngine(**kw)
+    host.set_weights(w)
+    want = run(host)
+    wd = {k: torch.as_tensor(v).cuda() for k, v in w.items()}
+    dev = LRPEngine(**kw)
+    dev.set_weights_from_device(wd)
+    got = run(dev)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    # mixed: decoder from the host, encoder from the device, one weight overwritten by the other route afterwards
+    mix = LRPEngine(**kw)
+    mix.set_weights({k: v for k, v in w.items() if not k.startswith("c")})
+    mix.set_weights_from_device({k: v for k, v in wd.items() if k.startswith("c")})
+    mix.set_weights_from_device({"output_W": wd["output_W"]})
+    mix.set_weights({"c2_W": w["c2_W"]})
+    for a, b in zip(run(mix), want):
+        assert torch.equal(a, b)
+    # a second device set with other values really replaces the operands
+    w2 = {k: (v * 1.25).astype(np.float32) for k, v in w.items()}
+    dev.set_weights_from_device({k: torch.as_tensor(v).cuda() for k, v in w2.items()})
+    host.set_weights(w2)
+    for a, b in zip(run(dev), run(host)):
+        assert torch.equal(a, b)
+    # the fine-tune step starts from device-set weights too
+    fresh_h, fresh_d = LRPEngine(**kw), LRPEngine(**kw)
+    fresh_h.set_weights(w)
+    fresh_d.set_weights_from_device(wd)
+    cap_in = np.array([[1, 4, 8, 16], [1, 7, 2, 0]], dtype=np.int32)
+    y = np.array([[4, 8, 16, 0], [7, 2, 0, -1]], dtype=np.int32)
+    lw = (1 + rs.uniform(0, 1, size=(2, 4, V))).astype(np.float32)
+    res = []
+    for e in (fresh_h, fresh_d):
+        e.train_begin(lr=1e-3)
+        e.encode_images(X)
+        g, l = e.train_step(cap_in, y, lw)
+        e.train_apply(g)
+        e.encode_images(X)
+        g2, l2 = e.train_step(cap_in, y, lw)
+        res.append((g.clone(), l.clone(), g2.clone(), l2.clone()))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
+def test_pipeline_result_consumed_on_the_callers_stream():
+    """explain_batch(out=None) allocates the result under the slot's stream; a consumer on the caller's stream only needs
+    `wait(slot)` — an event wait, not a device-wide synchronise — and gets complete heat-maps."""
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    from lrp_imagecaptioning_amd.pipeline import LRPPipeline
+    import torch
+    w, rs = _weights(4)
+    kw = dict(decoder="adaptive", cnn_cfg=CFG, img_hw=(HW, HW), L=L, D=D, H=H, E=H, V=V, max_images=2, max_tokens=8, max_caption_len=5)
+    pipe = LRPPipeline(2, **kw)
+    pipe.set_weights(w)
+    one = LRPEngine(**kw)
+    one.set_weights(w)
+    caps = [[5, 9, 17, 1], [8, 3, 1]]
+    idx, tpos = [0, 0, 0, 1, 1], [1, 2, 3, 1, 2]
+    sums, wants = [], []
+    for i in range(6):
+        X = torch.as_tensor(rs.uniform(-120, 130, size=(2, HW, HW, 3)).astype(np.float32)).cuda()
+        out, slot = pipe.explain_batch(X, caps, idx, tpos)
+        pipe.wait(slot)
+        sums.append(out.double().abs().sum())               # consumer on the caller's (default) stream, no synchronize()
+        del out
+        one.encode_images(X)
+        one.decoder_forward(caps)
+        wants.append(one.explain_tokens(idx, tpos)[0].double().abs().sum())
+    torch.cuda.synchronize()
+    for a, b in zip(sums, wants):
+        assert float(a) == float(b)
+
+
+def test_log_softmax_topk_on_device_matches_numpy():
+    """lrp_op_log_softmax_topk == `_log_softmax` + argpartition top-k (explainers.py:45-48, :76-78), at a vocabulary-sized row."""
+    import torch
+    from lrp_imagecaptioning_amd.beam import topk_log_softmax
+    from lrp_imagecaptioning_amd.engine import log_softmax_topk
+    rs = np.random.RandomState(3)
+    for rows, Vn, k in [(6, 10000, 3), (1, 37, 5), (9, 257, 1), (2, 40, 32)]:
+        x = rs.standard_normal((rows, Vn)) * 4
+        x[0, 5] = x[0, 7] = x[0].max() + 1.0                # an exact tie for the top: the lower column comes first
+        ids, lp = log_softmax_topk(torch.as_tensor(x).cuda(), k)
+        rid, rlp = topk_log_softmax(x, k)
+        assert np.array_equal(ids.cpu().numpy(), rid)
+        np.testing.assert_allclose(lp.cpu().numpy(), rlp, rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        log_softmax_topk(torch.zeros((2, 10), dtype=torch.float64, device="cuda"), 33)
