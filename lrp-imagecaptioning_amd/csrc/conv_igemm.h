@@ -89,6 +89,10 @@ struct ConvArgs {
   int tiles_x, tiles_y, img_mode;
   const float* ximg;
   const float* addend; // BIAS / BIAS_RELU epilogues: out = [relu](acc + bias + addend)  (bias may be null)
+  // EPI_BIAS only: out = gate_src / SafeDivide-denominator(acc + bias) — the relevance gate G_l = a_l / safe(Z+_l)
+  // (IL:456-458) straight from the denominator conv, Z+_l itself never goes to memory.  gate_src may alias out (the
+  // overlapped encode parks a_l in the gate's storage): an element is read and written by the same thread.
+  const float* gate_src;
   // EPI_MUL only — tail of a residual block in one epilogue (ResNet walk):
   //   r    = acc * aux[img] + join[row] * join_gate[img]     (the shortcut's share joins the main branch, KG:799-803)
   //   out  = r                                               (fp32 / split8 as usual)
@@ -724,6 +728,13 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
             if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
             if (a.addend) v += *reinterpret_cast<const f32x4*>(a.addend + (size_t)row * a.N + col);   // second pass of a product
+            if constexpr (EPI == EPI_BIAS) {
+              if (a.gate_src) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a.gate_src + (size_t)row * a.N + col);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = av[q] / (v[q] + (v[q] == 0.f ? 1e-7f : 0.f));
+              }
+            }
             if constexpr (EPI == EPI_BIAS_RELU) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);

@@ -29,6 +29,7 @@ struct ConvLayer {
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
+  DevBuf w_bwd_full_s;  // the same in split8 form: backward-data conv of the fine-tune step on the bf16 matrix cores
   DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
@@ -91,6 +92,14 @@ struct Encoder {
   }
   static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
     const char* e = getenv("LRP_FWD_X6");
+    return !e || atoi(e) != 0;
+  }
+  static bool train_split_enabled() {                  // LRP_TRAIN_SPLIT=0: exact-fp32 backward-data convs in the fine-tune step
+    const char* e = getenv("LRP_TRAIN_SPLIT");
+    return !e || atoi(e) != 0;
+  }
+  static bool gate_fused() {
+    const char* e = getenv("LRP_GATE_FUSED");
     return !e || atoi(e) != 0;
   }
   static bool overlap_enabled() {
@@ -267,6 +276,12 @@ struct Encoder {
       pack_conv_bwd(w, 9, L.cin, L.cout, 0, pk.data());
       LRP_TRY(L.w_bwd_full.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_bwd_full.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      {
+        std::vector<float> sp(pk.size());
+        pack_split8(pk.data(), pk.size(), sp.data());
+        LRP_TRY(L.w_bwd_full_s.alloc(sp.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_full_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
     }
     L.have_w = true;
     return LRP_OK;
@@ -293,7 +308,7 @@ struct Encoder {
     const size_t nf = (size_t)conv_npad(L.cout) * Kf, nb = (size_t)conv_npad(L.cin) * Kb;
     LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf));
     LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
-    LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb));
+    LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
     if (conv_npad(L.cin) == 64) LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb));
     if (pack_tmp.bytes < nf * sizeof(float)) LRP_TRY(pack_tmp.alloc(nf * sizeof(float), total));
     return LRP_OK;
@@ -333,6 +348,7 @@ struct Encoder {
       hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_s.as<float>(),
                          L.w_bwd_frag.as<float>(), CPo);
     pack(L.w_bwd_full.as<float>(), 1, Npb, 0, 0);
+    split(L.w_bwd_full.as<float>(), L.w_bwd_full_s.as<float>(), nb);
     LRP_HIP_CHECK(hipGetLastError());
     return LRP_OK;
   }
@@ -521,6 +537,14 @@ struct Encoder {
         cz.in = bufXs.as<float>(); cz.NB = B; cz.H = L.H; cz.W = L.W; cz.Cin = L.cin; cz.CinP = conv_cinp(L.cin); cz.taps = 9;
         cz.bias = L.bias.as<float>(); cz.wpk = L.w_fwd_zs.as<float>(); cz.N = L.cout;
         cz.out = top ? ztop.as<float>() : bufZ.as<float>();
+        if (!top && !L.pool_after && gate_fused()) {
+          // no pool behind this layer: G_l = a_l / safe(Z+_l) in the conv's epilogue, Z+_l never written (LRP_GATE_FUSED=0:
+          // separate gate_kernel pass)
+          cz.gate_src = keep_acts ? L.Akeep.as<float>() : L.G.as<float>();
+          cz.out = L.G.as<float>();
+          LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, side, PREC_BF16X3));
+          continue;
+        }
         LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, side, PREC_BF16X3));
         if (top) continue;
         const size_t n = (size_t)B * L.act_elems();
@@ -558,9 +582,15 @@ struct Encoder {
     float* S = s0.as<float>();
     float* Snext = s1.as<float>();
     bool split = prec == PREC_BF16X3 && walk == 0;
+    // Fine-tune step (layer_hook, walk = 1) in the default arithmetic: the backward-data convs run split-bf16 too —
+    // bf16 operands (hi + lo), three MFMAs per product, fp32 accumulate; the hook still sees plain fp32 dZ (the weight
+    // gradient reads it), so every layer's dZ is written fp32 and re-split by one streaming pass in front of its conv.
+    bool hook_split = prec == PREC_BF16X3 && walk == 1 && layer_hook != nullptr && train_split_enabled();
     for (const ConvLayer& L : layers)
-      if (L.cout & 7) split = false;                    // split8 groups need widths % 8 == 0: exact fp32 otherwise
-    const int run_prec = split ? PREC_BF16X3 : PREC_FP32;
+      if (L.cout & 7) split = hook_split = false;       // split8 groups need widths % 8 == 0: exact fp32 otherwise
+    for (size_t li = 1; li < layers.size(); ++li)
+      if (!layers[li].w_bwd_full_s.p) hook_split = false;
+    const int run_prec = (split || hook_split) ? PREC_BF16X3 : PREC_FP32;
     if (walk != 0) {
       const size_t per4 = T.act_elems() / 4;
       hipLaunchKernelGGL(grad_top_kernel, dim3(stream_grid((size_t)n * per4)), dim3(256), 0, st,
@@ -587,7 +617,14 @@ struct Encoder {
       }
       ConvArgs ca{};
       ca.in = S; ca.NB = n; ca.H = L.H; ca.W = L.W; ca.Cin = L.cout; ca.CinP = conv_cinp(L.cout); ca.taps = 9;
-      ca.wpk = walk != 0 ? L.w_bwd_full.as<float>() : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
+      if (hook_split) {
+        const size_t n8 = (size_t)n * L.act_elems() / 8;
+        hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, S, bufXs.as<float>(), n8);
+        LRP_HIP_CHECK(hipGetLastError());
+        ca.in = bufXs.as<float>();
+        ca.out_plain = 1;
+      }
+      ca.wpk = hook_split ? L.w_bwd_full_s.as<float>() : walk != 0 ? L.w_bwd_full.as<float>() : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
       ca.wpk_frag = (split && walk == 0) ? L.w_bwd_frag.as<float>() : nullptr;
       ca.row2img = row2img_dev;
       ca.gate_binary = walk != 0; ca.relu_out = walk == 3;

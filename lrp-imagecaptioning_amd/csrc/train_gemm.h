@@ -230,7 +230,11 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   const long steps = (a.K + SG_BK - 1) / SG_BK;
   const long tiles = (long)gx * gy * taps;
   if (ws && tiles < 384 && steps >= 16) {
-    ks = (int)((768 + tiles - 1) / tiles);                        // ~3 workgroups per CU in flight
+    // ~3 workgroups per CU in flight; the 64 x 64 tile (17 KB of LDS, 4 MFMAs per wave and k-pair) is latency-bound per
+    // k-slab, so its products — the image layer's weight gradient: M = N = 64, K = 1.6 M pixels — get ~8 per CU instead
+    // [MI355X: 1.75 -> see profiles/r02_config5.txt]
+    const long want = (tm == 1 && tn == 1) ? 2048 : 768;
+    ks = (int)((want + tiles - 1) / tiles);
     const long max_by_k = steps / 8 > 0 ? steps / 8 : 1;          // at least 8 slabs per slice
     if (ks > max_by_k) ks = (int)max_by_k;
     const size_t per = (size_t)a.M * a.N * taps;
