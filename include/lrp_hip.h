@@ -294,6 +294,9 @@ int lrp_op_sgemm(const float* A_dev, const float* B_dev, float* C_dev, int32_t M
                  int64_t ldc, int32_t transA, int32_t transB, int32_t accumulate, float* ws_dev, int64_t ws_floats, void* stream);
 int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream);
+/* the same product with bf16 operands (LRP_TRAIN_BF16; csrc/train_gemm_bf16.h) */
+int lrp_op_conv_wgrad_bf16(const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H,
+                           int32_t W, int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream);
 
 /* ---- Fine-tune step of the LRP-inference training loop (train.py:573-581:
  * `keras_model.train_on_batch(X + [lrp_weight], [y, y])` on ImgCaptioningAdaptiveAttentionLRPInferenceModel,
@@ -317,6 +320,15 @@ int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_de
  * lstm_rec (T, 4, B, H) (for grid-TD the language LSTM: lstm_in (T, 4, B, 2H)); logits (B, T, V): the grid-TD model's
  * Dropout on the logits (M:1303-1304), NULL for the adaptive model. */
 int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float beta2, float eps);
+/* ABI v3.  Arithmetic of the step's convolution gradients (BASELINE config 5 names bf16; models/model.py:1340-1374 is
+ * float32 in the reference).  Master weights, Adam and every accumulation are fp32 in both modes.
+ *   LRP_TRAIN_FP32 (default)  weight gradients on the fp32 MFMA; backward-data convs split-bf16 (three bf16 MFMAs per
+ *                             product, fp32-grade) — exact fp32 when the handle is in LRP_PREC_FP32.
+ *   LRP_TRAIN_BF16            the encoder's weight gradients with bf16 operands (activations and dZ rounded to bf16,
+ *                             v_mfma_f32_32x32x16_bf16, fp32 accumulate): conv weight gradients within ~1e-2 relative L1
+ *                             of the fp32 ones (tests/test_gpu_train.py), 5-10x less matrix time. */
+enum { LRP_TRAIN_FP32 = 0, LRP_TRAIN_BF16 = 1 };
+int lrp_train_set_precision(lrp_handle* h, int32_t mode);
 int64_t lrp_train_flat_size(const lrp_handle* h);
 int32_t lrp_train_num_params(const lrp_handle* h);
 int lrp_train_param_info(const lrp_handle* h, int32_t i, const char** name, int64_t* offset, int64_t* size);

@@ -14,6 +14,7 @@ LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
 LRP_EXPLAIN_SEQUENCE, LRP_EXPLAIN_SINGLE_STEP = 0, 1
 LRP_PREC_FP32, LRP_PREC_BF16X3, LRP_PREC_BF16X3_FAST = 0, 1, 2
 LRP_MAX_CONV = 32
+LRP_TRAIN_FP32, LRP_TRAIN_BF16 = 0, 1
 
 
 class LrpConfig(C.Structure):
@@ -63,6 +64,8 @@ SYMBOLS = {
     "lrp_op_sgemm": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, _P, C.c_int64, _P]),
     "lrp_op_conv_wgrad": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    "lrp_op_conv_wgrad_bf16": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P]),
+    "lrp_train_set_precision": (C.c_int, [_P, C.c_int32]),
     "lrp_train_begin": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]),
     "lrp_train_flat_size": (C.c_int64, [_P]),
     "lrp_train_num_params": (C.c_int32, [_P]),

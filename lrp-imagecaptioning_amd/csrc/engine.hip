@@ -564,19 +564,32 @@ int lrp_op_sgemm(const float* A_dev, const float* B_dev, float* C_dev, int32_t M
   });
 }
 
+static int op_conv_wgrad(bool bf16, const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H,
+                         int32_t W, int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream) {
+  if (!x_dev || !dz_dev || !dw_hwio_dev || !ws_dev) return fail(LRP_ERR_INVALID, "null argument");
+  if (NB < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(LRP_ERR_INVALID, "sizes must be positive");
+  if (ws_floats < (int64_t)2 * 9 * Cin * Cout) return fail(LRP_ERR_INVALID, "workspace smaller than 2 x 9 x Cin x Cout floats");
+  SgemmArgs a{};
+  a.A = x_dev; a.lda = Cin; a.B = dz_dev; a.ldb = Cout; a.C = dw_hwio_dev; a.ldc = Cout;
+  a.M = Cin; a.N = Cout; a.K = (long)NB * H * W; a.transA = 1;
+  a.gather = 1; a.gH = H; a.gW = W; a.taps = 9; a.tapC = (long)Cin * Cout;
+  if (bf16) LRP_HIP_CHECK(wgrad_bf16(a, ws_dev, (size_t)ws_floats, S(stream)));
+  else LRP_HIP_CHECK(sgemm(a, ws_dev, (size_t)ws_floats, S(stream)));
+  if (db_dev) LRP_HIP_CHECK(colsum(dz_dev, Cout, (long)NB * H * W, Cout, db_dev, 0, ws_dev, (size_t)ws_floats, S(stream)));
+  return LRP_OK;
+}
+
 int lrp_op_conv_wgrad(const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H, int32_t W,
                       int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream) {
   return guarded([&]() -> int {
-    if (!x_dev || !dz_dev || !dw_hwio_dev || !ws_dev) return fail(LRP_ERR_INVALID, "null argument");
-    if (NB < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return fail(LRP_ERR_INVALID, "sizes must be positive");
-    if (ws_floats < (int64_t)2 * 9 * Cin * Cout) return fail(LRP_ERR_INVALID, "workspace smaller than 2 x 9 x Cin x Cout floats");
-    SgemmArgs a{};
-    a.A = x_dev; a.lda = Cin; a.B = dz_dev; a.ldb = Cout; a.C = dw_hwio_dev; a.ldc = Cout;
-    a.M = Cin; a.N = Cout; a.K = (long)NB * H * W; a.transA = 1;
-    a.gather = 1; a.gH = H; a.gW = W; a.taps = 9; a.tapC = (long)Cin * Cout;
-    LRP_HIP_CHECK(sgemm(a, ws_dev, (size_t)ws_floats, S(stream)));
-    if (db_dev) LRP_HIP_CHECK(colsum(dz_dev, Cout, (long)NB * H * W, Cout, db_dev, 0, ws_dev, (size_t)ws_floats, S(stream)));
-    return LRP_OK;
+    return op_conv_wgrad(false, x_dev, dz_dev, dw_hwio_dev, db_dev, NB, H, W, Cin, Cout, ws_dev, ws_floats, stream);
+  });
+}
+
+int lrp_op_conv_wgrad_bf16(const float* x_dev, const float* dz_dev, float* dw_hwio_dev, float* db_dev, int32_t NB, int32_t H,
+                           int32_t W, int32_t Cin, int32_t Cout, float* ws_dev, int64_t ws_floats, void* stream) {
+  return guarded([&]() -> int {
+    return op_conv_wgrad(true, x_dev, dz_dev, dw_hwio_dev, db_dev, NB, H, W, Cin, Cout, ws_dev, ws_floats, stream);
   });
 }
 
@@ -588,6 +601,14 @@ int lrp_train_begin(lrp_handle* h, float lr, float clipvalue, float beta1, float
     if (!(lr > 0.f) || clipvalue < 0.f || !(eps > 0.f)) return fail(LRP_ERR_INVALID, "lr, eps must be positive, clipvalue >= 0");
     LRP_HIP_CHECK(hipSetDevice(h->cfg.device));
     return h->trainer.begin(h->enc, h->dec, h->cfg, lr, clipvalue, beta1, beta2, eps, &h->ws_bytes);
+  });
+}
+
+int lrp_train_set_precision(lrp_handle* h, int32_t mode) {
+  return with_handle(h, [&]() -> int {
+    if (mode != LRP_TRAIN_FP32 && mode != LRP_TRAIN_BF16) return fail(LRP_ERR_INVALID, "unknown training precision %d", mode);
+    h->trainer.train_prec = mode;
+    return LRP_OK;
   });
 }
 

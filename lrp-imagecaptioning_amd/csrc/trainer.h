@@ -24,6 +24,7 @@
 #include "decoder.h"
 #include "encoder.h"
 #include "train_gemm.h"
+#include "train_gemm_bf16.h"
 #include "train_kernels.h"
 
 namespace lrp {
@@ -36,6 +37,10 @@ struct TrainParam {
 
 struct Trainer {
   bool ready = false, gridtd = false;
+  // LRP_TRAIN_FP32: fp32-grade step (weight gradients on the fp32 MFMA; backward-data convs split-bf16 x3, or exact fp32
+  // when the handle runs in LRP_PREC_FP32).  LRP_TRAIN_BF16 (BASELINE config 5 "bf16"): the encoder's weight gradients
+  // with bf16 operands on v_mfma_f32_32x32x16_bf16 (train_gemm_bf16.h), fp32 accumulation, fp32 master weights / Adam.
+  int train_prec = LRP_TRAIN_FP32;
   int Bm = 0, Tm = 0, L = 0, D = 0, H = 0, E = 0, V = 0;
   std::vector<TrainParam> params;
   size_t n_total = 0;
@@ -320,7 +325,8 @@ struct Trainer {
         a.A = enc.layer_input(li); a.lda = Ly.cin; a.B = dZ; a.ldb = Ly.cout; a.C = gw; a.ldc = Ly.cout;
         a.M = Ly.cin; a.N = Ly.cout; a.K = K; a.transA = 1; a.transB = 0;
         a.gather = 1; a.gH = Ly.H; a.gW = Ly.W; a.taps = 9; a.tapC = (long)Ly.cin * Ly.cout;
-        LRP_HIP_CHECK(sgemm(a, wsf, ws_floats, st));
+        if (train_prec == LRP_TRAIN_BF16) LRP_HIP_CHECK(wgrad_bf16(a, wsf, ws_floats, st));
+        else LRP_HIP_CHECK(sgemm(a, wsf, ws_floats, st));
       }
       LRP_HIP_CHECK(colsum(dZ, Ly.cout, K, Ly.cout, grads + params[2 * li + 1].off, 0, wsf, ws_floats, st));
       return LRP_OK;

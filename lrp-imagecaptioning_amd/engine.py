@@ -215,6 +215,15 @@ class LRPEngine(object):
         self.n_images = 0
         return self.train_layout
 
+    def train_set_precision(self, mode):
+        """'fp32' (default: fp32-grade gradients) or 'bf16' (BASELINE config 5: the encoder's weight gradients with bf16
+        operands, fp32 accumulation and fp32 master weights) — lrp_train_set_precision."""
+        m = {"fp32": _capi.LRP_TRAIN_FP32, "bf16": _capi.LRP_TRAIN_BF16}.get(mode)
+        if m is None:
+            raise ValueError("training precision must be 'fp32' or 'bf16'")
+        _capi.check(self._lib.lrp_train_set_precision(self._h, m))
+        self.train_precision = mode
+
     def _train_inputs(self, cap_in, masks):
         """Device copies + checks of what the decoder's training forward reads: cap_in (B, T) and the dropout masks."""
         masks = masks or {}
@@ -430,15 +439,16 @@ def op_sgemm(A, B, transA=False, transB=False, C_init=None, split=True):
     return out
 
 
-def op_conv_wgrad(x, dz):
-    """Weight / bias gradient of a 3x3 'same' conv (lrp_op_conv_wgrad): x (NB,H,W,Cin), dz (NB,H,W,Cout) -> (dw HWIO, db)."""
+def op_conv_wgrad(x, dz, bf16=False):
+    """Weight / bias gradient of a 3x3 'same' conv (lrp_op_conv_wgrad[_bf16]): x (NB,H,W,Cin), dz (NB,H,W,Cout) -> (dw HWIO, db)."""
     lib = _capi.load()
     NB, H, W, Cin = x.shape
     Cout = dz.shape[3]
     dw = torch.empty((3, 3, Cin, Cout), dtype=torch.float32, device=x.device)
     db = torch.empty((Cout,), dtype=torch.float32, device=x.device)
     ws = torch.empty(16 << 20, dtype=torch.float32, device=x.device)
-    _capi.check(lib.lrp_op_conv_wgrad(C.c_void_p(x.data_ptr()), C.c_void_p(dz.data_ptr()), C.c_void_p(dw.data_ptr()),
+    fn = lib.lrp_op_conv_wgrad_bf16 if bf16 else lib.lrp_op_conv_wgrad
+    _capi.check(fn(C.c_void_p(x.data_ptr()), C.c_void_p(dz.data_ptr()), C.c_void_p(dw.data_ptr()),
                                       C.c_void_p(db.data_ptr()), NB, H, W, Cin, Cout, C.c_void_p(ws.data_ptr()), ws.numel(),
                                       _cur_stream(x.device)))
     return dw, db

@@ -42,6 +42,7 @@ def main():
         ex = ExplainImgCaptioningGridTDModel(spec, None, None, max_caption_length=T - 1, max_images=B)
         tr = TrainingLRPInferenceGridTD(ex, learning_rate=2e-4, drop_rate=0.5)
     eng = ex._engine
+    eng.train_set_precision(os.environ.get("TRAIN_PREC", "bf16"))   # BASELINE config 5 names bf16; TRAIN_PREC=fp32: the fp32-grade step
     rs = np.random.RandomState(100 + rank)              # this rank's shard of the batch
     X = torch.as_tensor(images(rs, B)).cuda()
     cap_in = np.concatenate([np.full((B, 1), 1), rs.randint(2, V, size=(B, T - 1))], axis=1).astype(np.int32)
@@ -72,9 +73,9 @@ def main():
             return
         print("data parallel x%d (%s): weights identical on every rank after %d updates; gradient all-reduce %.1f ms"
               % (world, dist.get_backend(), n + 2, t_ar))
-    print("config5 (fine-tune step, VGG16 + %s, B=%d, T=%d, %d heat-maps): %.1f ms/iteration; predict %.1f, lrp_weight %.1f, "
+    print("config5 (fine-tune step, %s gradients, VGG16 + %s, B=%d, T=%d, %d heat-maps): %.1f ms/iteration; predict %.1f, lrp_weight %.1f, "
           "gradients %.1f, Adam + operand rebuild %.1f ms; losses %s; workspace %.1f GB" % (
-              kind, B, T, n_maps, t_all / n, t_pred, t_lrp, t_step, t_apply, [round(float(v), 4) for v in losses.cpu()],
+              eng.train_precision, kind, B, T, n_maps, t_all / n, t_pred, t_lrp, t_step, t_apply, [round(float(v), 4) for v in losses.cpu()],
               eng.workspace_bytes / 1e9))
     assert torch.isfinite(g).all()
     if world > 1:

@@ -10,7 +10,7 @@ from conftest import ROOT
 def _declared():
     src = open(os.path.join(ROOT, "include", "lrp_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(lrp_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(lrp_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():

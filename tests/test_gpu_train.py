@@ -436,3 +436,58 @@ def test_early_forward_is_dropped_by_a_new_encode_or_weight():
             eng.encode_images(X1)
         g, l = eng.train_step(cap_in, y, lw, masks)
         assert torch.equal(g, g_ref) and torch.equal(l, l_ref), how
+
+
+@pytest.mark.parametrize("NB,HW,Cin,Cout", [(2, 112, 64, 128), (4, 28, 512, 512), (2, 56, 128, 256), (3, 14, 136, 72), (1, 5, 8, 8),
+                                            (2, 224, 64, 64)])
+def test_conv_wgrad_bf16_matches_torch(NB, HW, Cin, Cout):
+    """lrp_op_conv_wgrad_bf16 (csrc/train_gemm_bf16.h: operands rounded to bf16, transposed LDS reads, bf16 MFMA, fp32
+    accumulate).  Two bars: (a) against the float64 gradient of the SAME bf16-rounded operands only the fp32
+    accumulation differs -> 2e-5; (b) against the float64 gradient of the unrounded operands the rounding shows: the
+    stated tolerance of the bf16 training mode, 1e-2 relative L1 (2^-9 per operand, random sign, averaged over K)."""
+    import torch.nn.functional as F
+    from lrp_imagecaptioning_amd.engine import op_conv_wgrad
+    g = torch.Generator().manual_seed(NB + HW)
+    x = torch.randn((NB, HW, HW, Cin), generator=g)
+    dz = torch.randn((NB, HW, HW, Cout), generator=g) * (torch.rand((NB, HW, HW, Cout), generator=g) > 0.5)
+
+    def grad(xx, dd):
+        w = torch.zeros((Cout, Cin, 3, 3), dtype=torch.float64, requires_grad=True)
+        y = F.conv2d(xx.double().permute(0, 3, 1, 2), w, None, padding=1)
+        y.backward(dd.double().permute(0, 3, 1, 2))
+        return w.grad.permute(2, 3, 1, 0).numpy()                      # OIHW -> HWIO
+    dw, db = op_conv_wgrad(x.cuda(), dz.cuda(), bf16=True)
+    dw = dw.cpu().numpy()
+    assert np.isfinite(dw).all()
+    assert rel_l1(dw, grad(x.bfloat16().float(), dz.bfloat16().float())) < 2e-5
+    assert rel_l1(dw, grad(x, dz)) < 1e-2
+    assert rel_l1(db.cpu().numpy(), dz.double().sum((0, 1, 2)).numpy()) < 1e-5      # (the bias gradient stays fp32)
+    dw2, _ = op_conv_wgrad(x.cuda(), dz.cuda(), bf16=True)
+    assert np.array_equal(dw2.cpu().numpy(), dw)                       # deterministic K split
+
+
+def test_gradients_in_bf16_training_mode():
+    """lrp_train_set_precision(LRP_TRAIN_BF16) — BASELINE config 5's arithmetic: the encoder's weight gradients on the
+    bf16 MFMA (operands rounded to bf16), everything else as in the fp32 mode.  Stated tolerance vs the float64 oracle:
+    conv kernels 2e-2 relative L1, every other tensor (decoder, biases) the fp32 mode's 2e-4."""
+    from oracle import train_ref as T
+    w, X, cap_in, y, lw, masks = _case()
+    eng = _engine(w, len(X))
+    layout = eng.train_begin(lr=1e-3, clipvalue=0.01)
+    with pytest.raises(ValueError):
+        eng.train_set_precision("fp8")
+    eng.train_set_precision("bf16")
+    eng.encode_images(X)
+    grads, losses = eng.train_step(cap_in, y, lw, masks)
+    total, l1, l2, g, _ = T.loss_and_grads(w, CFG, X, cap_in, y, lw, masks)
+    np.testing.assert_allclose(losses.cpu().numpy()[:3], [total, l1, l2], rtol=2e-5)
+    gf = grads.cpu().numpy()
+    conv_w = {name + "_W" for name, _, _, _ in CFG[1:]}                # (the image layer's product stays on the fp32 MFMA)
+    worst = {name: rel_l1(gf[off:off + n], g[name]) for name, (off, n) in layout.items()}
+    bad = {k: v for k, v in worst.items() if not v < (2e-2 if k in conv_w else 2e-4)}
+    assert not bad, bad
+    assert max(worst[k] for k in conv_w) > 1e-5                        # the mode really took the bf16 path
+    eng.train_set_precision("fp32")
+    g32, _ = eng.train_step(cap_in, y, lw, masks)
+    worst32 = {name: rel_l1(g32.cpu().numpy()[off:off + n], g[name]) for name, (off, n) in layout.items()}
+    assert all(v < 2e-4 for v in worst32.values()), worst32
