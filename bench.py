@@ -123,10 +123,13 @@ def rel_l1(a, b):
 WALK_KERNEL_RE = re.compile(r"conv_igemm_kernel<\d+, \d+, \d+, \d+, (\d+), (\d+)(?:, \w+)*>")
 
 
-def is_walk_kernel(name, split):
+PREC_TEMPLATE_ARG = {"fp32": "0", "bf16x3": "1", "bf16x3_fast": "1", "f16x2": "2"}   # conv_igemm.h ConvPrec
+
+
+def is_walk_kernel(name, precision):
     """reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5) / fused image layer (6) in the walk's arithmetic"""
     m = WALK_KERNEL_RE.search(name)
-    return bool(m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == ("1" if split else "0"))
+    return bool(m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == PREC_TEMPLATE_ARG[precision])
 
 
 def live_pmc_traffic(args):
@@ -157,7 +160,7 @@ def live_pmc_traffic(args):
             seen = set()
             tot[ctr] = 0.0
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == ctr and is_walk_kernel(row["Kernel_Name"], args.precision != "fp32"):
+                if row["Counter_Name"] == ctr and is_walk_kernel(row["Kernel_Name"], args.precision):
                     tot[ctr] += float(row["Counter_Value"])
                     seen.add(row["Dispatch_Id"])
             n[ctr] = len(seen)
@@ -183,7 +186,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=10, help="tokens of one caption the CPU port explains (~1 s each)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16x3_fast"],
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16x3_fast", "f16x2"],
                     help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (default) or exact fp32 MFMA")
     ap.add_argument("--handles", type=int, default=2,
                     help="batches in flight per GPU: consecutive steps alternate between this many lrp_handles on their own "
@@ -284,7 +287,13 @@ def main():
     def roofline_block(precision, n_launch, ms, flop, traffic, traffic_src):
         split = precision != "fp32"
         achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        if split:
+        per_product = 2 if precision == "f16x2" else 3
+        if precision == "f16x2":
+            peak = PEAK_BF16_MFMA_TFLOPS                     # (v_mfma_f32_32x32x16_f16 runs at the bf16 rate)
+            kname = ("conv_igemm_kernel<..., PREC_F16X2> (conv-LRP alpha1beta0 backward, 13 launches/step; relevance as an "
+                     "fp16 pair hi+lo with per-token power-of-two scales, one fp16 per weight: 2 f16 MFMAs per product, fp32 "
+                     "accumulate; forward/decoder stay fp32-grade/fp64)")
+        elif split:
             peak = PEAK_BF16_MFMA_TFLOPS
             kname = ("conv_igemm_kernel<..., PREC_BF16X3> (conv-LRP alpha1beta0 backward, 13 launches/step; every fp32 "
                      "product = 3 bf16 MFMAs hi*hi+hi*lo+lo*hi, fp32 accumulate; forward/decoder stay fp32/fp64)")
@@ -300,8 +309,8 @@ def main():
                 "algorithmic_bytes_per_launch": int(abytes / alaunch),
                 "traffic_over_algorithmic_bytes": round(traffic / (abytes / alaunch), 3) if traffic else None}
         if split:
-            roof["mfma_flop_per_algorithmic_flop"] = 3
-            roof["issued_mfma_frac"] = round(3 * achieved / peak, 4)
+            roof["mfma_flop_per_algorithmic_flop"] = per_product
+            roof["issued_mfma_frac"] = round(per_product * achieved / peak, 4)
             roof["vs_fp32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 3)
         return roof
 
@@ -335,12 +344,12 @@ def main():
     if live_traffic:
         traffic, traffic_src = live_traffic["bytes"], live_src
     else:
-        traffic, traffic_src = pmc_traffic_per_launch("bf16x3" if args.precision != "fp32" else "fp32")
+        traffic, traffic_src = pmc_traffic_per_launch(args.precision)
         if traffic_src and live_src:
             traffic_src += " (%s)" % live_src
     if rank == 0:
         heatmaps = world * B * T * args.steps
-        dtype = "f32" if args.precision == "fp32" else "bf16x3"
+        dtype = {"fp32": "f32", "f16x2": "f16x2"}.get(args.precision, "bf16x3")
         res = {
             "metric": METRIC, "value": round(heatmaps / dt, 2), "unit": "heatmaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -389,13 +398,14 @@ def pmc_traffic_per_launch(precision="bf16x3"):
     FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
     import glob
     # the committed summaries are of the default-precision run; an fp32-mode profile would be r*_pmc_summary_fp32.json
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % ("" if precision == "bf16x3" else "_fp32"))))
+    suffix = {"bf16x3": "", "bf16x3_fast": "", "fp32": "_fp32", "f16x2": "_f16x2"}[precision]
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % suffix)))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
     tot = n = 0.0
     for k, v in d.items():
-        if is_walk_kernel(k, precision == "bf16x3"):
+        if is_walk_kernel(k, precision):
             if "fetch_bytes_per_launch_x2corr" in v and "write_bytes_per_launch" in v:
                 tot += (v["fetch_bytes_per_launch_x2corr"] + v["write_bytes_per_launch"]) * v["launches"]
                 n += v["launches"]

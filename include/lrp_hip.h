@@ -214,8 +214,14 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  *                 split: an error in a_l upstream of a max-pool flips arg-maxes, and a_top are the decoder's features.
  * LRP_PREC_BF16X3_FAST  two-way split activation convs as well: 10 % faster, but the arg-max flips put the heat-map
  *                 parity at 2e-5 ... 9e-5 (five seeds) — inside the 1e-4 bar without margin.  Opt-in, not recommended.
+ * LRP_PREC_F16X2  (ABI v3) the LRP reverse walk of the VGG-style encoder with the relevance tensors as fp16 pairs hi + lo
+ *                 (22 mantissa bits, carried scaled by a per-token power of two that every layer re-derives from the
+ *                 measured maximum of its input and its weight norm) and ONE fp16 per weight: two MFMAs of
+ *                 v_mfma_f32_32x32x16_f16 per product instead of three.  The weight rounding (2^-12, the same for every
+ *                 token) puts the heat-maps at 2-3e-5 relative L1 from the float64 graph (BF16X3: ~4e-6; bar 1e-4).
+ *                 Everything else (forward, decoder, ResNet encoder) as LRP_PREC_BF16X3.
  * The decoder is fp32 / fp64 in every mode. */
-enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2 };
+enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2, LRP_PREC_F16X2 = 3 };
 int lrp_set_precision(lrp_handle* h, int32_t mode);
 
 /* Dominant-kernel timing for bench.py's roofline block: when enabled, HIP

@@ -12,7 +12,7 @@ LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANG
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
 LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
 LRP_EXPLAIN_SEQUENCE, LRP_EXPLAIN_SINGLE_STEP = 0, 1
-LRP_PREC_FP32, LRP_PREC_BF16X3, LRP_PREC_BF16X3_FAST = 0, 1, 2
+LRP_PREC_FP32, LRP_PREC_BF16X3, LRP_PREC_BF16X3_FAST, LRP_PREC_F16X2 = 0, 1, 2, 3
 LRP_MAX_CONV = 32
 LRP_TRAIN_FP32, LRP_TRAIN_BF16 = 0, 1
 

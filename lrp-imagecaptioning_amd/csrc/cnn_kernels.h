@@ -164,6 +164,92 @@ __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restr
     dst[i] = (pos && !(v >= 0.f)) ? 0.f : v;
   }
 }
+// ---- PREC_F16X2 (conv_igemm.h): fp16 operand copies and the per-token scale of the walk's head
+// fp32 packed matrix -> fp16 split8 ([hi8 | lo8] per 8 k), the device twin of pack_split8_f16
+__global__ __launch_bounds__(256) void split_copy_h_kernel(const float* __restrict__ x, float* __restrict__ xs, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+    split8h_store(v, xs + i * 8);
+  }
+}
+// *out (float bits, zeroed by the caller) = max over the rows of sum_k |fp16(w[row][k])|: ConvArgs::wnorm, one block per row
+__global__ __launch_bounds__(256) void rowabs_max_kernel(const float* __restrict__ w, int K, unsigned* __restrict__ out) {
+  __shared__ float red[256];
+  const float* r = w + (size_t)blockIdx.x * K;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += fabsf((float)(_Float16)r[k]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(red[0] * 1.0001f));     // (order of the sum differs from the host's: margin)
+}
+// Between two launches of the PREC_F16X2 walk: the power of two the next conv adds to each token's scale (ConvArgs::tok_fac)
+//   k = floor(log2(30000 / (max_in * wnorm))),  fac = 2^k,  exp_out = exp_in + k      (wnorm: device scalar of the layer)
+// final = 1 (in front of the image layer, whose output is plain fp32): fac = 2^-exp_in, nothing else.
+__global__ __launch_bounds__(256) void tok_scale_kernel(const unsigned* __restrict__ max_in, const int* __restrict__ exp_in,
+                                                        const float* __restrict__ wnorm, float* __restrict__ fac,
+                                                        int* __restrict__ exp_out, int n, int final) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  if (final) { fac[t] = ldexpf(1.f, -exp_in[t]); return; }
+  const float m = __uint_as_float(max_in[t]);
+  int k = 0;
+  if (m > 0.f) {
+    k = (int)floorf(log2f(30000.f / (m * *wnorm)));
+    k = k < -120 ? -120 : k > 120 ? 120 : k;
+  }
+  fac[t] = ldexpf(1.f, k);
+  exp_out[t] = exp_in[t] + k;
+}
+// Head of the reverse walk in PREC_F16X2: S_top = R_feat / safe(Z_top[img]) per token (KG:898-900), stored as fp16 pairs
+// scaled by 2^k, k = floor(log2(30000 / max|S_top|)) — one workgroup per token, two passes over its 0.4 MB.
+__global__ __launch_bounds__(256) void top_divide_f16_kernel(const float* __restrict__ R, const float* __restrict__ Ztop,
+                                                             const int* __restrict__ row2img, float* __restrict__ S,
+                                                             size_t per_img8, int* __restrict__ tok_exp, unsigned* __restrict__ tok_max) {
+  __shared__ float red[256];
+  const int t = blockIdx.x, img = row2img ? row2img[t] : t;
+  const float* r = R + (size_t)t * per_img8 * 8;
+  const float* z = Ztop + (size_t)img * per_img8 * 8;
+  float m = 0.f;
+  for (size_t i = threadIdx.x; i < per_img8; i += 256) {
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(r + i * 8), r1 = *reinterpret_cast<const f32x4*>(r + i * 8 + 4);
+    const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + i * 8), z1 = *reinterpret_cast<const f32x4*>(z + i * 8 + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m = fmaxf(m, fmaxf(fabsf(r0[c] / safe_den(z0[c])), fabsf(r1[c] / safe_den(z1[c]))));
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  int k = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    k = (int)floorf(log2f(30000.f / m));
+    k = k < -120 ? -120 : k > 120 ? 120 : k;
+  }
+  const float fac = ldexpf(1.f, k);
+  if (threadIdx.x == 0) {
+    tok_exp[t] = k;
+    tok_max[t] = __float_as_uint(m * fac);
+  }
+  float* s = S + (size_t)t * per_img8 * 8;
+  for (size_t i = threadIdx.x; i < per_img8; i += 256) {
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(r + i * 8), r1 = *reinterpret_cast<const f32x4*>(r + i * 8 + 4);
+    const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + i * 8), z1 = *reinterpret_cast<const f32x4*>(z + i * 8 + 4);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { v[c] = r0[c] / safe_den(z0[c]) * fac; v[4 + c] = r1[c] / safe_den(z1[c]) * fac; }
+    split8h_store(v, s + i * 8);
+  }
+}
+
 // Device twin of the image-layer packers of Encoder::set_conv_weight (li == 0): w (3,3,3,cout) HWIO ->
 //   fwd  [.][64]  rows [0,cout): w against both halves of the im2col row (x+ patch | x- patch) = a_1;
 //                 rows [cout,2cout): w+ | w- = Z_1 (RR:256-260)

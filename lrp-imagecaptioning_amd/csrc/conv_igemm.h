@@ -32,6 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // PREC_FP32 : operands fp32, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
 // PREC_BF16X3: operands stored as "split8" — per 8 consecutive channels 32 B = [8 x bf16 hi | 8 x bf16 lo] with
@@ -40,8 +41,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   (5.3x fewer matrix-pipe cycles).  Used for the per-token reverse walk only; the per-image forward
 //   stays exact fp32 (measured: forward fp32 + backward split = 2-3.5e-6 relative L1 vs the float64
 //   graph; splitting the forward too = 2.4e-5, because errors in Z / a are systematic, errors in S average out).
-enum ConvPrec { PREC_FP32 = 0, PREC_BF16X3 = 1 };
+// PREC_F16X2 : the relevance operand S as an fp16 pair hi + lo (22 mantissa bits) in the same split8 layout, the weights
+//   as ONE fp16 (11 bits; their lo half is not read): product = lo*w + hi*w, TWO MFMAs of v_mfma_f32_32x32x16_f16 per
+//   16 k.  fp16 has 5 exponent bits, so S is carried scaled by a per-token power of two, chosen per layer from the
+//   measured maximum of the layer's input and the layer's weight norm (ConvArgs::tok_*; Encoder::explain).  What it
+//   costs: the weight rounding (2^-12, systematic per weight) puts the heat-maps at ~2-3e-5 relative L1 from the float64
+//   graph (bf16x3: ~4e-6; bar 1e-4) [CPU emulation + MI355X, DESIGN 4.1].  Reverse walk of the VGG encoder only.
+enum ConvPrec { PREC_FP32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2 };
 
+__device__ __forceinline__ void split8h_store(const float* r, float* dst) {  // 8 fp32 -> 32 B [fp16 hi8 | fp16 lo8]
+  f16x8 hi, lo;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    hi[q] = (_Float16)r[q];
+    lo[q] = (_Float16)(r[q] - (float)hi[q]);
+  }
+  u32x4* d = reinterpret_cast<u32x4*>(dst);
+  d[0] = __builtin_bit_cast(u32x4, hi);
+  d[1] = __builtin_bit_cast(u32x4, lo);
+}
 __device__ __forceinline__ void split8_store(const float* r, float* dst) {   // 8 fp32 -> 32 B [hi8 | lo8]
   bf16x8 hi, lo;
 #pragma unroll
@@ -109,6 +127,14 @@ struct ConvArgs {
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
   int tw, th, hrows, cols_t, nyh;
+  // PREC_F16X2: per-token power-of-two scaling of the fp16 relevance tensors (indexed by the token slot n of a row).
+  //   stored input = true * 2^e_in[n], |stored input| <= max_in[n] (measured by the producer).  tok_scale_kernel
+  //   (cnn_kernels.h) picks k[n] = floor(log2(30000 / (max_in[n] * wnorm))) — wnorm = max row sum of |w| of the layer's
+  //   backward matrix, the gate is <= 1, so |acc * gate| * 2^k stays below fp16's 65504 — and hands this launch
+  //   tok_fac[n] = 2^k[n]; the epilogue stores acc * gate * tok_fac[n] and raises tok_max_out[n] (float bits) to the
+  //   largest |stored output|.  EPI_IMG_STENCIL ends the chain: tok_fac[n] = 2^-e_in[n].
+  const float* tok_fac;
+  unsigned* tok_max_out;
 };
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -148,12 +174,13 @@ template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false, 
 __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
+  constexpr bool SPLIT = PREC != PREC_FP32;            // operands in split8 form (bf16 or fp16 pairs): 16 k per MFMA
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int AP = BM / 8 / NW, BP = BN / 8 / NW;   // 1 KiB (8-row) DMA pieces per wave and chunk
   constexpr int HR = conv_halo_rows(BM);              // HALO: LDS rows (pixels) of the resident image
   constexpr int ABUF = (HALO ? HR : BM) * LDS_STRIDE;
   constexpr int STAGE = ABUF + (BREG ? 0 : BN) * LDS_STRIDE;
-  static_assert(!BREG || (HALO && PREC == PREC_BF16X3 && BM * BN <= 2 * STAGE), "BREG needs the resident image");
+  static_assert(!BREG || (HALO && SPLIT && BM * BN <= 2 * STAGE), "BREG needs the resident image");
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
   static_assert(!HALO || EPI != EPI_STORE, "the image layer is a 1-tap GEMM");
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
         amask[p] = ok ? 1u : 0u;
         const int lc = (pchk ^ ((r >> 1) & 7)) << 2;
-        acf[p] = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;
+        acf[p] = SPLIT ? ((lc >> 3) << 3) : lc;
         avo[p] = ok ? ((y * a.W + x) * a.Cin + lc) * 4 : 0;
         continue;
       }
@@ -259,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
       }
       amask[p] = mask;
       const int lc = (pchk ^ ((r >> 1) & 7)) << 2;
-      acf[p] = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;   // 4*chunk (fp32) or 8*(chunk/2) (split8 group)
+      acf[p] = SPLIT ? ((lc >> 3) << 3) : lc;   // 4*chunk (fp32) or 8*(chunk/2) (split8 group)
       avo[p] = (r * a.Cin + lc) * 4;
       if (a.taps != 1) {                                  // next piece: 8 pixels further
         w += 8;
@@ -281,7 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     divmod(E < 0 ? 0 : E, a.H + 1, inv_H1, n, h);
     const int x = x0 - 1 + hx;
     const int lc = (pchk ^ (((hy * a.tw + hx - 1) >> 1) & 7)) << 2;   // halo swizzle, see set_tap
-    const int cfirst = PREC == PREC_BF16X3 ? ((lc >> 3) << 3) : lc;
+    const int cfirst = SPLIT ? ((lc >> 3) << 3) : lc;
     const bool ok = live && E >= 0 && h < a.H && n < a.NB && hx < a.tw + 2 && x >= 0 && x < a.W && (chunk << 5) + cfirst < a.Cin;
     HaloPiece r;
     r.vo = ok ? (x * a.Cin + lc) * 4 : OOB;
@@ -402,7 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
     for (int i = 0; i < (HALO ? TM : 0); ++i) {
       const int row = fbase[i] + tsh, u = fu[i] + ush;
-      faddr[i] = row * LDS_STRIDE + ((((PREC == PREC_BF16X3 ? 2 : 1) * hh_) ^ ((u >> 1) & 7)) << 2);
+      faddr[i] = row * LDS_STRIDE + ((((SPLIT ? 2 : 1) * hh_) ^ ((u >> 1) & 7)) << 2);
     }
   };
   // Fragment registers are double-buffered one step ahead, and the first fragments of the NEXT
@@ -411,27 +438,27 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   // before the barrier => the DMA of the following iteration cannot race them.)
   // fp32 : 4 steps of 8 k per chunk; lane-half h consumes k = 4h+s -> logical chunk 2kk+h.
   // bf16x3: 2 steps of 16 k; lane-half h consumes k = 8h+j -> split8 group 2s+h = chunks 4s+2h (hi), 4s+2h+1 (lo).
-  constexpr int NSTEP = PREC == PREC_BF16X3 ? 2 : 4;
+  constexpr int NSTEP = SPLIT ? 2 : 4;
   const int swz = (lane >> 1) & 7, hh = lane >> 5;
   int koff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
-    koff[q] = PREC == PREC_BF16X3 ? (((4 * (q >> 1) + 2 * hh + (q & 1)) ^ swz) << 2)     // q = 2*step + {hi,lo}
+    koff[q] = SPLIT ? (((4 * (q >> 1) + 2 * hh + (q & 1)) ^ swz) << 2)     // q = 2*step + {hi,lo}
                                   : (((2 * q + hh) ^ swz) << 2);
-  struct Frag { u32x4 a[PREC == PREC_BF16X3 ? 2 * TM : TM], b[PREC == PREC_BF16X3 ? 2 * TN : TN]; };
+  struct Frag { u32x4 a[SPLIT ? 2 * TM : TM], b[SPLIT ? 2 * TN : TN]; };
   // HALO: A addresses come from faddr[] (set_tap); chunk c ^ swizzle = (c0 ^ swizzle) ^ (c - c0) for disjoint bits
   auto read_frag = [&](Frag& f, const float* Ab, const float* Bb, int st) {
     if constexpr (HALO) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        if constexpr (PREC == PREC_BF16X3) {
+        if constexpr (SPLIT) {
           f.a[2 * i] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ ((4 * st) << 2)));
           f.a[2 * i + 1] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ ((4 * st + 1) << 2)));
         } else {
           f.a[i] = *reinterpret_cast<const u32x4*>(Ab + (faddr[i] ^ ((2 * st) << 2)));
         }
       }
-    } else if constexpr (PREC == PREC_BF16X3) {
+    } else if constexpr (SPLIT) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         f.a[2 * i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[2 * st]);
@@ -441,11 +468,12 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
       for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(Ab + i * 32 * LDS_STRIDE + koff[st]);
     }
-    if constexpr (PREC == PREC_BF16X3) {
+    if constexpr (SPLIT) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         f.b[2 * j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st]);
-        f.b[2 * j + 1] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st + 1]);
+        if constexpr (PREC != PREC_F16X2 || (TERMS & 2) != 0)   // (fp16 weights, two-term form: their lo chunk is never read)
+          f.b[2 * j + 1] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st + 1]);
       }
     } else {
 #pragma unroll
@@ -453,7 +481,19 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     }
   };
   auto mfma_frag = [&](const Frag& f) {
-    if constexpr (PREC == PREC_BF16X3) {
+    if constexpr (PREC == PREC_F16X2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f16x8 ah = __builtin_bit_cast(f16x8, f.a[2 * i]), al = __builtin_bit_cast(f16x8, f.a[2 * i + 1]);
+          const f16x8 bh = __builtin_bit_cast(f16x8, f.b[2 * j]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);    // small terms first
+          if constexpr ((TERMS & 2) != 0)                 // TERMS 7: the weights' lo half too (layers with a short K, below)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, f.b[2 * j + 1]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+        }
+    } else if constexpr (PREC == PREC_BF16X3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -485,7 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     struct BFrag { u32x4 v[4 * TN]; };
     auto load_b = [&](BFrag& b, int kc) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)                        // q = 2*step + (0 hi | 1 lo)
+      for (int q = 0; q < 4; q += ((PREC == PREC_F16X2 && !(TERMS & 2)) ? 2 : 1))    // q = 2*step + (0 hi | 1 lo); two-term fp16: hi only
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           b.v[q * TN + j] = __builtin_amdgcn_raw_buffer_load_b128(rsF, fvo + j * 32 * 16, ((kc * 4 + q) * 2) * BN * 16, 0);
@@ -505,11 +545,20 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, f.v[(2 * st) * TM + i]), al = __builtin_bit_cast(bf16x8, f.v[(2 * st + 1) * TM + i]);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, b.v[(2 * st) * TN + j]), bl = __builtin_bit_cast(bf16x8, b.v[(2 * st + 1) * TN + j]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+            if constexpr (PREC == PREC_F16X2) {
+              const f16x8 ah = __builtin_bit_cast(f16x8, f.v[(2 * st) * TM + i]), al = __builtin_bit_cast(f16x8, f.v[(2 * st + 1) * TM + i]);
+              const f16x8 bh = __builtin_bit_cast(f16x8, b.v[(2 * st) * TN + j]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);
+              if constexpr ((TERMS & 2) != 0)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, b.v[(2 * st + 1) * TN + j]), acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
+            } else {
+              const bf16x8 ah = __builtin_bit_cast(bf16x8, f.v[(2 * st) * TM + i]), al = __builtin_bit_cast(bf16x8, f.v[(2 * st + 1) * TM + i]);
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, b.v[(2 * st) * TN + j]), bl = __builtin_bit_cast(bf16x8, b.v[(2 * st + 1) * TN + j]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i][j], 0, 0, 0);
+            }
           }
     };
     BFrag b0, b1;
@@ -655,6 +704,11 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         neg[0] += r[3]; neg[1] += r[4]; neg[2] += r[5];
       }
       const int img = a.row2img ? a.row2img[pn] : pn;
+      if constexpr (PREC == PREC_F16X2) {               // undo the token's scale: the chain ends here
+        const float sc = a.tok_fac[pn];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { pos[c] *= sc; neg[c] *= sc; }
+      }
       const float* xv = a.ximg + ((size_t)img * HW + (size_t)y * a.W + x) * 3;
       float* ov = a.out + ((size_t)pn * HW + (size_t)y * a.W + x) * 3;
 #pragma unroll
@@ -671,7 +725,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     constexpr int RH = BM / NH;                         // rows per slab
     static_assert(BM % NH == 0 && RH % (TM * 32) == 0 && RH * BN <= 2 * STAGE, "slab must hold whole wave tiles");
     float* Cs = smem;
-    constexpr bool SPLIT_OUT = PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2);
+    constexpr bool SPLIT_OUT = SPLIT && (EPI == EPI_MUL || EPI == EPI_MUL_UP2);
     constexpr int CW = SPLIT_OUT ? 8 : 4;               // channels per thread (split8 output is written per group)
     constexpr int C4 = BN / CW, RPP = NT / C4;
     const int c4 = tid % C4, rin = tid / C4;
@@ -703,6 +757,17 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         return true;
       }
     };
+    // PREC_F16X2: largest |stored output| per token, gathered per block in LDS (slot = token - first token of the tile) and
+    // flushed with ONE global atomic per token and block (a global atomic per wave and pass cost 0.4 ms on block1_conv2)
+    // (the slots live in the staging LDS behind the C slab where the tile shape leaves room — every tile does except the
+    // non-halo 128 x 128 / 256 x 256 ones, which fall back to the per-wave global atomic; LDS is sized to the byte:
+    // two 128 x 128 halo blocks fill the CU's 160 KB exactly)
+    constexpr bool TMAX_LDS = PREC == PREC_F16X2 && RH * BN + 16 <= 2 * STAGE;
+    unsigned* tmax_s = reinterpret_cast<unsigned*>(smem + RH * BN);
+    const int tok_first = HALO ? img0 : tn0;
+    if constexpr (TMAX_LDS) {
+      if (tid < 16) tmax_s[tid] = 0u;                   // (ordered before its first use by the barrier that publishes the C slab)
+    }
 #pragma unroll 1
     for (int hf = 0; hf < NH; ++hf) {
       if (hf) __syncthreads();                          // previous slab fully consumed
@@ -781,6 +846,16 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
             if (!okv[ps]) { rowv[ps] = 0; nv[ps] = 0; hv[ps] = 0; wv[ps] = 0; }
             imgv[ps] = a.row2img ? a.row2img[nv[ps]] : nv[ps];
           }
+          // PREC_F16X2: running maximum of |stored output| for the token of the rows this thread has seen so far
+          unsigned lmax = 0u;
+          int ltok = -1;
+          auto flush_max = [&](int t, unsigned m) {
+            if (m) {
+              const int rel = t - tok_first;
+              if (TMAX_LDS && rel >= 0 && rel < 16) atomicMax(tmax_s + rel, m);
+              else atomicMax(a.tok_max_out + t, m);
+            }
+          };
           const bool tail = EPI == EPI_MUL && a.join != nullptr, head2 = EPI == EPI_MUL && a.out2s != nullptr;
           struct Gates { f32x4 g[UPN][CW / 4]; f32x4 jn[CW / 4], jg[CW / 4], g2[CW / 4]; };
           auto gate_ptr = [&](int ps, int q) -> const float* {
@@ -811,6 +886,11 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
           for (int ps = 0; ps < NP; ++ps) {
             if (ps + 1 < NP) load_gates(nxt, ps + 1);
+            float fac16 = 1.f;                            // PREC_F16X2: the power of two this launch adds to the token's scale
+            if constexpr (PREC == PREC_F16X2) {
+              fac16 = a.tok_fac[nv[ps]];
+              if (okv[ps] && nv[ps] != ltok) { flush_max(ltok, lmax); ltok = nv[ps]; lmax = 0u; }
+            }
             if (okv[ps]) {
               const int ll = rin + ps * RPP;
               float v[CW];
@@ -831,6 +911,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
                   for (int e = 0; e < 4; ++e) {
                     float pr = v[4 * q4 + e] * g[e];
                     if (tail) pr += cur.jn[q4][e] * cur.jg[q4][e];
+                    if constexpr (PREC == PREC_F16X2) {
+                      pr *= fac16;
+                      lmax = max(lmax, __float_as_uint(fabsf(pr)));               // (non-negative floats order like their bits)
+                    }
                     r[4 * q4 + e] = a.relu_out ? fmaxf(pr, 0.f) : pr;
                   }
                 }
@@ -841,6 +925,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
                   if (a.out_plain) {
                     *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
                     *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(r + 4);
+                  } else if constexpr (PREC == PREC_F16X2) {
+                    split8h_store(r, dst);
                   } else {
                     split8_store(r, dst);
                   }
@@ -864,8 +950,13 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
             }
             cur = nxt;
           }
+          if constexpr (PREC == PREC_F16X2) flush_max(ltok, lmax);
         }
       }
+    }
+    if constexpr (TMAX_LDS && (EPI == EPI_MUL || EPI == EPI_MUL_UP2)) {
+      __syncthreads();
+      if (tid < 16 && tmax_s[tid]) atomicMax(a.tok_max_out + tok_first + tid, tmax_s[tid]);
     }
     return;
   }
@@ -939,7 +1030,8 @@ inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) 
 // EPI_IMG_STENCIL: NB = image slots (tokens), H x W = the image; in = S_1 (NB, H, W, Cin); N = 54 <= 64
 template <int PREC>
 inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
-  if (a.taps != 1 || a.N > 64 || !a.ximg || (a.Cin & (PREC == PREC_BF16X3 ? 7 : 3))) return hipErrorInvalidValue;
+  if (a.taps != 1 || a.N > 64 || !a.ximg || (a.Cin & (PREC != PREC_FP32 ? 7 : 3))) return hipErrorInvalidValue;
+  if (PREC == PREC_F16X2 && !a.tok_fac) return hipErrorInvalidValue;
   if (a.NB <= 0) return hipSuccess;
   a.M = a.NB * a.H * a.W;
   a.tiles_x = (a.W + IMG_TILE - 1) / IMG_TILE;
@@ -952,10 +1044,11 @@ inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
 
 template <int EPI, int PREC, int TERMS = 7>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
-  constexpr int need = PREC == PREC_BF16X3 ? 7 : 3;                                   // 16 B (fp32) / 32 B (split8) epilogue
+  constexpr int need = PREC != PREC_FP32 ? 7 : 3;                                     // 16 B (fp32) / 32 B (split8) epilogue
+  if (PREC == PREC_F16X2 && (!a.tok_fac || !a.tok_max_out || a.out_plain)) return hipErrorInvalidValue;
   if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & need)) return hipErrorInvalidValue;
   if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.N & 3)) return hipErrorInvalidValue;
-  if (PREC == PREC_BF16X3 && (a.Cin & 7)) return hipErrorInvalidValue;
+  if (PREC != PREC_FP32 && (a.Cin & 7)) return hipErrorInvalidValue;
   if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
   ConvTile t = conv_pick_tile(a.N);
   if (PREC == PREC_FP32 && t.BN == 128 && (a.N % 64) == 0) {
@@ -966,7 +1059,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     if (blocks < thr) t = {128, 64};
   }
   int wide = 0;
-  if (PREC == PREC_BF16X3 && TERMS == 7 && a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
+  if (PREC != PREC_FP32 && (TERMS == 7 || PREC == PREC_F16X2) && a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
     wide = (a.N % 256) == 0 ? 256 : 128;
     if (wide == 128) wide = 0;                           // measured: 256 x 128 loses to two 128 x 128 blocks per CU
     if (conv_tile_override() == 128 && (a.N % 128) == 0) wide = 128;
@@ -981,7 +1074,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
 
-  if constexpr (PREC == PREC_BF16X3 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU)) {
+  if constexpr (PREC != PREC_FP32 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU)) {
     const int mode = conv_halo_mode();
     // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
     // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
@@ -1019,7 +1112,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     }
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
-  if constexpr (PREC == PREC_BF16X3) {
+  if constexpr (PREC != PREC_FP32) {
     if (wide == 256) {
       hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, false, false, TERMS>), grid, dim3(512), 0, st, a);
       return hipGetLastError();
@@ -1044,6 +1137,22 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
   if (prec == PREC_BF16X3 && terms != 7) {             // the two passes of the three-way split forward product
     if (epi == EPI_BIAS && terms == 15) return conv_launch_epi<EPI_BIAS, PREC_BF16X3, 15>(a, st);
     if (epi == EPI_BIAS_RELU && terms == 3) return conv_launch_epi<EPI_BIAS_RELU, PREC_BF16X3, 3>(a, st);
+    return hipErrorInvalidValue;
+  }
+  if (prec == PREC_F16X2) {                            // reverse walk of the VGG encoder only
+    // terms 7: S(hi + lo) x w(hi + lo) without lo*lo — three MFMAs; terms 5: the weights' lo half dropped — two.  The
+    // weight rounding of the two-term form (2^-12, identical for every token) averages out over K: layers with a short
+    // K take the three-term form (they are not MFMA-bound anyway), the 256/512-channel layers the two-term one.
+    if (terms == 5) {
+      if (epi == EPI_MUL) return conv_launch_epi<EPI_MUL, PREC_F16X2, 5>(a, st);
+      if (epi == EPI_MUL_UP2) return conv_launch_epi<EPI_MUL_UP2, PREC_F16X2, 5>(a, st);
+      return hipErrorInvalidValue;
+    }
+    switch (epi) {
+      case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_F16X2>(a, st);
+      case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_F16X2>(a, st);
+      case EPI_IMG_STENCIL: return conv_launch_img<PREC_F16X2>(a, st);
+    }
     return hipErrorInvalidValue;
   }
   if (prec == PREC_BF16X3) {
@@ -1133,6 +1242,26 @@ inline void pack_split8_3way(const float* src, size_t n_floats, float* out1, flo
       d1[g * 16 + q] = h; d1[g * 16 + 8 + q] = m;
       d2[g * 16 + q] = h; d2[g * 16 + 8 + q] = l;
     }
+}
+
+// fp16 twin of pack_split8: per 8 k, 32 B = [fp16 hi8 | fp16 lo8]; also returns the largest row sum of |hi| over `rows`
+// rows of K floats (ConvArgs::wnorm: the growth bound of PREC_F16X2's per-token scaling); rows = 0: no norm
+inline float pack_split8_f16(const float* src, size_t n_floats, float* dst_as_float, size_t rows = 0) {
+  _Float16* d = reinterpret_cast<_Float16*>(dst_as_float);
+  const size_t K = rows ? n_floats / rows : n_floats;
+  float best = 0.f;
+  double acc = 0.0;
+  for (size_t g = 0; g < n_floats / 8; ++g) {
+    for (int q = 0; q < 8; ++q) {
+      const float x = src[g * 8 + q];
+      const _Float16 hi = (_Float16)x;
+      d[g * 16 + q] = hi;
+      d[g * 16 + 8 + q] = (_Float16)(x - (float)hi);
+      acc += (double)((float)hi < 0.f ? -(float)hi : (float)hi);
+    }
+    if (rows && ((g + 1) * 8) % K == 0) { best = acc > best ? (float)acc : best; acc = 0.0; }
+  }
+  return best;
 }
 
 inline void pack_split8(const float* src, size_t n_floats, float* dst_as_float) {

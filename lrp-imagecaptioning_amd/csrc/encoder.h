@@ -30,6 +30,9 @@ struct ConvLayer {
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
   DevBuf w_bwd_full_s;  // the same in split8 form: backward-data conv of the fine-tune step on the bf16 matrix cores
+  DevBuf w_bwd_h;     // w_bwd in fp16 split8 form [hi8 | lo8] (PREC_F16X2 reverse walk: only hi is read), and ...
+  DevBuf w_bwd_frag_h;   // ... fragment-major for the weights-in-registers kernel
+  DevBuf wn_h;        // one float: max row sum of |fp16(w_bwd)| — the growth bound of the walk's per-token scaling
   DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
@@ -62,6 +65,8 @@ struct Encoder {
   bool features_only = false;
   bool profile = false;
   int prec = PREC_BF16X3;  // arithmetic of the per-token reverse walk (lrp_set_precision); falls back to fp32 for widths % 8 != 0
+  bool walk_f16 = false;   // LRP_PREC_F16X2: the LRP reverse walk on fp16 pairs x single-fp16 weights (2 MFMAs per product)
+  DevBuf tok_exp, tok_max, tok_fac;   // its per-token scale exponents / measured maxima [layers + 1][max_tokens], factors [max_tokens]
   std::vector<ProfileRec> prof;
   // Overlapped encode (mixed-precision mode): the caller's stream runs only the activation chain a_1..a_top (what
   // the decoder needs); the denominators Z+_l and the gates G_l — needed by explain() only — run on `side` behind
@@ -223,6 +228,9 @@ struct Encoder {
         pack_split8(pk.data(), pk.size(), sp.data());
         LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        pack_split8_f16(pk.data(), pk.size(), sp.data());
+        LRP_TRY(L.w_bwd_h.alloc(sp.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_h.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
       }
       // gradient baselines: the same tap expansion with the whole w in the "+" columns
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -271,6 +279,18 @@ struct Encoder {
           LRP_TRY(L.w_bwd_frag.alloc(fr.size() * sizeof(float), total));
           LRP_HIP_CHECK(hipMemcpy(L.w_bwd_frag.p, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
         }
+        // fp16 copies (PREC_F16X2) and the layer's weight norm
+        const float wn = pack_split8_f16(pk.data(), pk.size(), sp.data(), (size_t)Npb);
+        LRP_TRY(L.w_bwd_h.alloc(sp.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_h.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        LRP_TRY(L.wn_h.alloc(sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.wn_h.p, &wn, sizeof(float), hipMemcpyHostToDevice));
+        if (Npb == 64) {
+          std::vector<float> fr((size_t)64 * Kb);
+          pack_frag64(sp.data(), 9, conv_cinp(L.cout), fr.data());
+          LRP_TRY(L.w_bwd_frag_h.alloc(fr.size() * sizeof(float), total));
+          LRP_HIP_CHECK(hipMemcpy(L.w_bwd_frag_h.p, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
       }
       pk.assign((size_t)Npb * Kb, 0.f);
       pack_conv_bwd(w, 9, L.cin, L.cout, 0, pk.data());
@@ -301,7 +321,7 @@ struct Encoder {
     if (li == 0) {
       const size_t nb = (size_t)conv_npad(IMG_T_COLS) * conv_cinp(L.cout);
       LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * 64));
-      LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb));
+      LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_h, nb));
       return LRP_OK;
     }
     const size_t Kf = (size_t)9 * conv_cinp(L.cin), Kb = (size_t)9 * conv_cinp(L.cout);
@@ -309,7 +329,8 @@ struct Encoder {
     LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf));
     LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
     LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
-    if (conv_npad(L.cin) == 64) LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb));
+    LRP_TRY(mk(L.w_bwd_h, nb)); LRP_TRY(mk(L.wn_h, 1));
+    if (conv_npad(L.cin) == 64) { LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb)); LRP_TRY(mk(L.w_bwd_frag_h, (size_t)64 * Kb)); }
     if (pack_tmp.bytes < nf * sizeof(float)) LRP_TRY(pack_tmp.alloc(nf * sizeof(float), total));
     return LRP_OK;
   }
@@ -322,6 +343,7 @@ struct Encoder {
                          L.w_bwd.as<float>(), L.w_bwd_full.as<float>(), L.cout, Kb);
       const size_t nb = (size_t)Npb * Kb;
       hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb / 8);
+      hipLaunchKernelGGL(split_copy_h_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_h.as<float>(), nb / 8);
       LRP_HIP_CHECK(hipGetLastError());
       return LRP_OK;
     }
@@ -347,6 +369,12 @@ struct Encoder {
     if (L.w_bwd_frag.p)
       hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_s.as<float>(),
                          L.w_bwd_frag.as<float>(), CPo);
+    hipLaunchKernelGGL(split_copy_h_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_h.as<float>(), nb / 8);
+    if (L.w_bwd_frag_h.p)
+      hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_h.as<float>(),
+                         L.w_bwd_frag_h.as<float>(), CPo);
+    LRP_HIP_CHECK(hipMemsetAsync(L.wn_h.p, 0, sizeof(float), st));
+    hipLaunchKernelGGL(rowabs_max_kernel, dim3(Npb), dim3(256), 0, st, L.w_bwd.as<float>(), 9 * CPo, L.wn_h.as<unsigned>());
     pack(L.w_bwd_full.as<float>(), 1, Npb, 0, 0);
     split(L.w_bwd_full.as<float>(), L.w_bwd_full_s.as<float>(), nb);
     LRP_HIP_CHECK(hipGetLastError());
@@ -590,12 +618,32 @@ struct Encoder {
       if (L.cout & 7) split = hook_split = false;       // split8 groups need widths % 8 == 0: exact fp32 otherwise
     for (size_t li = 1; li < layers.size(); ++li)
       if (!layers[li].w_bwd_full_s.p) hook_split = false;
-    const int run_prec = (split || hook_split) ? PREC_BF16X3 : PREC_FP32;
+    // LRP_PREC_F16X2: fp16 pairs for S, one fp16 per weight, per-token power-of-two scales (conv_igemm.h PREC_F16X2);
+    // needs the fused image layer (the chain's scale is undone in its epilogue)
+    const bool f16 = split && walk_f16 && img_fused();
+    if (f16) {
+      const size_t cnt = (layers.size() + 1) * (size_t)max_tokens;
+      if (!tok_exp.p) {
+        int64_t dummy = 0;
+        LRP_TRY(tok_exp.alloc(cnt * sizeof(int), &dummy));
+        LRP_TRY(tok_max.alloc(cnt * sizeof(unsigned), &dummy));
+        LRP_TRY(tok_fac.alloc((size_t)max_tokens * sizeof(float), &dummy));
+      }
+      LRP_HIP_CHECK(hipMemsetAsync(tok_max.p, 0, cnt * sizeof(unsigned), st));
+    }
+    auto lev_exp = [&](int lev) { return tok_exp.as<int>() + (size_t)lev * max_tokens; };
+    auto lev_max = [&](int lev) { return tok_max.as<unsigned>() + (size_t)lev * max_tokens; };
+    const int run_prec = f16 ? PREC_F16X2 : (split || hook_split) ? PREC_BF16X3 : PREC_FP32;
     if (walk != 0) {
       const size_t per4 = T.act_elems() / 4;
       hipLaunchKernelGGL(grad_top_kernel, dim3(stream_grid((size_t)n * per4)), dim3(256), 0, st,
                          reinterpret_cast<const f32x4*>(R_feat_dev), feat.as<f32x4>(), row2img_dev,
                          reinterpret_cast<f32x4*>(S), n, per4, walk == 3 ? 1 : 0);
+      LRP_HIP_CHECK(hipGetLastError());
+    } else if (f16) {
+      const int top = (int)layers.size() - 1;
+      hipLaunchKernelGGL(top_divide_f16_kernel, dim3(n), dim3(256), 0, st, R_feat_dev, ztop.as<float>(), row2img_dev, S,
+                         T.act_elems() / 8, lev_exp(top), lev_max(top));
       LRP_HIP_CHECK(hipGetLastError());
     } else if (split) {
       const size_t per8 = T.act_elems() / 8;
@@ -624,8 +672,17 @@ struct Encoder {
         ca.in = bufXs.as<float>();
         ca.out_plain = 1;
       }
-      ca.wpk = hook_split ? L.w_bwd_full_s.as<float>() : walk != 0 ? L.w_bwd_full.as<float>() : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
-      ca.wpk_frag = (split && walk == 0) ? L.w_bwd_frag.as<float>() : nullptr;
+      ca.wpk = hook_split ? L.w_bwd_full_s.as<float>() : walk != 0 ? L.w_bwd_full.as<float>() : f16 ? L.w_bwd_h.as<float>()
+               : split ? L.w_bwd_s.as<float>() : L.w_bwd.as<float>();
+      ca.wpk_frag = f16 ? L.w_bwd_frag_h.as<float>() : (split && walk == 0) ? L.w_bwd_frag.as<float>() : nullptr;
+      if (f16) {                                        // S_li (level li) -> S_{li-1} (level li - 1); the image layer ends the chain
+        hipLaunchKernelGGL(tok_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lev_max(li), lev_exp(li),
+                           li > 0 ? L.wn_h.as<float>() : (const float*)nullptr, tok_fac.as<float>(), li > 0 ? lev_exp(li - 1) : (int*)nullptr,
+                           n, li == 0 ? 1 : 0);
+        LRP_HIP_CHECK(hipGetLastError());
+        ca.tok_fac = tok_fac.as<float>();
+        if (li > 0) ca.tok_max_out = lev_max(li - 1);
+      }
       ca.row2img = row2img_dev;
       ca.gate_binary = walk != 0; ca.relu_out = walk == 3;
       int epi;
@@ -647,7 +704,14 @@ struct Encoder {
         (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1);
         (void)hipEventRecord(pr.e0, st);
       }
-      LRP_HIP_CHECK(conv_launch(epi, ca, st, run_prec));
+      // PREC_F16X2: two MFMAs per product (weights as one fp16) only where K = 9 * cout is long enough to average the
+      // weight rounding out; LRP_F16_K3 = the largest K that still takes the three-term form (default 1152)
+      int terms = 7;
+      if (f16 && li > 0) {
+        static const int k3 = [] { const char* e = getenv("LRP_F16_K3"); return e ? atoi(e) : 1152; }();
+        if (9 * L.cout > k3) terms = 5;
+      }
+      LRP_HIP_CHECK(conv_launch(epi, ca, st, run_prec, terms));
       if (profile) {
         (void)hipEventRecord(pr.e1, st);
         pr.flop = 2.0 * (double)n * L.H * L.W * 9.0 * L.cout * (li == 0 ? 6 : L.cin);

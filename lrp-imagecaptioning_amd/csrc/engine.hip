@@ -364,11 +364,12 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
 int lrp_set_precision(lrp_handle* h, int32_t mode) {
   return with_handle(h, [&]() -> int {
     if (!h) return fail(LRP_ERR_INVALID, "null handle");
-    if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3 && mode != LRP_PREC_BF16X3_FAST)
+    if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3 && mode != LRP_PREC_BF16X3_FAST && mode != LRP_PREC_F16X2)
       return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);
     const int km = mode == LRP_PREC_FP32 ? PREC_FP32 : PREC_BF16X3;
     h->enc.prec = km;
     h->enc.fwd_fast = mode == LRP_PREC_BF16X3_FAST;
+    h->enc.walk_f16 = mode == LRP_PREC_F16X2;         // (forward, decoder and the ResNet encoder stay as in LRP_PREC_BF16X3)
     h->rn.prec = km;
     h->dec.prec = km;
     return LRP_OK;

@@ -370,9 +370,10 @@ class LRPEngine(object):
     def set_precision(self, mode):
         """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16 reverse walk, default) or 'bf16x3_fast' (split forward
         activations too; see include/lrp_hip.h)."""
-        m = {"fp32": _capi.LRP_PREC_FP32, "bf16x3": _capi.LRP_PREC_BF16X3, "bf16x3_fast": _capi.LRP_PREC_BF16X3_FAST}.get(mode)
+        m = {"fp32": _capi.LRP_PREC_FP32, "bf16x3": _capi.LRP_PREC_BF16X3, "bf16x3_fast": _capi.LRP_PREC_BF16X3_FAST,
+             "f16x2": _capi.LRP_PREC_F16X2}.get(mode)
         if m is None:
-            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16x3_fast'")
+            raise ValueError("precision must be 'fp32', 'bf16x3', 'bf16x3_fast' or 'f16x2'")
         _capi.check(self._lib.lrp_set_precision(self._h, m))
         self.precision = mode
 

@@ -62,7 +62,7 @@ def config1():
     return w, batches, refs
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("prec", ["bf16x3", "fp32", "f16x2"])
 def test_config1_b32_two_handles_matches_oracle_and_small_batch(config1, prec):
     from lrp_imagecaptioning_amd.engine import LRPEngine
     from lrp_imagecaptioning_amd.pipeline import LRPPipeline
@@ -86,7 +86,8 @@ def test_config1_b32_two_handles_matches_oracle_and_small_batch(config1, prec):
     for (k, b, t), ref in refs.items():
         errs[(k, b, t)] = rel_l1(outs[k][b * T + t - 1].cpu().numpy(), ref)
     report("config1_b32_oracle_" + prec, max_rel_l1=max(errs.values()), samples=len(errs))
-    assert max(errs.values()) < TOL, errs
+    # (f16x2 is the opt-in two-MFMA mode: measured 1.0e-4 here — at the bar, no margin — and held to 2e-4)
+    assert max(errs.values()) < (2e-4 if prec == "f16x2" else TOL), errs
     # (b) every heat-map vs its image explained alone on a B = 1 handle (small-tile kernels)
     solo = LRPEngine(decoder="adaptive", V=V, max_images=1, max_tokens=T, max_caption_len=T + 1)
     solo.set_precision(prec)
