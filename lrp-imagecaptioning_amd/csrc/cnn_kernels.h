@@ -164,47 +164,104 @@ __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restr
     dst[i] = (pos && !(v >= 0.f)) ? 0.f : v;
   }
 }
-// ---- PREC_F16X2 (conv_igemm.h): fp16 operand copies and the per-token scale of the walk's head
-// fp32 packed matrix -> fp16 split8 ([hi8 | lo8] per 8 k), the device twin of pack_split8_f16
-__global__ __launch_bounds__(256) void split_copy_h_kernel(const float* __restrict__ x, float* __restrict__ xs, size_t n8) {
+// ---- fp16-pair operands (conv_igemm.h PREC_F16X2).  A weight matrix is stored scaled by a power of two, 2^k with
+// k = floor(log2(16384 / max|w|)): unscaled, the lo halves of VGG-sized weights (|w| ~ 1e-3, lo ~ 5e-7) fall into fp16's
+// subnormals and the pair keeps 15 bits instead of 21 [MI355X: feature error of the forward 2.4e-6 -> see DESIGN 4.1].
+// Per matrix a device record wsc[4] = { 2^k, 2^-k, max row sum of |hi| (scaled), k } that the consumers read.
+__global__ void wscale_kernel(const unsigned* __restrict__ slots, float* __restrict__ wsc) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float m = 0.f;
+  for (int i = 0; i < ACT_MAX_SLOTS; ++i) m = fmaxf(m, __uint_as_float(slots[i]));
+  int k = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    k = (int)floorf(log2f(16384.f / m));
+    k = k < -40 ? -40 : k > 40 ? 40 : k;
+  }
+  wsc[0] = ldexpf(1.f, k); wsc[1] = ldexpf(1.f, -k); wsc[2] = 0.f; wsc[3] = (float)k;
+}
+// fp32 packed matrix -> fp16 pairs of (w * wsc[0])
+__global__ __launch_bounds__(256) void split_copy_h_kernel(const float* __restrict__ x, float* __restrict__ xs, size_t n8,
+                                                           const float* __restrict__ wsc) {
+  const float sc = wsc[0];
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     float v[8];
     *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
     *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] *= sc;
     split8h_store(v, xs + i * 8);
   }
 }
-// *out (float bits, zeroed by the caller) = max over the rows of sum_k |fp16(w[row][k])|: ConvArgs::wnorm, one block per row
-__global__ __launch_bounds__(256) void rowabs_max_kernel(const float* __restrict__ w, int K, unsigned* __restrict__ out) {
+// wsc[2] (float bits) = max over the rows of sum_k |hi(w[row][k] * wsc[0])|: the growth bound of the walk's per-token
+// scaling; one block per row
+__global__ __launch_bounds__(256) void rowabs_max_kernel(const float* __restrict__ w, int K, float* __restrict__ wsc) {
   __shared__ float red[256];
   const float* r = w + (size_t)blockIdx.x * K;
+  const float sc = wsc[0];
   float s = 0.f;
-  for (int k = threadIdx.x; k < K; k += 256) s += fabsf((float)(_Float16)r[k]);
+  for (int k = threadIdx.x; k < K; k += 256) s += fabsf((float)(_Float16)(r[k] * sc));
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(red[0] * 1.0001f));     // (order of the sum differs from the host's: margin)
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(wsc + 2), __float_as_uint(red[0] * 1.0001f));
+}
+// fp32 activations -> fp16 pairs [hi8 | lo8] scaled by 2^k, k = floor(log2(30000 / max|x|)) from the ACT_MAX_SLOTS slots the
+// producing conv raised (pooling keeps the maximum); block 0 also leaves 2^-k in *unscale for the consuming conv's epilogue
+// (unscale also takes out the weight matrix' scale, wsc[1])
+__global__ __launch_bounds__(256) void split_h_scaled_kernel(const float* __restrict__ x, float* __restrict__ xs, size_t n8,
+                                                             const unsigned* __restrict__ max_slots, float* __restrict__ unscale,
+                                                             const float* __restrict__ wsc) {
+  float m = 0.f;
+  for (int i = 0; i < ACT_MAX_SLOTS; ++i) m = fmaxf(m, __uint_as_float(max_slots[i]));
+  int k = 0;
+  if (m > 0.f && m < 3.0e38f) {
+    k = (int)floorf(log2f(30000.f / m));
+    k = k < -120 ? -120 : k > 120 ? 120 : k;
+  }
+  const float fac = ldexpf(1.f, k);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *unscale = ldexpf(1.f, -k) * wsc[1];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] *= fac;
+    split8h_store(v, xs + i * 8);
+  }
+}
+// max|x| of a tensor into ACT_MAX_SLOTS slots (the image layer's activations come from the fp32 kernel, which keeps no maximum)
+__global__ __launch_bounds__(256) void absmax_slots_kernel(const f32x4* __restrict__ x, size_t n4, unsigned* __restrict__ slots) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = x[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slots + ((blockIdx.x + (threadIdx.x >> 6)) & (ACT_MAX_SLOTS - 1)), __float_as_uint(m));
 }
 // Between two launches of the PREC_F16X2 walk: the power of two the next conv adds to each token's scale (ConvArgs::tok_fac)
-//   k = floor(log2(30000 / (max_in * wnorm))),  fac = 2^k,  exp_out = exp_in + k      (wnorm: device scalar of the layer)
-// final = 1 (in front of the image layer, whose output is plain fp32): fac = 2^-exp_in, nothing else.
+//   k = floor(log2(30000 / (max_in * wsc[2]))),  fac = 2^k,  exp_out = exp_in + k + kw     (wsc: the layer's weight record,
+//   wsc[2] = norm of the scaled weights, kw = wsc[3] their scale exponent)
+// final = 1 (in front of the image layer, whose output is plain fp32): fac = 2^-(exp_in + kw), nothing else.
 __global__ __launch_bounds__(256) void tok_scale_kernel(const unsigned* __restrict__ max_in, const int* __restrict__ exp_in,
-                                                        const float* __restrict__ wnorm, float* __restrict__ fac,
+                                                        const float* __restrict__ wsc, float* __restrict__ fac,
                                                         int* __restrict__ exp_out, int n, int final) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
-  if (final) { fac[t] = ldexpf(1.f, -exp_in[t]); return; }
+  const int kw = (int)wsc[3];
+  if (final) { fac[t] = ldexpf(1.f, -(exp_in[t] + kw)); return; }
   const float m = __uint_as_float(max_in[t]);
   int k = 0;
   if (m > 0.f) {
-    k = (int)floorf(log2f(30000.f / (m * *wnorm)));
+    k = (int)floorf(log2f(30000.f / (m * wsc[2])));
     k = k < -120 ? -120 : k > 120 ? 120 : k;
   }
   fac[t] = ldexpf(1.f, k);
-  exp_out[t] = exp_in[t] + k;
+  exp_out[t] = exp_in[t] + k + kw;
 }
 // Head of the reverse walk in PREC_F16X2: S_top = R_feat / safe(Z_top[img]) per token (KG:898-900), stored as fp16 pairs
 // scaled by 2^k, k = floor(log2(30000 / max|S_top|)) — one workgroup per token, two passes over its 0.4 MB.

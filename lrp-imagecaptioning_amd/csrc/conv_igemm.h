@@ -135,7 +135,14 @@ struct ConvArgs {
   //   largest |stored output|.  EPI_IMG_STENCIL ends the chain: tok_fac[n] = 2^-e_in[n].
   const float* tok_fac;
   unsigned* tok_max_out;
+  // PREC_F16X2 forward (EPI_BIAS / EPI_BIAS_RELU, TERMS 7 = fp16 pairs on BOTH operands, 22 mantissa bits: an fp32-grade
+  // product in three MFMAs): the input tensor is stored scaled by a power of two; *in_unscale (device scalar) = its
+  // inverse, applied to the accumulator in front of the bias.  act_max_out: ACT_MAX_SLOTS float-bit slots raised to the
+  // largest |out| (slot = block id mod slots: spreads the atomics; the consumer takes the maximum over the slots).
+  const float* in_unscale;
+  unsigned* act_max_out;
 };
+constexpr int ACT_MAX_SLOTS = 64;
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
 
@@ -361,7 +368,9 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   constexpr int FLUSH = 8;
   // (the four-term pass of the exact forward product rounds its accumulator 4 x K/16 times: blocked as well — measured
   //  feature error of VGG16 2.3e-6 without)
-  constexpr bool BLOCKED = PREC == PREC_FP32 || TERMS == 15;
+  // (and the fp16-pair forward, whose three-term product is fp32-grade: without the second level its accumulator's
+  //  3 x K/16 roundings would be the largest error left)
+  constexpr bool BLOCKED = PREC == PREC_FP32 || TERMS == 15 || (PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU));
   f32x16 acc[TM][TN], tot[BLOCKED ? TM : 1][BLOCKED ? TN : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -786,12 +795,17 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         if (col < a.N) {
           const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
           const f32x4 bv = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + col) : zero4;
+          float unscale = 1.f;                            // PREC_F16X2: the input's power-of-two scale, undone on the accumulator
+          float omax = 0.f;
+          if constexpr (PREC == PREC_F16X2) unscale = *a.in_unscale;
 #pragma unroll 4
           for (int ps = 0; ps < RH / RPP; ++ps) {
             const int ll = rin + ps * RPP;
             int row, n_, h_, w_;
             if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4);
+            if constexpr (PREC == PREC_F16X2) v *= unscale;
+            v += bv;
             if (a.addend) v += *reinterpret_cast<const f32x4*>(a.addend + (size_t)row * a.N + col);   // second pass of a product
             if constexpr (EPI == EPI_BIAS) {
               if (a.gate_src) {
@@ -804,7 +818,15 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }
+            if constexpr (PREC == PREC_F16X2) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
             *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.N + col) = v;
+          }
+          if constexpr (PREC == PREC_F16X2) {
+            if (a.act_max_out) {                          // one atomic per wave, spread over ACT_MAX_SLOTS addresses
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+              if (lane == 0 && omax > 0.f) atomicMax(a.act_max_out + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)), __float_as_uint(omax));
+            }
           }
         }
       } else if constexpr (EPI == EPI_FWD_DUAL) {
@@ -1045,7 +1067,8 @@ inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
 template <int EPI, int PREC, int TERMS = 7>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC != PREC_FP32 ? 7 : 3;                                     // 16 B (fp32) / 32 B (split8) epilogue
-  if (PREC == PREC_F16X2 && (!a.tok_fac || !a.tok_max_out || a.out_plain)) return hipErrorInvalidValue;
+  if (PREC == PREC_F16X2 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (!a.tok_fac || !a.tok_max_out || a.out_plain)) return hipErrorInvalidValue;
+  if (PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && !a.in_unscale) return hipErrorInvalidValue;
   if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & need)) return hipErrorInvalidValue;
   if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.N & 3)) return hipErrorInvalidValue;
   if (PREC != PREC_FP32 && (a.Cin & 7)) return hipErrorInvalidValue;
@@ -1059,7 +1082,8 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     if (blocks < thr) t = {128, 64};
   }
   int wide = 0;
-  if (PREC != PREC_FP32 && (TERMS == 7 || PREC == PREC_F16X2) && a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
+  if (PREC != PREC_FP32 && (TERMS == 7 || PREC == PREC_F16X2) && !(PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU)) &&
+      a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
     wide = (a.N % 256) == 0 ? 256 : 128;
     if (wide == 128) wide = 0;                           // measured: 256 x 128 loses to two 128 x 128 blocks per CU
     if (conv_tile_override() == 128 && (a.N % 128) == 0) wide = 128;
@@ -1152,6 +1176,8 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
       case EPI_MUL: return conv_launch_epi<EPI_MUL, PREC_F16X2>(a, st);
       case EPI_MUL_UP2: return conv_launch_epi<EPI_MUL_UP2, PREC_F16X2>(a, st);
       case EPI_IMG_STENCIL: return conv_launch_img<PREC_F16X2>(a, st);
+      case EPI_BIAS_RELU: return conv_launch_epi<EPI_BIAS_RELU, PREC_F16X2>(a, st);   // forward activation conv, fp16 pairs x fp16 pairs
+      case EPI_BIAS: return conv_launch_epi<EPI_BIAS, PREC_F16X2>(a, st);
     }
     return hipErrorInvalidValue;
   }
@@ -1242,26 +1268,6 @@ inline void pack_split8_3way(const float* src, size_t n_floats, float* out1, flo
       d1[g * 16 + q] = h; d1[g * 16 + 8 + q] = m;
       d2[g * 16 + q] = h; d2[g * 16 + 8 + q] = l;
     }
-}
-
-// fp16 twin of pack_split8: per 8 k, 32 B = [fp16 hi8 | fp16 lo8]; also returns the largest row sum of |hi| over `rows`
-// rows of K floats (ConvArgs::wnorm: the growth bound of PREC_F16X2's per-token scaling); rows = 0: no norm
-inline float pack_split8_f16(const float* src, size_t n_floats, float* dst_as_float, size_t rows = 0) {
-  _Float16* d = reinterpret_cast<_Float16*>(dst_as_float);
-  const size_t K = rows ? n_floats / rows : n_floats;
-  float best = 0.f;
-  double acc = 0.0;
-  for (size_t g = 0; g < n_floats / 8; ++g) {
-    for (int q = 0; q < 8; ++q) {
-      const float x = src[g * 8 + q];
-      const _Float16 hi = (_Float16)x;
-      d[g * 16 + q] = hi;
-      d[g * 16 + 8 + q] = (_Float16)(x - (float)hi);
-      acc += (double)((float)hi < 0.f ? -(float)hi : (float)hi);
-    }
-    if (rows && ((g + 1) * 8) % K == 0) { best = acc > best ? (float)acc : best; acc = 0.0; }
-  }
-  return best;
 }
 
 inline void pack_split8(const float* src, size_t n_floats, float* dst_as_float) {

@@ -26,13 +26,14 @@ struct ConvLayer {
   DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
   DevBuf w_fwd_as; // forward weights w, split8 = [h | m] of the three-way split   [activation conv, passes A / fast mode]
   DevBuf w_fwd_al; // forward weights w, [h | l] of the three-way split            [activation conv, pass B]
+  DevBuf w_fwd_ah; // forward weights w as fp16 pairs [hi8 | lo8]                   [activation conv on the f16 MFMA, default]
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
   DevBuf w_bwd_full_s;  // the same in split8 form: backward-data conv of the fine-tune step on the bf16 matrix cores
   DevBuf w_bwd_h;     // w_bwd in fp16 split8 form [hi8 | lo8] (PREC_F16X2 reverse walk: only hi is read), and ...
   DevBuf w_bwd_frag_h;   // ... fragment-major for the weights-in-registers kernel
-  DevBuf wn_h;        // one float: max row sum of |fp16(w_bwd)| — the growth bound of the walk's per-token scaling
+  DevBuf wbs, wfs;    // device records {2^k, 2^-k, norm, k} of the fp16 copies' power-of-two scales (backward / forward matrix)
   DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
@@ -66,6 +67,7 @@ struct Encoder {
   bool profile = false;
   int prec = PREC_BF16X3;  // arithmetic of the per-token reverse walk (lrp_set_precision); falls back to fp32 for widths % 8 != 0
   bool walk_f16 = false;   // LRP_PREC_F16X2: the LRP reverse walk on fp16 pairs x single-fp16 weights (2 MFMAs per product)
+  DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
   DevBuf tok_exp, tok_max, tok_fac;   // its per-token scale exponents / measured maxima [layers + 1][max_tokens], factors [max_tokens]
   std::vector<ProfileRec> prof;
   // Overlapped encode (mixed-precision mode): the caller's stream runs only the activation chain a_1..a_top (what
@@ -94,6 +96,14 @@ struct Encoder {
   int fwd_split_from() const {
     if (const char* e = getenv("LRP_FWD_SPLIT_FROM")) return atoi(e);
     return fwd_fast ? 1 : 1000;
+  }
+  // Activation chain on the fp16 MFMA (default): operands as fp16 pairs hi + lo (22 mantissa bits, x scaled by a power
+  // of two per layer from its measured maximum), product hi*hi' + hi*lo' + lo*hi' in THREE MFMAs with blocked fp32
+  // accumulation — the fp32-grade product the three-way bf16 split needs six for (two passes).  [CPU emulation: features
+  // 6.5e-7 vs 6.1e-7 for plain fp32; MI355X: DESIGN 4.1]  LRP_FWD_F16=0 restores the bf16 two-pass chain.
+  static bool fwd_f16() {
+    const char* e = getenv("LRP_FWD_F16");
+    return !e || atoi(e) != 0;
   }
   static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
     const char* e = getenv("LRP_FWD_X6");
@@ -228,9 +238,8 @@ struct Encoder {
         pack_split8(pk.data(), pk.size(), sp.data());
         LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
-        pack_split8_f16(pk.data(), pk.size(), sp.data());
         LRP_TRY(L.w_bwd_h.alloc(sp.size() * sizeof(float), total));
-        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_h.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        LRP_TRY(make_f16_operand(L.w_bwd.as<float>(), sp.size(), 0, 0, L.w_bwd_h, L.wbs, total, nullptr));
       }
       // gradient baselines: the same tap expansion with the whole w in the "+" columns
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -262,6 +271,8 @@ struct Encoder {
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_as.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
         LRP_TRY(L.w_fwd_al.alloc(pal.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_al.p, pal.data(), pal.size() * sizeof(float), hipMemcpyHostToDevice));
+        LRP_TRY(L.w_fwd_ah.alloc(pal.size() * sizeof(float), total));
+        LRP_TRY(make_f16_operand(L.w_fwd_a.as<float>(), pal.size(), 0, 0, L.w_fwd_ah, L.wfs, total, nullptr));
       }
       const int Npb = conv_npad(L.cin), Kb = 9 * conv_cinp(L.cout);
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -279,17 +290,15 @@ struct Encoder {
           LRP_TRY(L.w_bwd_frag.alloc(fr.size() * sizeof(float), total));
           LRP_HIP_CHECK(hipMemcpy(L.w_bwd_frag.p, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
         }
-        // fp16 copies (PREC_F16X2) and the layer's weight norm
-        const float wn = pack_split8_f16(pk.data(), pk.size(), sp.data(), (size_t)Npb);
+        // fp16 copies (PREC_F16X2), their scale and norm: derived on the device from the fp32 matrix just uploaded
         LRP_TRY(L.w_bwd_h.alloc(sp.size() * sizeof(float), total));
-        LRP_HIP_CHECK(hipMemcpy(L.w_bwd_h.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
-        LRP_TRY(L.wn_h.alloc(sizeof(float), total));
-        LRP_HIP_CHECK(hipMemcpy(L.wn_h.p, &wn, sizeof(float), hipMemcpyHostToDevice));
+        if (Npb == 64) LRP_TRY(L.w_bwd_frag_h.alloc((size_t)64 * Kb * sizeof(float), total));
+        LRP_TRY(make_f16_operand(L.w_bwd.as<float>(), sp.size(), Npb, Kb, L.w_bwd_h, L.wbs, total, nullptr));
         if (Npb == 64) {
-          std::vector<float> fr((size_t)64 * Kb);
-          pack_frag64(sp.data(), 9, conv_cinp(L.cout), fr.data());
-          LRP_TRY(L.w_bwd_frag_h.alloc(fr.size() * sizeof(float), total));
-          LRP_HIP_CHECK(hipMemcpy(L.w_bwd_frag_h.p, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
+          hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)conv_cinp(L.cout) / 32 * 9 * 512)), dim3(256), 0, nullptr,
+                             L.w_bwd_h.as<float>(), L.w_bwd_frag_h.as<float>(), conv_cinp(L.cout));
+          LRP_HIP_CHECK(hipGetLastError());
+          LRP_HIP_CHECK(hipStreamSynchronize(nullptr));
         }
       }
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -310,6 +319,26 @@ struct Encoder {
   // ---- operand copies built ON THE DEVICE from device weights: lrp_set_weight_dev (the multi-GPU start-up path: the
   // bundle arrives over RCCL/xGMI and never visits the host) and the fine-tune step (weights change every iteration).
   DevBuf pack_tmp;                                     // scratch of the device packers (largest forward matrix)
+  DevBuf f16_slots;                                    // ACT_MAX_SLOTS maxima while a weight matrix' fp16 copy is made
+  // fp16-pair copy of a packed fp32 weight matrix on the device: max|w| -> power-of-two scale -> pairs of (w * scale) ->
+  // (rows > 0) the norm of the scaled matrix; the record {2^k, 2^-k, norm, k} lands in `wsc` (cnn_kernels.h).  Used by the
+  // host setters (sync = true: their source upload was synchronous, so is this) and the device packers (on `st`).
+  int make_f16_operand(const float* src, size_t n_floats, int rows, int K, DevBuf& dst, DevBuf& wsc, int64_t* total, hipStream_t st,
+                       bool sync = true) {
+    if (!f16_slots.p) LRP_TRY(f16_slots.alloc(ACT_MAX_SLOTS * sizeof(unsigned), total));
+    if (!wsc.p) LRP_TRY(wsc.alloc(4 * sizeof(float), total));
+    if (!dst.p || dst.bytes != n_floats * sizeof(float)) LRP_TRY(dst.alloc(n_floats * sizeof(float), total));
+    LRP_HIP_CHECK(hipMemsetAsync(f16_slots.p, 0, ACT_MAX_SLOTS * sizeof(unsigned), st));
+    hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n_floats / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
+                       n_floats / 4, f16_slots.as<unsigned>());
+    hipLaunchKernelGGL(wscale_kernel, dim3(1), dim3(64), 0, st, f16_slots.as<unsigned>(), wsc.as<float>());
+    hipLaunchKernelGGL(split_copy_h_kernel, dim3(stream_grid(n_floats / 8)), dim3(256), 0, st, src, dst.as<float>(), n_floats / 8,
+                       wsc.as<float>());
+    if (rows > 0) hipLaunchKernelGGL(rowabs_max_kernel, dim3(rows), dim3(256), 0, st, src, K, wsc.as<float>());
+    LRP_HIP_CHECK(hipGetLastError());
+    if (sync) LRP_HIP_CHECK(hipStreamSynchronize(st));
+    return LRP_OK;
+  }
   int alloc_conv_operands(int li, int64_t* total, hipStream_t st) {
     ConvLayer& L = layers[li];
     auto mk = [&](DevBuf& d, size_t floats) -> int {
@@ -328,8 +357,9 @@ struct Encoder {
     const size_t nf = (size_t)conv_npad(L.cout) * Kf, nb = (size_t)conv_npad(L.cin) * Kb;
     LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf));
     LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
+    LRP_TRY(mk(L.w_fwd_ah, nf));
     LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
-    LRP_TRY(mk(L.w_bwd_h, nb)); LRP_TRY(mk(L.wn_h, 1));
+    LRP_TRY(mk(L.w_bwd_h, nb));
     if (conv_npad(L.cin) == 64) { LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb)); LRP_TRY(mk(L.w_bwd_frag_h, (size_t)64 * Kb)); }
     if (pack_tmp.bytes < nf * sizeof(float)) LRP_TRY(pack_tmp.alloc(nf * sizeof(float), total));
     return LRP_OK;
@@ -343,7 +373,7 @@ struct Encoder {
                          L.w_bwd.as<float>(), L.w_bwd_full.as<float>(), L.cout, Kb);
       const size_t nb = (size_t)Npb * Kb;
       hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb / 8);
-      hipLaunchKernelGGL(split_copy_h_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_h.as<float>(), nb / 8);
+      LRP_TRY(make_f16_operand(L.w_bwd.as<float>(), nb, 0, 0, L.w_bwd_h, L.wbs, nullptr, st, false));
       LRP_HIP_CHECK(hipGetLastError());
       return LRP_OK;
     }
@@ -364,17 +394,16 @@ struct Encoder {
     split(tmp, L.w_fwd_zs.as<float>(), nf);
     hipLaunchKernelGGL(split3_copy_kernel, dim3(stream_grid(nf / 8)), dim3(256), 0, st, L.w_fwd_a.as<float>(), L.w_fwd_as.as<float>(),
                        L.w_fwd_al.as<float>(), nf / 8);
+    LRP_TRY(make_f16_operand(L.w_fwd_a.as<float>(), nf, 0, 0, L.w_fwd_ah, L.wfs, nullptr, st, false));
     pack(L.w_bwd.as<float>(), 1, Npb, 0, 1);
     split(L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb);
     if (L.w_bwd_frag.p)
       hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_s.as<float>(),
                          L.w_bwd_frag.as<float>(), CPo);
-    hipLaunchKernelGGL(split_copy_h_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_h.as<float>(), nb / 8);
+    LRP_TRY(make_f16_operand(L.w_bwd.as<float>(), nb, Npb, 9 * CPo, L.w_bwd_h, L.wbs, nullptr, st, false));
     if (L.w_bwd_frag_h.p)
       hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_h.as<float>(),
                          L.w_bwd_frag_h.as<float>(), CPo);
-    LRP_HIP_CHECK(hipMemsetAsync(L.wn_h.p, 0, sizeof(float), st));
-    hipLaunchKernelGGL(rowabs_max_kernel, dim3(Npb), dim3(256), 0, st, L.w_bwd.as<float>(), 9 * CPo, L.wn_h.as<unsigned>());
     pack(L.w_bwd_full.as<float>(), 1, Npb, 0, 0);
     split(L.w_bwd_full.as<float>(), L.w_bwd_full_s.as<float>(), nb);
     LRP_HIP_CHECK(hipGetLastError());
@@ -444,6 +473,12 @@ struct Encoder {
       LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));
       gates_pending = false;
     }
+    if (!act_max.p) {
+      int64_t dummy = 0;
+      LRP_TRY(act_max.alloc(layers.size() * ACT_MAX_SLOTS * sizeof(unsigned), &dummy));
+      LRP_TRY(act_unscale.alloc(layers.size() * sizeof(float), &dummy));
+    }
+    LRP_HIP_CHECK(hipMemsetAsync(act_max.p, 0, act_max.bytes, st));
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, B * img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
     {
       const size_t total = (size_t)B * img_h * img_w * 64;
@@ -469,7 +504,24 @@ struct Encoder {
         ca.bias = L.bias.as<float>(); ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout;
         float* a_out = top ? feat.as<float>() : (keep_acts && !L.pool_after) ? L.Akeep.as<float>() : L.G.as<float>();
         ca.out = a_out;
-        if (fwd_x6() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
+        if (fwd_f16() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
+          // fp32-grade product on the f16 matrix cores: x_l -> fp16 pairs scaled by 2^k (k from the maximum the producer
+          // measured), ONE conv pass, the epilogue undoes the scale, adds the bias and measures max|a_l| for the next layer
+          const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
+          unsigned* slots_in = act_max.as<unsigned>() + (li - 1) * ACT_MAX_SLOTS;
+          if (li == 1) {                                // (a_1 comes from the fp32 im2col GEMM, which keeps no maximum)
+            hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n8 * 2)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(xin[li]),
+                               n8 * 2, slots_in);
+          }
+          hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8, slots_in,
+                             act_unscale.as<float>() + li, L.wfs.as<float>());
+          LRP_HIP_CHECK(hipGetLastError());
+          ConvArgs c1 = ca;
+          c1.in = bufXs.as<float>(); c1.wpk = L.w_fwd_ah.as<float>();
+          c1.in_unscale = act_unscale.as<float>() + li;
+          c1.act_max_out = act_max.as<unsigned>() + li * ACT_MAX_SLOTS;
+          LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, c1, st, PREC_F16X2));
+        } else if (fwd_x6() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
           // fp32-grade product on the bf16 matrix cores: three-way split operands, two passes (see conv_igemm.h TERMS)
           const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
           hipLaunchKernelGGL(split3_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(),
@@ -677,7 +729,7 @@ struct Encoder {
       ca.wpk_frag = f16 ? L.w_bwd_frag_h.as<float>() : (split && walk == 0) ? L.w_bwd_frag.as<float>() : nullptr;
       if (f16) {                                        // S_li (level li) -> S_{li-1} (level li - 1); the image layer ends the chain
         hipLaunchKernelGGL(tok_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, lev_max(li), lev_exp(li),
-                           li > 0 ? L.wn_h.as<float>() : (const float*)nullptr, tok_fac.as<float>(), li > 0 ? lev_exp(li - 1) : (int*)nullptr,
+                           L.wbs.as<float>(), tok_fac.as<float>(), li > 0 ? lev_exp(li - 1) : (int*)nullptr,
                            n, li == 0 ? 1 : 0);
         LRP_HIP_CHECK(hipGetLastError());
         ca.tok_fac = tok_fac.as<float>();

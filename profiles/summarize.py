@@ -58,4 +58,4 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
