@@ -370,7 +370,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   //  feature error of VGG16 2.3e-6 without)
   // (and the fp16-pair forward, whose three-term product is fp32-grade: without the second level its accumulator's
   //  3 x K/16 roundings would be the largest error left)
-  constexpr bool BLOCKED = PREC == PREC_FP32 || TERMS == 15 || (PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU));
+  constexpr bool BLOCKED = PREC == PREC_FP32 || TERMS == 15 ||
+                           (PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL));
   f32x16 acc[TM][TN], tot[BLOCKED ? TM : 1][BLOCKED ? TN : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -836,17 +837,31 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
           const int c = isz ? col - a.split : col;
           const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + c);
           float* dst = (isz ? a.out2 : a.out) + c;
+          float unscale = 1.f, omax = 0.f;                // PREC_F16X2: as in the BIAS epilogues (max of the a half only)
+          if constexpr (PREC == PREC_F16X2) unscale = *a.in_unscale;
 #pragma unroll 4
           for (int ps = 0; ps < RH / RPP; ++ps) {
             const int ll = rin + ps * RPP;
             int row, n_, h_, w_;
             if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4) + bv;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * 4);
+            if constexpr (PREC == PREC_F16X2) v *= unscale;
+            v += bv;
             if (!isz && !a.dual_norelu) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
             }
+            if constexpr (PREC == PREC_F16X2) {
+              if (!isz) omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
             *reinterpret_cast<f32x4*>(dst + (size_t)row * a.split) = v;
+          }
+          if constexpr (PREC == PREC_F16X2) {
+            if (a.act_max_out) {
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+              if (lane == 0 && omax > 0.f) atomicMax(a.act_max_out + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)), __float_as_uint(omax));
+            }
           }
         }
       } else {
@@ -1068,7 +1083,7 @@ template <int EPI, int PREC, int TERMS = 7>
 inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   constexpr int need = PREC != PREC_FP32 ? 7 : 3;                                     // 16 B (fp32) / 32 B (split8) epilogue
   if (PREC == PREC_F16X2 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (!a.tok_fac || !a.tok_max_out || a.out_plain)) return hipErrorInvalidValue;
-  if (PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && !a.in_unscale) return hipErrorInvalidValue;
+  if (PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL) && !a.in_unscale) return hipErrorInvalidValue;
   if ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && (a.N & need)) return hipErrorInvalidValue;
   if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.N & 3)) return hipErrorInvalidValue;
   if (PREC != PREC_FP32 && (a.Cin & 7)) return hipErrorInvalidValue;
@@ -1082,7 +1097,8 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     if (blocks < thr) t = {128, 64};
   }
   int wide = 0;
-  if (PREC != PREC_FP32 && (TERMS == 7 || PREC == PREC_F16X2) && !(PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU)) &&
+  if (PREC != PREC_FP32 && (TERMS == 7 || PREC == PREC_F16X2) &&
+      !(PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL)) &&
       a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
     wide = (a.N % 256) == 0 ? 256 : 128;
     if (wide == 128) wide = 0;                           // measured: 256 x 128 loses to two 128 x 128 blocks per CU
@@ -1098,7 +1114,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
 
-  if constexpr (PREC != PREC_FP32 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU)) {
+  if constexpr (PREC != PREC_FP32 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL)) {
     const int mode = conv_halo_mode();
     // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
     // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
@@ -1178,6 +1194,7 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
       case EPI_IMG_STENCIL: return conv_launch_img<PREC_F16X2>(a, st);
       case EPI_BIAS_RELU: return conv_launch_epi<EPI_BIAS_RELU, PREC_F16X2>(a, st);   // forward activation conv, fp16 pairs x fp16 pairs
       case EPI_BIAS: return conv_launch_epi<EPI_BIAS, PREC_F16X2>(a, st);
+      case EPI_FWD_DUAL: return conv_launch_epi<EPI_FWD_DUAL, PREC_F16X2>(a, st);       // a_l and Z+_l from one pass over x_l
     }
     return hipErrorInvalidValue;
   }

@@ -26,7 +26,9 @@ struct ConvLayer {
   DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
   DevBuf w_fwd_as; // forward weights w, split8 = [h | m] of the three-way split   [activation conv, passes A / fast mode]
   DevBuf w_fwd_al; // forward weights w, [h | l] of the three-way split            [activation conv, pass B]
-  DevBuf w_fwd_ah; // forward weights w as fp16 pairs [hi8 | lo8]                   [activation conv on the f16 MFMA, default]
+  DevBuf w_fwd_ah; // forward weights w as fp16 pairs [hi8 | lo8]                   [activation conv on the f16 MFMA]
+  DevBuf w_fwd_h;  // the dual matrix (w | w+) of w_fwd as fp16 pairs, one common scale (record wds)   [a_l and Z+_l in one pass, default]
+  DevBuf wds;
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
   DevBuf w_bwd_s;  // the same matrix in split8 (bf16 hi|lo) form for the bf16x3 reverse walk
   DevBuf w_bwd_full;  // full w (both signs), tap-flipped: the gradient baselines' backward-data conv (fp32)
@@ -103,6 +105,13 @@ struct Encoder {
   // 6.5e-7 vs 6.1e-7 for plain fp32; MI355X: DESIGN 4.1]  LRP_FWD_F16=0 restores the bf16 two-pass chain.
   static bool fwd_f16() {
     const char* e = getenv("LRP_FWD_F16");
+    return !e || atoi(e) != 0;
+  }
+  // ... and the denominators Z+_l from the SAME pass: weights (w | w+) stacked along N like the fp32 kernel's dual
+  // matrix, one A operand staged for both, gates on the caller's stream behind the next layer's split — the side-stream
+  // Z+ chain (its own split pass, 11 more conv launches at low priority) disappears.  LRP_FWD_DUAL=0 restores it.
+  static bool fwd_dual() {
+    const char* e = getenv("LRP_FWD_DUAL");
     return !e || atoi(e) != 0;
   }
   static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
@@ -255,6 +264,8 @@ struct Encoder {
       pack_conv_fwd(wp.data(), 9, L.cin, L.cout, L.cout, Np, pk.data());    // input >= 0: Z = x.w+ + b
       LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      LRP_TRY(L.w_fwd_h.alloc(pk.size() * sizeof(float), total));
+      LRP_TRY(make_f16_operand(L.w_fwd.as<float>(), pk.size(), 0, 0, L.w_fwd_h, L.wds, total, nullptr));
       {  // mixed-precision forward: w (fp32) and w+ (split8) as separate N = cout matrices
         const int Npa = conv_npad(L.cout);
         std::vector<float> pa((size_t)Npa * K, 0.f), pz((size_t)Npa * K, 0.f), pzs((size_t)Npa * K);
@@ -355,7 +366,7 @@ struct Encoder {
     }
     const size_t Kf = (size_t)9 * conv_cinp(L.cin), Kb = (size_t)9 * conv_cinp(L.cout);
     const size_t nf = (size_t)conv_npad(L.cout) * Kf, nb = (size_t)conv_npad(L.cin) * Kb;
-    LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf));
+    LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf)); LRP_TRY(mk(L.w_fwd_h, (size_t)conv_npad(2 * L.cout) * Kf));
     LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
     LRP_TRY(mk(L.w_fwd_ah, nf));
     LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
@@ -389,6 +400,7 @@ struct Encoder {
     };
     const size_t nf = (size_t)Npa * 9 * CPi, nb = (size_t)Npb * 9 * CPo;
     pack(L.w_fwd.as<float>(), 0, Np2, 1, 0);
+    LRP_TRY(make_f16_operand(L.w_fwd.as<float>(), (size_t)Np2 * 9 * CPi, 0, 0, L.w_fwd_h, L.wds, nullptr, st, false));
     pack(L.w_fwd_a.as<float>(), 0, Npa, 0, 0);
     pack(tmp, 0, Npa, 0, 1);
     split(tmp, L.w_fwd_zs.as<float>(), nf);
@@ -494,6 +506,17 @@ struct Encoder {
       if (L.cout & 7) mixed = false;
     const bool overlap = mixed && side && overlap_enabled() && layers.size() > 1;
     std::vector<const float*> xin(layers.size() + 1, nullptr);   // overlapped path: input of every conv
+    bool dual = overlap && fwd_f16() && fwd_dual() && fwd_split_from() >= 1000;
+    for (size_t li = 1; li < layers.size(); ++li)
+      if (((layers[li].cin | layers[li].cout) & 7) || !layers[li].w_fwd_h.p) dual = false;
+    int gate_due = -1;                                 // dual path: layer whose gate waits for the next layer's split (it reads a_l)
+    auto launch_gate = [&](int gl) {
+      ConvLayer& Lg = layers[gl];
+      const size_t ng = (size_t)B * Lg.act_elems();
+      hipLaunchKernelGGL(gate_kernel, dim3(stream_grid(ng / 4)), dim3(256), 0, st,
+                         reinterpret_cast<const f32x4*>(keep_acts ? Lg.Akeep.as<float>() : Lg.G.as<float>()),
+                         reinterpret_cast<const f32x4*>(bufZ.as<float>()), Lg.G.as<f32x4>(), ng / 4);
+    };
     for (size_t li = 0; li < layers.size(); ++li) {
       ConvLayer& L = layers[li];
       const bool top = li + 1 == layers.size();
@@ -504,6 +527,36 @@ struct Encoder {
         ca.bias = L.bias.as<float>(); ca.wpk = L.w_fwd_a.as<float>(); ca.N = L.cout;
         float* a_out = top ? feat.as<float>() : (keep_acts && !L.pool_after) ? L.Akeep.as<float>() : L.G.as<float>();
         ca.out = a_out;
+        if (dual) {
+          const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
+          unsigned* slots_in = act_max.as<unsigned>() + (li - 1) * ACT_MAX_SLOTS;
+          if (li == 1)
+            hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n8 * 2)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(xin[li]),
+                               n8 * 2, slots_in);
+          hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8, slots_in,
+                             act_unscale.as<float>() + li, L.wds.as<float>());
+          if (gate_due >= 0) { launch_gate(gate_due); gate_due = -1; }       // a_{l-1} has been read: it may become G_{l-1} now
+          LRP_HIP_CHECK(hipGetLastError());
+          ConvArgs cd = ca;
+          cd.in = bufXs.as<float>(); cd.wpk = L.w_fwd_h.as<float>(); cd.N = 2 * L.cout; cd.split = L.cout;
+          cd.out = a_out; cd.out2 = top ? ztop.as<float>() : bufZ.as<float>();
+          cd.in_unscale = act_unscale.as<float>() + li;
+          cd.act_max_out = act_max.as<unsigned>() + li * ACT_MAX_SLOTS;
+          LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2));
+          if (top) break;
+          if (L.pool_after) {
+            const size_t n = (size_t)B * L.act_elems();
+            hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);
+            hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
+                               (float*)nullptr, L.G.as<float>(), B, L.H, L.W, L.cout);
+            LRP_HIP_CHECK(hipGetLastError());
+            xin[li + 1] = L.P.as<float>();
+          } else {
+            xin[li + 1] = a_out;
+            gate_due = (int)li;
+          }
+          continue;
+        }
         if (fwd_f16() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
           // fp32-grade product on the f16 matrix cores: x_l -> fp16 pairs scaled by 2^k (k from the maximum the producer
           // measured), ONE conv pass, the epilogue undoes the scale, adds the bias and measures max|a_l| for the next layer
@@ -602,7 +655,10 @@ struct Encoder {
         LRP_HIP_CHECK(hipGetLastError());
       }
     }
-    if (overlap) {
+    if (dual) {
+      if (gate_due >= 0) launch_gate(gate_due);         // (cannot happen for a net that ends in conv layers feeding the top: kept for safety)
+      LRP_HIP_CHECK(hipGetLastError());
+    } else if (overlap) {
       // side stream, top layer first: layer l's input x_l = a_{l-1} lives in the gate storage of layer l-1, which
       // is turned into G_{l-1} only after layer l is done with it
       LRP_HIP_CHECK(hipEventRecord(ev_fwd, st));
