@@ -119,3 +119,25 @@ def test_reference_surface_with_resnet():
     o.forward(feat.astype(np.float32), cap)
     for i, Rf in enumerate(rel):
         assert rel_l1(ex._explain_CNN(X, Rf), RN.analyze(w, spec, X, o.explain(i + 1)[0])) < TOL
+
+
+def test_resnet_handle_takes_weights_from_device():
+    """lrp_set_weight_dev on a ResNet handle: the decoder's weights are packed on the device, the encoder units (conv + BN
+    folding is a host packer) are staged once through the host — the handle must end up in the host-set state exactly."""
+    import torch
+    stacks, stem, hw, H, V = ((4, 2), (8, 2)), 8, 32, 32, 50
+    rs = np.random.RandomState(19)
+    w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
+    L, D = 16, 32
+    w.update(gridtd_weights(rs, L, D, H, H, V))
+    X = rs.uniform(-120, 130, size=(1, hw, hw, 3)).astype(np.float32)
+    cap = [7, 19, 33, 1]
+    host, _, _ = _engine(stacks, stem, hw, 1, 4, w, decoder="gridtd", H=H, V=V)
+    dev, _, _ = _engine(stacks, stem, hw, 1, 4, {}, decoder="gridtd", H=H, V=V)
+    dev.set_weights_from_device({k: torch.as_tensor(v).cuda() for k, v in w.items()})
+    outs = []
+    for eng in (host, dev):
+        eng.encode_images(X)
+        eng.decoder_forward([cap])
+        outs.append([t.clone() for t in eng.explain_tokens([0, 0, 0], [1, 2, 3], want_R_feat=True)[:2]])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
