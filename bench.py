@@ -97,6 +97,17 @@ def algorithmic_bytes_per_walk(n_tokens, n_images):
     return tot, len(VGG16_CFG)
 
 
+def top_block_flop_share():
+    """share of the reverse walk's algorithmic flops in the layers after the last pool (the three-MFMA layers of f16x2)"""
+    from lrp_imagecaptioning_amd.synthetic import VGG16_CFG
+    r, fl, last_pool = 224, [], -1
+    for li, (_, cin, cout, pool) in enumerate(VGG16_CFG):
+        fl.append(r * r * 9.0 * cout * (6 if li == 0 else cin))
+        if pool:
+            last_pool, r = li, r // 2
+    return sum(fl[last_pool + 1:]) / sum(fl)
+
+
 def oracle_heatmaps(w, X, caps, samples):
     """Float64 oracle (oracle/: decoder pinned by the reference's own outputs, CNN = literal iNNvestigate graph) for
     the sampled (image, t) pairs of the timed batch: {(b, t): (224, 224, 3) relevance}."""
@@ -186,8 +197,9 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=10, help="tokens of one caption the CPU port explains (~1 s each)")
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "bf16x3_fast", "f16x2"],
-                    help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (default) or exact fp32 MFMA")
+    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16x3", "fp32", "bf16x3_fast"],
+                    help="arithmetic of the per-token reverse walk: fp16 pairs, 2 MFMAs per product below the top block "
+                         "(library default), split-bf16 x3 MFMA, or exact fp32 MFMA")
     ap.add_argument("--handles", type=int, default=2,
                     help="batches in flight per GPU: consecutive steps alternate between this many lrp_handles on their own "
                          "HIP streams (pipeline.py); 1 = strictly one step after the other")
@@ -287,12 +299,14 @@ def main():
     def roofline_block(precision, n_launch, ms, flop, traffic, traffic_src):
         split = precision != "fp32"
         achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        per_product = 2 if precision == "f16x2" else 3
+        per_product = 3
         if precision == "f16x2":
             peak = PEAK_BF16_MFMA_TFLOPS                     # (v_mfma_f32_32x32x16_f16 runs at the bf16 rate)
+            per_product = round(2.0 + top_block_flop_share(), 3)   # 3 MFMAs per product after the last pool, 2 below
             kname = ("conv_igemm_kernel<..., PREC_F16X2> (conv-LRP alpha1beta0 backward, 13 launches/step; relevance as an "
-                     "fp16 pair hi+lo with per-token power-of-two scales, one fp16 per weight: 2 f16 MFMAs per product, fp32 "
-                     "accumulate; forward/decoder stay fp32-grade/fp64)")
+                     "fp16 pair hi+lo with per-token power-of-two scales, weights as scaled fp16 pairs: 3 f16 MFMAs per "
+                     "product in block5, 2 (weights' hi half only) below, fp32 accumulate; forward/decoder stay "
+                     "fp32-grade/fp64)")
         elif split:
             peak = PEAK_BF16_MFMA_TFLOPS
             kname = ("conv_igemm_kernel<..., PREC_BF16X3> (conv-LRP alpha1beta0 backward, 13 launches/step; every fp32 "
@@ -392,13 +406,13 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic_per_launch(precision="bf16x3"):
+def pmc_traffic_per_launch(precision="f16x2"):
     """Fallback when the live rocprofv3 passes cannot run (no profiler, N > 1): the per-launch fabric traffic of the
     reverse-walk conv launches from the newest committed PMC summary (profiles/run_profile.sh: separate --pmc
     FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
     import glob
     # the committed summaries are of the default-precision run; an fp32-mode profile would be r*_pmc_summary_fp32.json
-    suffix = {"bf16x3": "", "bf16x3_fast": "", "fp32": "_fp32", "f16x2": "_f16x2"}[precision]
+    suffix = {"f16x2": "", "bf16x3": "_bf16x3", "bf16x3_fast": "_bf16x3", "fp32": "_fp32"}[precision]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % suffix)))
     if not files:
         return None, None

@@ -205,21 +205,25 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
 
 /* Arithmetic of the per-token reverse walk through the encoder (lrp_cnn_explain / lrp_explain_tokens).
  * LRP_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
- * LRP_PREC_BF16X3 split-bf16: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
- *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
- *                 Default.  Measured parity of the heat-maps vs the float64 reference graph: 2e-6 ... 7e-6 relative L1
- *                 over five seeds (fp32 mode: 1e-7 ... 8e-6; bar 1e-4; single arg-max flips reach 3e-5 in any mode).  Conv widths % 8 != 0 silently use the fp32 path.
- *                 The per-image forward keeps fp32-grade activations (three-way split operands, six bf16 MFMAs per
- *                 product, measured 7e-7 on the features like the fp32 MFMA); only the denominators Z+ are two-way
- *                 split: an error in a_l upstream of a max-pool flips arg-maxes, and a_top are the decoder's features.
- * LRP_PREC_BF16X3_FAST  two-way split activation convs as well: 10 % faster, but the arg-max flips put the heat-map
- *                 parity at 2e-5 ... 9e-5 (five seeds) — inside the 1e-4 bar without margin.  Opt-in, not recommended.
- * LRP_PREC_F16X2  (ABI v3) the LRP reverse walk of the VGG-style encoder with the relevance tensors as fp16 pairs hi + lo
- *                 (22 mantissa bits, carried scaled by a per-token power of two that every layer re-derives from the
- *                 measured maximum of its input and its weight norm) and ONE fp16 per weight: two MFMAs of
- *                 v_mfma_f32_32x32x16_f16 per product instead of three.  The weight rounding (2^-12, the same for every
- *                 token) puts the heat-maps at 2-3e-5 relative L1 from the float64 graph (BF16X3: ~4e-6; bar 1e-4).
- *                 Everything else (forward, decoder, ResNet encoder) as LRP_PREC_BF16X3.
+ * LRP_PREC_F16X2  DEFAULT (for VGG-style encoders; ABI v3).  The relevance tensors are fp16 pairs hi + lo (22 mantissa
+ *                 bits, carried scaled by a per-token power of two that every layer re-derives from the measured
+ *                 maximum of its input and its weight norm); the weights are fp16 pairs scaled by a power of two per
+ *                 matrix.  Layers after the last pool (VGG16: block5) take the full product hi*hi' + hi*lo' + lo*hi'
+ *                 (three v_mfma_f32_32x32x16_f16, fp32 accumulation); every layer below reads only the hi half of the
+ *                 weights: TWO MFMAs per product.  Measured parity of the heat-maps vs the float64 reference graph:
+ *                 2.7e-6 at the bench configuration, median 3.7e-6 / worst 2.4e-5 (one arg-max flip) over 13 seeds —
+ *                 the same as LRP_PREC_BF16X3 (bar 1e-4).  Two-term products in the top block as well would cost
+ *                 1e-4 (the relevance there is too concentrated for the weight rounding to average out) and are not
+ *                 offered.  Conv widths % 8 != 0 silently use the fp32 path.  The per-image forward is fp32-grade in
+ *                 every mode except _FAST (fp16 pairs on both operands, three MFMAs, blocked accumulation: 7e-7 on the
+ *                 features like the fp32 MFMA).  The ResNet encoder's walk runs as LRP_PREC_BF16X3 in this mode.
+ * LRP_PREC_BF16X3 split-bf16 walk: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
+ *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — three MFMAs
+ *                 in every layer, no scaling state.  Parity as above; ~6 % slower than the default on MI355X (the
+ *                 walk is power-bound: it is the MFMA count that is paid for).
+ * LRP_PREC_BF16X3_FAST  LRP_PREC_BF16X3 with two-way split activation convs in the forward as well: 10 % faster, but
+ *                 the arg-max flips put the heat-map parity at 2e-5 ... 9e-5 (five seeds) — inside the 1e-4 bar
+ *                 without margin.  Opt-in, not recommended.
  * The decoder is fp32 / fp64 in every mode. */
 enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2, LRP_PREC_F16X2 = 3 };
 int lrp_set_precision(lrp_handle* h, int32_t mode);

@@ -13,6 +13,7 @@
 #include "cnn_kernels.h"
 #include "common.h"
 #include "conv_igemm.h"
+#include "f16_operand.h"
 
 namespace lrp {
 
@@ -68,7 +69,7 @@ struct Encoder {
   bool features_only = false;
   bool profile = false;
   int prec = PREC_BF16X3;  // arithmetic of the per-token reverse walk (lrp_set_precision); falls back to fp32 for widths % 8 != 0
-  bool walk_f16 = false;   // LRP_PREC_F16X2: the LRP reverse walk on fp16 pairs x single-fp16 weights (2 MFMAs per product)
+  bool walk_f16 = true;    // LRP_PREC_F16X2 (default): the LRP reverse walk on fp16 pairs, 2 MFMAs per product below the top block
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
   DevBuf tok_exp, tok_max, tok_fac;   // its per-token scale exponents / measured maxima [layers + 1][max_tokens], factors [max_tokens]
   std::vector<ProfileRec> prof;
@@ -331,24 +332,9 @@ struct Encoder {
   // bundle arrives over RCCL/xGMI and never visits the host) and the fine-tune step (weights change every iteration).
   DevBuf pack_tmp;                                     // scratch of the device packers (largest forward matrix)
   DevBuf f16_slots;                                    // ACT_MAX_SLOTS maxima while a weight matrix' fp16 copy is made
-  // fp16-pair copy of a packed fp32 weight matrix on the device: max|w| -> power-of-two scale -> pairs of (w * scale) ->
-  // (rows > 0) the norm of the scaled matrix; the record {2^k, 2^-k, norm, k} lands in `wsc` (cnn_kernels.h).  Used by the
-  // host setters (sync = true: their source upload was synchronous, so is this) and the device packers (on `st`).
   int make_f16_operand(const float* src, size_t n_floats, int rows, int K, DevBuf& dst, DevBuf& wsc, int64_t* total, hipStream_t st,
                        bool sync = true) {
-    if (!f16_slots.p) LRP_TRY(f16_slots.alloc(ACT_MAX_SLOTS * sizeof(unsigned), total));
-    if (!wsc.p) LRP_TRY(wsc.alloc(4 * sizeof(float), total));
-    if (!dst.p || dst.bytes != n_floats * sizeof(float)) LRP_TRY(dst.alloc(n_floats * sizeof(float), total));
-    LRP_HIP_CHECK(hipMemsetAsync(f16_slots.p, 0, ACT_MAX_SLOTS * sizeof(unsigned), st));
-    hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n_floats / 4)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src),
-                       n_floats / 4, f16_slots.as<unsigned>());
-    hipLaunchKernelGGL(wscale_kernel, dim3(1), dim3(64), 0, st, f16_slots.as<unsigned>(), wsc.as<float>());
-    hipLaunchKernelGGL(split_copy_h_kernel, dim3(stream_grid(n_floats / 8)), dim3(256), 0, st, src, dst.as<float>(), n_floats / 8,
-                       wsc.as<float>());
-    if (rows > 0) hipLaunchKernelGGL(rowabs_max_kernel, dim3(rows), dim3(256), 0, st, src, K, wsc.as<float>());
-    LRP_HIP_CHECK(hipGetLastError());
-    if (sync) LRP_HIP_CHECK(hipStreamSynchronize(st));
-    return LRP_OK;
+    return lrp::make_f16_operand(f16_slots, src, n_floats, rows, K, dst, wsc, total, st, sync);      // f16_operand.h
   }
   int alloc_conv_operands(int li, int64_t* total, hipStream_t st) {
     ConvLayer& L = layers[li];
@@ -812,12 +798,20 @@ struct Encoder {
         (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1);
         (void)hipEventRecord(pr.e0, st);
       }
-      // PREC_F16X2: two MFMAs per product (weights as one fp16) only where K = 9 * cout is long enough to average the
-      // weight rounding out; LRP_F16_K3 = the largest K that still takes the three-term form (default 1152)
+      // PREC_F16X2: two MFMAs per product (the weights as ONE fp16, 11 bits) below the top block, three (fp16 pairs on
+      // both sides) in the layers after the last pool.  [MI355X, bench configuration, relative L1 vs the float64 graph:
+      // all layers three-term 2.8e-6 | two-term up to block4 3.1e-6 | two-term in block5 as well 9.7e-5 — the
+      // relevance entering the top block is so concentrated that a sum has one or two dominant products and the
+      // weight rounding, the same for every token, no longer averages out; profiles/r02_f16_terms_sweep.txt]
+      // LRP_F16_T2MASK (bit li = layer li takes the two-term form) overrides the rule for experiments.
       int terms = 7;
       if (f16 && li > 0) {
-        static const int k3 = [] { const char* e = getenv("LRP_F16_K3"); return e ? atoi(e) : 1152; }();
-        if (9 * L.cout > k3) terms = 5;
+        int last_pool = -1;
+        for (size_t q = 0; q < layers.size(); ++q)
+          if (layers[q].pool_after) last_pool = (int)q;
+        if ((int)li <= last_pool) terms = 5;
+        static const int t2mask = [] { const char* e = getenv("LRP_F16_T2MASK"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
+        if (t2mask >= 0) terms = ((t2mask >> li) & 1) ? 5 : 7;
       }
       LRP_HIP_CHECK(conv_launch(epi, ca, st, run_prec, terms));
       if (profile) {

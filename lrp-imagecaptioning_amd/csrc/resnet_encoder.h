@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "conv_igemm.h"
+#include "f16_operand.h"
 #include "resnet_kernels.h"
 
 namespace lrp {
@@ -26,6 +27,7 @@ struct RnUnit {            // conv + BN
   bool have[6] = {false, false, false, false, false, false};   // W b gamma beta mean var
   DevBuf w_a, w_z, w_b, w_bs, bias, gamma, beta, mean, var;   // w_bs: w_b in split8 form (bf16x3 reverse walk)
   DevBuf w_dual;   // [w rows | w+ rows]: c and Z+ of the unit in one conv pass (EPI_FWD_DUAL without the relu)
+  DevBuf w_dual_h, wds;    // w_dual as fp16 pairs scaled by a power of two + its scale record (f16_operand.h)
   DevBuf gate;             // [B][Hout][Wout][cout]: act*Q (relu units) or Q (pre-Add units)
   size_t out_elems() const { return (size_t)Hout * Wout * cout; }
   size_t in_elems() const { return (size_t)Hin * Win * cin; }
@@ -46,6 +48,9 @@ struct ResNetEncoder {
   std::vector<RnBlock> blocks;
   DevBuf images, stemA, a0;        // image copy, stem im2col, stem activation [B][H/2][W/2][stem]
   DevBuf fa, fb, fc, fz, fsc;      // forward scratch
+  DevBuf fxs;                      // a unit's input as scaled fp16 pairs (fp16-pair forward)
+  DevBuf f16_slots;                // scratch maxima of make_f16_operand
+  DevBuf act_max, act_unscale;     // ACT_MAX_SLOTS maxima per unit output / block output; 2^-k per unit input
   DevBuf feat;                     // [B][top...]
   DevBuf r0, r1, r2, r3, r4, r5;   // reverse scratch (per token)
   int encoded = 0;
@@ -98,7 +103,9 @@ struct ResNetEncoder {
     LRP_TRY(a0.alloc(B * stem_hw * stem_c * 4, total));
     LRP_TRY(q_stem.alloc(B * stem_hw * stem_c * 4, total));
     LRP_TRY(pool_win.alloc(B * (stem_hw / 4) * stem_c, total));      // winner of every 3x3/2 pool window (one byte)
-    for (DevBuf* d : {&fa, &fb, &fc, &fz, &fsc}) LRP_TRY(d->alloc(B * max_act * 4, total));
+    for (DevBuf* d : {&fa, &fb, &fc, &fz, &fsc, &fxs}) LRP_TRY(d->alloc(B * max_act * 4, total));
+    LRP_TRY(act_max.alloc((units.size() + blocks.size()) * ACT_MAX_SLOTS * sizeof(unsigned), total));
+    LRP_TRY(act_unscale.alloc(units.size() * sizeof(float), total));
     LRP_TRY(feat.alloc(B * (size_t)top_h * top_w * top_c * 4, total));
     const size_t max_tok = std::max(max_act, stem_hw * (size_t)std::max(RN_STEM_TCOLS, stem_c));
     for (DevBuf* d : {&r0, &r1, &r2, &r3, &r4, &r5}) LRP_TRY(d->alloc(NT * max_tok * 4, total));
@@ -189,6 +196,8 @@ struct ResNetEncoder {
       pack_conv_fwd(w, taps, u.cin, u.cout, 0, Nd, pk.data());
       pack_conv_fwd(wp.data(), taps, u.cin, u.cout, u.cout, Nd, pk.data());
       LRP_TRY(up(u.w_dual, pk, total));
+      if (!(u.cin & 7))
+        LRP_TRY(make_f16_operand(f16_slots, u.w_dual.as<float>(), pk.size(), 0, 0, u.w_dual_h, u.wds, total, nullptr));
     }
     const int Npb = conv_npad(u.cin), Kb = taps * conv_cinp(u.cout);
     pk.assign((size_t)Npb * Kb, 0.f);
@@ -206,8 +215,14 @@ struct ResNetEncoder {
     return LRP_OK;
   }
 
-  // conv + BN unit forward: x [B][Hin][Win][cin] -> act (relu(BN) or BN) and the unit's gate
-  int unit_forward(RnUnit& u, const float* x, int B, float* act, hipStream_t st) {
+  unsigned* unit_slots(int ui) { return act_max.as<unsigned>() + (size_t)ui * ACT_MAX_SLOTS; }
+  unsigned* block_slots(size_t bi) { return act_max.as<unsigned>() + (units.size() + bi) * ACT_MAX_SLOTS; }
+
+  // conv + BN unit forward: x [B][Hin][Win][cin] -> act (relu(BN) or BN) and the unit's gate.
+  // slots_in: maxima of x (fp16-pair forward: the power of two x is scaled by); slots_out: where max|act| is collected
+  // (nullptr: nobody convolves this output)
+  int unit_forward(RnUnit& u, const float* x, int B, float* act, hipStream_t st, const unsigned* slots_in = nullptr,
+                   unsigned* slots_out = nullptr) {
     const float* xin = x;
     if (u.k == 1 && u.stride == 2) {
       const size_t n = (size_t)B * u.Hout * u.Wout * u.cin;
@@ -220,7 +235,18 @@ struct ResNetEncoder {
     if (u.k == 3) { ca.NB = B; ca.H = u.Hout; ca.W = u.Wout; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 9; }
     else { ca.NB = B * u.Hout * u.Wout; ca.H = 1; ca.W = 1; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 1; }
     ConvArgs cz = ca;
-    if (u.w_dual.p && dual_fwd()) {
+    const int ui = (int)(&u - units.data());
+    if (u.w_dual_h.p && slots_in && prec == PREC_BF16X3 && dual_fwd() && fwd_f16()) {
+      // the same single pass on the fp16 MFMA: x and (w | w+) as fp16 pairs, the product in three MFMAs with blocked
+      // fp32 accumulation (conv_igemm.h PREC_F16X2) — fp32-grade, ~2.5x the fp32 matrix rate
+      const size_t n8 = (size_t)B * u.Hout * u.Wout * u.cin / 8;
+      hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin, fxs.as<float>(), n8, slots_in,
+                         act_unscale.as<float>() + ui, u.wds.as<float>());
+      LRP_HIP_CHECK(hipGetLastError());
+      ca.in = fxs.as<float>(); ca.wpk = u.w_dual_h.as<float>(); ca.N = 2 * u.cout; ca.split = u.cout; ca.dual_norelu = 1;
+      ca.out = fc.as<float>(); ca.out2 = fz.as<float>(); ca.in_unscale = act_unscale.as<float>() + ui;
+      LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st, PREC_F16X2));
+    } else if (u.w_dual.p && dual_fwd()) {
       // c = conv(x, w) + b and Z = conv(x, w+) + b in ONE pass over x: the A tile is staged once for both
       ca.wpk = u.w_dual.as<float>(); ca.N = 2 * u.cout; ca.split = u.cout; ca.dual_norelu = 1;
       ca.out = fc.as<float>(); ca.out2 = fz.as<float>();
@@ -234,7 +260,7 @@ struct ResNetEncoder {
     const size_t n = (size_t)B * u.out_elems();
     hipLaunchKernelGGL(rn_bn_unit_kernel, dim3(stream_grid(n)), dim3(256), 0, st, fc.as<float>(), fz.as<float>(),
                        u.gamma.as<float>(), u.beta.as<float>(), u.mean.as<float>(), u.var.as<float>(), RN_BN_EPS, act,
-                       u.gate.as<float>(), (float*)nullptr, n, u.cout, u.relu ? 1 : 0);
+                       u.gate.as<float>(), (float*)nullptr, n, u.cout, u.relu ? 1 : 0, slots_out);
     LRP_HIP_CHECK(hipGetLastError());
     return LRP_OK;
   }
@@ -243,6 +269,7 @@ struct ResNetEncoder {
     if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
     LRP_TRY(check_ready());
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, (size_t)B * img_h * img_w * 3 * 4, hipMemcpyDeviceToDevice, st));
+    LRP_HIP_CHECK(hipMemsetAsync(act_max.p, 0, act_max.bytes, st));
     RnUnit& s = units[0];
     {  // stem: im2col -> two 1-tap GEMMs (c exact / Z with both sign branches) -> BN + relu + gate
       const size_t tot = (size_t)B * s.Hout * s.Wout * 2 * RN_STEM_K;
@@ -260,7 +287,7 @@ struct ResNetEncoder {
       const size_t n = (size_t)B * s.out_elems();
       hipLaunchKernelGGL(rn_bn_unit_kernel, dim3(stream_grid(n)), dim3(256), 0, st, fc.as<float>(), fz.as<float>(),
                          s.gamma.as<float>(), s.beta.as<float>(), s.mean.as<float>(), s.var.as<float>(), RN_BN_EPS,
-                         a0.as<float>(), s.gate.as<float>(), q_stem.as<float>(), n, s.cout, 1);
+                         a0.as<float>(), s.gate.as<float>(), q_stem.as<float>(), n, s.cout, 1, unit_slots(0));
       LRP_HIP_CHECK(hipGetLastError());
       const size_t np = (size_t)B * (s.Hout / 2) * (s.Wout / 2) * s.cout;
       hipLaunchKernelGGL(rn_pool3_kernel, dim3(stream_grid(np)), dim3(256), 0, st, a0.as<float>(), blocks[0].t_in.as<float>(),
@@ -270,6 +297,8 @@ struct ResNetEncoder {
     for (size_t bi = 0; bi < blocks.size(); ++bi) {
       RnBlock& b = blocks[bi];
       const float* t = b.t_in.as<float>();
+      // maxima of the block input: the pooled stem activation (bounded by the stem's) or the previous block's output
+      const unsigned* ts = bi == 0 ? unit_slots(0) : block_slots(bi - 1);
       if (b.stride == 2) {
         const size_t n = (size_t)B * b.H * b.W * b.cin;
         hipLaunchKernelGGL(rn_subsample2_kernel, dim3(stream_grid(n)), dim3(256), 0, st, t, b.t_sub.as<float>(), B, b.Hin,
@@ -277,12 +306,12 @@ struct ResNetEncoder {
         LRP_HIP_CHECK(hipGetLastError());
       }
       // main path: fa <- a1, fb <- a2, fa <- y3 ; shortcut: fsc2 (= r0 scratch is per-token; use GS buffer as temp) ...
-      LRP_TRY(unit_forward(units[b.u1], t, B, fa.as<float>(), st));
-      LRP_TRY(unit_forward(units[b.u2], fa.as<float>(), B, fb.as<float>(), st));
-      LRP_TRY(unit_forward(units[b.u3], fb.as<float>(), B, fa.as<float>(), st));        // fa = y3
+      LRP_TRY(unit_forward(units[b.u1], t, B, fa.as<float>(), st, ts, unit_slots(b.u1)));
+      LRP_TRY(unit_forward(units[b.u2], fa.as<float>(), B, fb.as<float>(), st, unit_slots(b.u1), unit_slots(b.u2)));
+      LRP_TRY(unit_forward(units[b.u3], fb.as<float>(), B, fa.as<float>(), st, unit_slots(b.u2)));        // fa = y3
       const float* sc = t;
       if (b.u0 >= 0) {
-        LRP_TRY(unit_forward(units[b.u0], t, B, fb.as<float>(), st));                   // fb = y0
+        LRP_TRY(unit_forward(units[b.u0], t, B, fb.as<float>(), st, ts));               // fb = y0
         sc = fb.as<float>();
       }
       const bool last = bi + 1 == blocks.size();
@@ -290,7 +319,7 @@ struct ResNetEncoder {
       const size_t n = (size_t)B * b.H * b.W * 4 * b.f;
       hipLaunchKernelGGL(rn_block_out_kernel, dim3(stream_grid(n)), dim3(256), 0, st, sc, fa.as<float>(),
                          units[b.u3].gate.as<float>(), b.u0 >= 0 ? units[b.u0].gate.as<float>() : (const float*)nullptr, o,
-                         b.GA.as<float>(), b.GS.as<float>(), n);
+                         b.GA.as<float>(), b.GS.as<float>(), n, last ? (unsigned*)nullptr : block_slots(bi));
       LRP_HIP_CHECK(hipGetLastError());
     }
     encoded = B;
@@ -436,6 +465,10 @@ struct ResNetEncoder {
   DevBuf pool_win;
   static bool dual_fwd() {                 // LRP_RN_DUAL=0: separate c / Z+ convs
     const char* e = getenv("LRP_RN_DUAL");
+    return !e || atoi(e) != 0;
+  }
+  static bool fwd_f16() {                  // LRP_RN_F16=0: the forward convs on the fp32 MFMA
+    const char* e = getenv("LRP_RN_F16");
     return !e || atoi(e) != 0;
   }
   static bool fuse_tail() {                // LRP_RN_FUSE=0: separate element-wise join / head kernels

@@ -11,6 +11,15 @@ namespace lrp {
 
 __device__ __forceinline__ float stab_sign(float d) { return d + (d >= 0.f ? 1e-7f : -1e-7f); }
 
+// max|.| of what a thread wrote -> one atomic per wave, spread over ACT_MAX_SLOTS float-bit slots (the fp16-pair forward
+// conv of the next unit scales its input by a power of two taken from them, cnn_kernels.h: split_h_scaled_kernel)
+__device__ __forceinline__ void rn_flush_max(float m, unsigned* __restrict__ slots) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f)
+    atomicMax(slots + ((blockIdx.x + (threadIdx.x >> 6)) & (ACT_MAX_SLOTS - 1)), __float_as_uint(m));
+}
+
 // After a conv unit: c = conv(x,w)+b (exact), Z = alpha1beta0 denominator.
 //   y = BN(c);  Q = c (y - beta) / stab((c - mu) y) / safe(Z)     [BN reverse o conv denominator]
 //   relu != 0: act = relu(y), gate = act * Q  (what the NEXT conv's relevance is multiplied with)
@@ -19,7 +28,9 @@ __global__ __launch_bounds__(256) void rn_bn_unit_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ var,
                                                          float bn_eps, float* __restrict__ act, float* __restrict__ gate,
-                                                         float* __restrict__ qonly, size_t n, int C, int relu) {
+                                                         float* __restrict__ qonly, size_t n, int C, int relu,
+                                                         unsigned* __restrict__ max_slots) {
+  float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const int ch = (int)(i % C);
     const float cv = c[i], mu = mean[ch], bt = beta[ch];
@@ -27,23 +38,29 @@ __global__ __launch_bounds__(256) void rn_bn_unit_kernel(const float* __restrict
     const float q = (cv * (y - bt)) / safe_den(stab_sign((cv - mu) * y)) / safe_den(Z[i]);
     const float av = relu ? fmaxf(y, 0.f) : y;
     act[i] = av;
+    m = fmaxf(m, fabsf(av));
     gate[i] = relu ? av * q : q;
     if (qonly) qonly[i] = q;
   }
+  if (max_slots) rn_flush_max(m, max_slots);
 }
 
 // Block end: o = relu(sc + y3);  GA = y3 / safe(sc + y3) * Q3;  GS = sc / safe(sc + y3) [* Q0 for a projection shortcut]
 __global__ __launch_bounds__(256) void rn_block_out_kernel(const float* __restrict__ sc, const float* __restrict__ y3,
                                                            const float* __restrict__ Q3, const float* __restrict__ Q0,
                                                            float* __restrict__ o, float* __restrict__ GA,
-                                                           float* __restrict__ GS, size_t n) {
+                                                           float* __restrict__ GS, size_t n,
+                                                           unsigned* __restrict__ max_slots) {
+  float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float s = sc[i], y = y3[i];
     const float den = safe_den(s + y);
     o[i] = fmaxf(s + y, 0.f);
+    m = fmaxf(m, s + y);
     GA[i] = y / den * Q3[i];
     GS[i] = Q0 ? s / den * Q0[i] : s / den;
   }
+  if (max_slots) rn_flush_max(m, max_slots);
 }
 
 // the same product written in the split-bf16 operand format of the conv kernel (8 channels per thread; head of a

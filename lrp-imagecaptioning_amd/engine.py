@@ -64,7 +64,7 @@ class LRPEngine(object):
             _capi.check(self._lib.lrp_create(C.byref(cfg), C.byref(self._h)))
         self.captions = None
         self.n_images = 0
-        self.precision = "bf16x3"                       # library default for the reverse walk (set_precision)
+        self.precision = "f16x2"                        # library default for the reverse walk (set_precision)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -368,8 +368,9 @@ class LRPEngine(object):
         return out, R, att, rw
 
     def set_precision(self, mode):
-        """'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16 reverse walk, default) or 'bf16x3_fast' (split forward
-        activations too; see include/lrp_hip.h)."""
+        """'f16x2' (fp16-pair reverse walk, two MFMAs per product below the top block; default), 'bf16x3' (split-bf16
+        walk, three everywhere), 'fp32' (exact fp32 MFMA) or 'bf16x3_fast' (split forward activations too; see
+        include/lrp_hip.h)."""
         m = {"fp32": _capi.LRP_PREC_FP32, "bf16x3": _capi.LRP_PREC_BF16X3, "bf16x3_fast": _capi.LRP_PREC_BF16X3_FAST,
              "f16x2": _capi.LRP_PREC_F16X2}.get(mode)
         if m is None:

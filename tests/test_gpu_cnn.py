@@ -49,10 +49,10 @@ def test_small_nets_match_oracle(name, cfg, hw, B, prec):
     errs = [rel_l1(out[i], ref[i]) for i in range(2 * B)]
     report("cnn_" + name + "_" + prec, max_rel_l1=max(errs))
     assert np.isfinite(out).all()
-    # f16x2 rounds every weight to fp16 (2^-12, the same error for every token): with K = 9 x 8 ... 9 x 64 products per
-    # output there is little to average it out, unlike VGG16's K = 576 ... 4608 (test_vgg16_full_size_matches_oracle
-    # holds the 1e-4 bar); these narrow nets only have to stay within 5e-4
-    assert max(errs) < (5e-4 if prec == "f16x2" else TOL), errs
+    # f16x2 (the default): layers up to the last pool read one fp16 per weight (2^-12, the same error for every token);
+    # with K = 9 x 8 ... 9 x 64 products per output these narrow nets average less of it out than VGG16 does
+    # (measured 6e-5 on the tiny net, 6e-6 on the mid one, 1e-6 at full size) — still inside the bar
+    assert max(errs) < TOL, errs
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16x3", "bf16x3_fast", "f16x2"])
@@ -78,9 +78,8 @@ def test_vgg16_full_size_matches_oracle(prec):
     errs = [rel_l1(out[i], ref[i]) for i in range(4)]
     report("cnn_vgg16_" + prec, feat_rel_l1=e_feat, max_rel_l1=max(errs))
     assert e_feat < (1e-5 if prec != "bf16x3_fast" else 5e-5)
-    # f16x2 (opt-in): its two-MFMA layers round every weight to fp16; measured 2-5e-5 on random relevance, up to 1e-4 on
-    # the decoder's peaky relevance maps — "within the bar without margin", so it is held to 2e-4 here
-    assert max(errs) < (2e-4 if prec == "f16x2" else TOL), errs
+    # every mode, the two-MFMA default included, holds the reference bar (f16x2 measured 1.2e-6 here)
+    assert max(errs) < TOL, errs
     # linearity in R (size-independent property): analyze(a*R1 + R2) = a*analyze(R1) + analyze(R2)
     out2 = eng.cnn_explain([0, 0], np.stack([2.5 * R[0] + R[3], R[3]])).cpu().numpy()
     assert rel_l1(out2[0], 2.5 * out[0] + out[3]) < (1e-5 if prec == "fp32" else 5e-5)
