@@ -1129,7 +1129,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true>), dim3(a.m_tiles), dim3(256), 0, st, a);
+          hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true, TERMS>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }
       }
@@ -1180,9 +1180,8 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
     return hipErrorInvalidValue;
   }
   if (prec == PREC_F16X2) {                            // reverse walk of the VGG encoder only
-    // terms 7: S(hi + lo) x w(hi + lo) without lo*lo — three MFMAs; terms 5: the weights' lo half dropped — two.  The
-    // weight rounding of the two-term form (2^-12, identical for every token) averages out over K: layers with a short
-    // K take the three-term form (they are not MFMA-bound anyway), the 256/512-channel layers the two-term one.
+    // terms 7: S(hi + lo) x w(hi + lo) without lo*lo — three MFMAs; terms 5: the weights' lo half dropped — two.  Which
+    // layers take which is the caller's rule (Encoder::explain: two-term up to the last pool, measured there).
     if (terms == 5) {
       if (epi == EPI_MUL) return conv_launch_epi<EPI_MUL, PREC_F16X2, 5>(a, st);
       if (epi == EPI_MUL_UP2) return conv_launch_epi<EPI_MUL_UP2, PREC_F16X2, 5>(a, st);
