@@ -11,10 +11,12 @@ images sharded per rank, no data-path collective (weak scaling).
 
 Prints ONE json line (rank 0).  See DESIGN.md §measurement for the roofline terms.
 
-The line is self-certifying (N = 1): besides the timed default mode (split-bf16 reverse walk) the same invocation
+The line is self-certifying (N = 1): besides the timed default mode (fp16-pair reverse walk, two MFMAs per product below
+the top block) the same invocation
   * times the exact-fp32 mode on the same batch              -> "fp32_mode"  {value, ms_per_step, roofline}
   * checks sampled heat-maps of the timed batch, in both modes, against the CPU oracle
-    (outside the timed region)                               -> "parity"     {bf16x3, fp32: worst relative L1}
+    (outside the timed region)                               -> "parity"     {f16x2, fp32: worst relative L1}
+  * reads board power and shader clock while the steps run   -> "power"      {socket_power_w, sclk_mhz}
   * measures the fabric traffic of the dominant kernel live: two `rocprofv3 --pmc` child passes of this same
     script (FETCH_SIZE, WRITE_SIZE; started BEFORE this process touches the GPU) -> roofline.traffic
 """
@@ -95,6 +97,52 @@ def algorithmic_bytes_per_walk(n_tokens, n_images):
         gate = n_images * r_out ** 2 * cin * 4             # (image layer: the image itself)
         tot += s_in + s_out + gate
     return tot, len(VGG16_CFG)
+
+
+def power_probe(step, torch, seconds=2.0):
+    """rocm-smi readings (socket power, sclk) taken while a helper thread keeps issuing the bench's steps: an untimed
+    look at the operating point the timed number was measured at.  None when rocm-smi is not there."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    stop = threading.Event()
+
+    def work():
+        k = 0
+        while not stop.is_set():
+            step()
+            k += 1
+            if k % 4 == 0:                                # (bounded queue; the handles keep overlapping as in the timed run)
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+    th = threading.Thread(target=work)
+    th.start()
+    watts, mhz = [], []
+    t0 = time.perf_counter()
+    try:
+        time.sleep(0.5)
+        while time.perf_counter() - t0 < seconds:
+            out = subprocess.run([smi, "-d", str(torch.cuda.current_device()), "--showpower", "--showclocks"],
+                                 capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            if m:
+                watts.append(float(m.group(1)))
+            if c:
+                mhz.append(int(c.group(1)))
+    except Exception:
+        pass
+    finally:
+        stop.set()
+        th.join()
+    if not watts or not mhz:
+        return None
+    return {"socket_power_w": round(float(np.median(watts)), 1), "sclk_mhz": int(np.median(mhz)), "samples": len(watts),
+            "source": "rocm-smi --showpower --showclocks while the bench's steps run (untimed)"}
 
 
 def top_block_flop_share():
@@ -200,6 +248,7 @@ def main():
     ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16x3", "fp32", "bf16x3_fast"],
                     help="arithmetic of the per-token reverse walk: fp16 pairs, 2 MFMAs per product below the top block "
                          "(library default), split-bf16 x3 MFMA, or exact fp32 MFMA")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock reading")
     ap.add_argument("--handles", type=int, default=2,
                     help="batches in flight per GPU: consecutive steps alternate between this many lrp_handles on their own "
                          "HIP streams (pipeline.py); 1 = strictly one step after the other")
@@ -339,6 +388,10 @@ def main():
     n_launch, ms, flop = dominant_kernel()
     got = {args.precision: sampled(args.precision)} if extras and not args.no_parity else {}
 
+    # ---- board power / shader clock while the same steps run (untimed): the walk is power-limited on MI355X, which is
+    # why its MFMA count, not the overlap of its phases, sets the rate
+    power_block = power_probe(step, torch) if extras and not args.no_power else None
+
     # ---- the same batch in exact-fp32 arithmetic (the reference's: TF float32 / numpy float64), same invocation
     fp32_block = None
     if extras and not args.no_fp32_mode and args.precision != "fp32":
@@ -382,6 +435,8 @@ def main():
             res["roofline"]["traffic_detail"] = live_traffic
         if fp32_block:
             res["fp32_mode"] = fp32_block
+        if power_block:
+            res["power"] = power_block
         if got:
             # worst relative L1 (BASELINE: sum|R - R_ref| / sum|R_ref| on the raw (224,224,3) relevance, per token) of the
             # sampled heat-maps of the TIMED batch against the float64 oracle; outside the timed region
