@@ -64,6 +64,39 @@ def test_cnn_linearity_and_zero(full_engine):
     assert np.isfinite(out).all()
 
 
+@pytest.mark.parametrize("prec", ["f16x2", "bf16x3"])
+def test_cnn_scale_invariance_over_80_orders_of_magnitude(full_engine, prec):
+    """analyze(c * R) = c * analyze(R) for c from 1e-30 to 1e+30, tokens of very different magnitude side by side in one
+    call.  The default walk carries relevance in fp16 (5 exponent bits) under a per-token power-of-two scale that every
+    layer re-derives from measured maxima: this is the property that scale has to deliver.  Powers of two must come out
+    bit-identical up to the scale (only exponents change), arbitrary factors within rounding."""
+    eng, w, V = full_engine
+    eng.set_precision(prec)
+    try:
+        rs = np.random.RandomState(21)
+        X = images(rs, 2)
+        eng.encode_images(X)
+        feat = eng.get_features().cpu().numpy()
+        R0 = (rs.standard_normal(feat[0].shape) * feat[0]).astype(np.float32)
+        R1 = (rs.standard_normal(feat[1].shape) * feat[1]).astype(np.float32)
+        fac = [1.0, 2.0 ** -90, 2.0 ** 80, 1e-30, 3e+30 / np.abs(R0).max(), 7.7e-12]
+        Rs = np.stack([np.float32(f) * R0 for f in fac] + [R1, np.float32(2.0 ** -60) * R1])
+        assert np.isfinite(Rs).all() and (np.abs(Rs[3]) > 0).any()
+        out = eng.cnn_explain([0] * len(fac) + [1, 1], Rs).cpu().numpy().astype(np.float64)
+        assert np.isfinite(out).all()
+        base, worst = out[0], 0.0
+        for i, f in enumerate(fac):
+            e = rel_l1(out[i] / float(np.float32(f)), base)
+            worst = max(worst, e)
+            # (a power of two only moves exponents — unless it pushes fp32 inputs into subnormals, which 2^-90 does not)
+            assert e < (1e-7 if f in (2.0 ** -90, 2.0 ** 80) else 2e-5), (prec, f, e)
+        e1 = rel_l1(out[len(fac) + 1] / 2.0 ** -60, out[len(fac)])
+        assert e1 < 1e-7, e1
+        report("cnn_scale_invariance_" + prec, worst_rel_l1=worst, factors=[float(f) for f in fac])
+    finally:
+        eng.set_precision("f16x2")
+
+
 def test_longest_caption_full_size(full_engine):
     """max_caption_length = 20 words + EOS (config.py:34): the deepest reverse scan, t = 20, vs the oracle."""
     eng, w, V = full_engine
