@@ -209,8 +209,8 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  *                 bits, carried scaled by a per-token power of two that every layer re-derives from the measured
  *                 maximum of its input and its weight norm); the weights are fp16 pairs scaled by a power of two per
  *                 matrix.  Layers after the last pool (VGG16: block5) take the full product hi*hi' + hi*lo' + lo*hi'
- *                 (three v_mfma_f32_32x32x16_f16, fp32 accumulation); every layer below reads only the hi half of the
- *                 weights: TWO MFMAs per product.  Measured parity of the heat-maps vs the float64 reference graph:
+ *                 (three v_mfma_f32_32x32x16_f16, fp32 accumulation); every layer below with at least 64 output channels
+ *                 (576 products per sum) reads only the hi half of the weights: TWO MFMAs per product.  Measured parity of the heat-maps vs the float64 reference graph:
  *                 2.7e-6 at the bench configuration, median 3.7e-6 / worst 2.4e-5 (one arg-max flip) over 13 seeds —
  *                 the same as LRP_PREC_BF16X3 (bar 1e-4).  Two-term products in the top block as well would cost
  *                 1e-4 (the relevance there is too concentrated for the weight rounding to average out) and are not

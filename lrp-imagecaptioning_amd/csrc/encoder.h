@@ -798,8 +798,8 @@ struct Encoder {
         (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1);
         (void)hipEventRecord(pr.e0, st);
       }
-      // PREC_F16X2: two MFMAs per product (the weights as ONE fp16, 11 bits) below the top block, three (fp16 pairs on
-      // both sides) in the layers after the last pool.  [MI355X, bench configuration, relative L1 vs the float64 graph:
+      // PREC_F16X2: two MFMAs per product (the weights as ONE fp16, 11 bits) below the top block where a sum has at
+      // least 576 products (64 channels), three (fp16 pairs on both sides) in the layers after the last pool.  [MI355X, bench configuration, relative L1 vs the float64 graph:
       // all layers three-term 2.8e-6 | two-term up to block4 3.1e-6 | two-term in block5 as well 9.7e-5 — the
       // relevance entering the top block is so concentrated that a sum has one or two dominant products and the
       // weight rounding, the same for every token, no longer averages out; profiles/r02_f16_terms_sweep.txt]
@@ -809,7 +809,7 @@ struct Encoder {
         int last_pool = -1;
         for (size_t q = 0; q < layers.size(); ++q)
           if (layers[q].pool_after) last_pool = (int)q;
-        if ((int)li <= last_pool) terms = 5;
+        if ((int)li <= last_pool && 9 * L.cout >= 576) terms = 5;      // (narrow test nets: too few products to average over)
         static const int t2mask = [] { const char* e = getenv("LRP_F16_T2MASK"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
         if (t2mask >= 0) terms = ((t2mask >> li) & 1) ? 5 : 7;
       }
