@@ -25,6 +25,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 namespace lrp {
 
@@ -87,6 +89,31 @@ enum ConvEpi {
 };
 constexpr int IMG_PATCH = 16, IMG_TILE = 14;
 
+// Halo-resident launches walk the image STACK (all tokens on top of each other) tile row by tile row.  The gate a tile is
+// multiplied with belongs to the token's IMAGE, and with several tokens per image (10 words per caption) the same gate rows
+// were fetched once per token — the stack order puts 25 tile rows of other traffic between two uses, far more than an
+// XCD's 4 MB of L2 [MI355X, block1_conv2: FETCH_SIZE 8.2 GB = S_in 4.1 + 10 x 0.41 of gates].  TileOrder is a per-layer
+// host cache of a permutation of the tile rows — sorted by (image, row band, token) — so that the tiles of an image's
+// tokens at the same height run back to back on one XCD; built from the call's token -> image map, rebuilt only when that
+// map changes.  Tiles are independent, so the order changes no result bit.
+struct TileOrder {
+  std::vector<int> sig;                                 // token -> image map the table was built for
+  int H = 0, th = 0, nyh = 0;
+  bool identity = true;
+  int* dev = nullptr;
+  int* pinned = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;                              // the last upload
+  TileOrder() = default;
+  TileOrder(const TileOrder&) = delete;
+  TileOrder& operator=(const TileOrder&) = delete;
+  ~TileOrder() {
+    if (dev) (void)hipFree(dev);
+    if (pinned) (void)hipHostFree(pinned);
+    if (ev) (void)hipEventDestroy(ev);
+  }
+};
+
 struct ConvArgs {
   const float* in;     // [NB][H][W][Cin] fp32
   const float* wpk;    // [n_tiles*BN][K] fp32, K = taps*CinP, CinP = roundup(Cin,32), zero padded
@@ -127,6 +154,9 @@ struct ConvArgs {
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
   int tw, th, hrows, cols_t, nyh;
+  const int* tile_rows;       // device: permutation of the tile rows (nullptr = stack order); filled by the launcher from:
+  TileOrder* order;           // host: the layer's cache (nullptr = never reorder)
+  const int* row2img_host;    // host copy of row2img for this call (nullptr = identity: one token per image)
   // PREC_F16X2: per-token power-of-two scaling of the fp16 relevance tensors (indexed by the token slot n of a row).
   //   stored input = true * 2^e_in[n], |stored input| <= max_in[n] (measured by the producer).  tok_scale_kernel
   //   (cnn_kernels.h) picks k[n] = floor(log2(30000 / (max_in[n] * wnorm))) — wnorm = max row sum of |w| of the layer's
@@ -212,9 +242,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   }
   int Y0 = 0, x0 = 0, img0 = 0;                          // HALO: first stack row / column of the tile, its image
   if constexpr (HALO) {
-    const int tyt = mt / a.cols_t;
-    Y0 = tyt * a.th;
+    int tyt = mt / a.cols_t;
     x0 = (mt - tyt * a.cols_t) * a.tw;
+    if (a.tile_rows) tyt = a.tile_rows[tyt];
+    Y0 = tyt * a.th;
     img0 = Y0 / a.H;
   }
   // exact small-integer division (operands < 2^22): float estimate + one fix-up step
@@ -1064,6 +1095,57 @@ inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) 
   return best;
 }
 
+// device table of a.order for this call's token -> image map (see TileOrder); nullptr when the stack order is as good
+inline const int* conv_tile_order(const ConvArgs& a, hipStream_t st) {
+  static const int on = [] { const char* e = getenv("LRP_TILE_ORDER"); return e ? atoi(e) : 1; }();
+  if (!on || !a.order || !a.row2img_host || a.NB < 2 || a.th < 1) return nullptr;
+  TileOrder& o = *a.order;
+  const int tiles_y = (a.nyh + a.th - 1) / a.th;
+  const bool same = o.H == a.H && o.th == a.th && o.nyh == a.nyh && (int)o.sig.size() == a.NB &&
+                    memcmp(o.sig.data(), a.row2img_host, (size_t)a.NB * sizeof(int)) == 0;
+  if (same) return o.identity ? nullptr : o.dev;
+  o.sig.assign(a.row2img_host, a.row2img_host + a.NB);
+  o.H = a.H; o.th = a.th; o.nyh = a.nyh;
+  std::vector<long long> key((size_t)tiles_y);
+  for (int ty = 0; ty < tiles_y; ++ty) {
+    int Ym = ty * a.th + a.th / 2;
+    if (Ym > a.nyh - 1) Ym = a.nyh - 1;
+    const int t = Ym / a.H, hpos = Ym - t * a.H;
+    static const int band = [] { const char* e = getenv("LRP_TILE_BAND"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+    key[ty] = ((long long)o.sig[t] << 42) | ((long long)(hpos / (a.th * band)) << 21) | (long long)t;
+  }
+  std::vector<int> perm((size_t)tiles_y);
+  for (int i = 0; i < tiles_y; ++i) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return key[x] < key[y]; });
+  o.identity = true;
+  for (int i = 0; i < tiles_y; ++i)
+    if (perm[i] != i) { o.identity = false; break; }
+  if (o.identity) return nullptr;
+  if (o.ev) (void)hipEventSynchronize(o.ev);            // the staging buffer may still feed the previous upload
+  if (o.cap < (size_t)tiles_y) {
+    if (o.dev) (void)hipFree(o.dev);
+    if (o.pinned) (void)hipHostFree(o.pinned);
+    o.dev = o.pinned = nullptr;
+    o.cap = 0;
+    if (hipMalloc((void**)&o.dev, (size_t)tiles_y * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&o.pinned, (size_t)tiles_y * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      o.sig.clear();                                    // (try again next call; this one runs in stack order)
+      return nullptr;
+    }
+    o.cap = (size_t)tiles_y;
+  }
+  memcpy(o.pinned, perm.data(), (size_t)tiles_y * sizeof(int));
+  if (!o.ev) (void)hipEventCreateWithFlags(&o.ev, hipEventDisableTiming);
+  if (hipMemcpyAsync(o.dev, o.pinned, (size_t)tiles_y * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) {
+    (void)hipGetLastError();
+    o.sig.clear();
+    return nullptr;
+  }
+  (void)hipEventRecord(o.ev, st);
+  return o.dev;
+}
+
 // EPI_IMG_STENCIL: NB = image slots (tokens), H x W = the image; in = S_1 (NB, H, W, Cin); N = 54 <= 64
 template <int PREC>
 inline hipError_t conv_launch_img(ConvArgs a, hipStream_t st) {
@@ -1129,6 +1211,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+          a.tile_rows = conv_tile_order(a, st);
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true, TERMS>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }
@@ -1140,6 +1223,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
         a.nyh = a.NB * a.H;
         a.cols_t = (a.W + a.tw - 1) / a.tw;
         a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+        if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) a.tile_rows = conv_tile_order(a, st);
         const dim3 hgrid(a.m_tiles * a.n_tiles);
         if (wide == 256)
           hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true, false, TERMS>), hgrid, dim3(512), 0, st, a);

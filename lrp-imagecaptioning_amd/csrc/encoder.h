@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,7 @@ struct ConvLayer {
   DevBuf w_bwd_h;     // w_bwd in fp16 split8 form [hi8 | lo8] (PREC_F16X2 reverse walk: only hi is read), and ...
   DevBuf w_bwd_frag_h;   // ... fragment-major for the weights-in-registers kernel
   DevBuf wbs, wfs;    // device records {2^k, 2^-k, norm, k} of the fp16 copies' power-of-two scales (backward / forward matrix)
+  std::unique_ptr<TileOrder> order{new TileOrder};   // tile-row order of this layer's reverse launch (conv_igemm.h)
   DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
@@ -69,6 +71,8 @@ struct Encoder {
   bool features_only = false;
   bool profile = false;
   int prec = PREC_BF16X3;  // arithmetic of the per-token reverse walk (lrp_set_precision); falls back to fp32 for widths % 8 != 0
+  const int* row2img_host = nullptr;   // host copy of the NEXT explain call's token -> image map (one-shot; lets the launcher
+                                       // order the tiles so that an image's gates are fetched once, conv_igemm.h TileOrder)
   bool walk_f16 = true;    // LRP_PREC_F16X2 (default): the LRP reverse walk on fp16 pairs, 2 MFMAs per product below the top block
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
   DevBuf tok_exp, tok_max, tok_fac;   // its per-token scale exponents / measured maxima [layers + 1][max_tokens], factors [max_tokens]
@@ -696,6 +700,8 @@ struct Encoder {
   // before that layer's backward-data conv is launched; the image layer itself is then skipped (R_img_dev may be null).
   int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st, int walk = 0,
               const std::function<int(int, const float*)>* layer_hook = nullptr) {
+    const int* r2i_host = row2img_host;
+    row2img_host = nullptr;                              // one-shot
     if (n < 1 || n > max_tokens) return fail(LRP_ERR_INVALID, "n=%d outside [1,%d]", n, max_tokens);
     if (walk < 0 || walk > 3) return fail(LRP_ERR_INVALID, "unknown walk %d", walk);
     if (encoded < 1 || features_only) return fail(LRP_ERR_STATE, "lrp_encode_images must run before the CNN explain");
@@ -778,6 +784,7 @@ struct Encoder {
         if (li > 0) ca.tok_max_out = lev_max(li - 1);
       }
       ca.row2img = row2img_dev;
+      ca.order = L.order.get(); ca.row2img_host = r2i_host;
       ca.gate_binary = walk != 0; ca.relu_out = walk == 3;
       int epi;
       if (li == 0 && img_fused()) {

@@ -319,6 +319,7 @@ int lrp_cnn_explain(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const
     if (h->encoded() < 1 || h->features_only()) return fail(LRP_ERR_STATE, "lrp_encode_images must run before lrp_cnn_explain");
     LRP_TRY(stage_indices(h, n, img_idx_host, nullptr, false, S(stream)));
     if (h->resnet) return h->rn.explain(n, h->idx_dev.as<int>(), R_feat_dev, R_img_dev, S(stream));
+    h->enc.row2img_host = h->idx_pinned;
     return h->enc.explain(n, h->idx_dev.as<int>(), R_feat_dev, R_img_dev, S(stream));
   });
 }
@@ -332,6 +333,7 @@ int lrp_explain_tokens(lrp_handle* h, int32_t n, const int32_t* img_idx_host, co
     LRP_TRY(h->dec.explain(n, h->idx_dev.as<int>(), h->idx_dev.as<int>() + n, img_idx_host, t_host, variant,
                            h->feat(), rf, att_dev, r_words_dev, S(stream)));
     if (h->resnet) return h->rn.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
+    h->enc.row2img_host = h->idx_pinned;
     return h->enc.explain(n, h->idx_dev.as<int>(), rf, R_img_dev, S(stream));
   });
 }
@@ -357,6 +359,7 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
     if (h->resnet && walk != LRP_WALK_LRP) return fail(LRP_ERR_UNSUPPORTED, "gradient walks exist for the conv-list (VGG) encoder only");
     LRP_TRY(stage_indices(h, n, img_idx_host, nullptr, false, S(stream)));
     if (h->resnet) return h->rn.explain(n, h->idx_dev.as<int>(), head_dev, out_dev, S(stream));
+    h->enc.row2img_host = h->idx_pinned;
     return h->enc.explain(n, h->idx_dev.as<int>(), head_dev, out_dev, S(stream), walk);
   });
 }
