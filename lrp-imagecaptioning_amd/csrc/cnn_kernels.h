@@ -156,6 +156,11 @@ __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restr
     bool pos = pos_only != 0;
     float v = 0.f;
     if (!bwd) {
+      if (dual == 2) {                                  // interleaved dual: blocks of 32 rows, [w | w+] of the same 32 channels
+        const int blk = row >> 5;
+        pos = (blk & 1) != 0;
+        row = (blk >> 1) * 32 + (row & 31);
+      } else
       if (dual && row >= Cout) { row -= Cout; pos = true; }
       if (row < Cout && c < Cin) v = w[((size_t)t * Cin + c) * Cout + row];
     } else {

@@ -150,6 +150,17 @@ struct ConvArgs {
   // active and it won its pool window), and guided backprop also clamps the propagated value at 0
   int gate_binary, relu_out;
   int dual_norelu;     // EPI_FWD_DUAL: first half without the relu (a conv + BatchNorm unit: c and Z+ in one pass)
+  // EPI_FWD_DUAL, interleaved weights (dual_il): the stacked matrix has its rows in blocks of 32 — [w of channels 32g..32g+31 |
+  // w+ of the SAME channels] — so a tile holds c and Z+ of a channel side by side and the epilogue can finish the pair:
+  // dual_gate = 1: out = a_l = relu(c), out2 = the relevance gate G_l = a_l / safe(Z+_l) (IL:456-458); Z+_l never goes to
+  // memory and no gate pass follows.  dual_gate = 0: out2 = Z+_l as in the stacked form.  Needs split % 32 == 0.
+  int dual_il, dual_gate;
+  // dual_gate = 2 (a conv + BatchNorm unit of the ResNet encoder, RA:197-257 folded with alpha1beta0; resnet_kernels.h
+  // rn_bn_unit_kernel is the unfused form): with c = conv + b, Z = the alpha1beta0 denominator,
+  //   y = gamma (c - mean) / sqrt(var + eps) + beta,  Q = c (y - beta) / stab((c - mean) y) / safe(Z)
+  //   bn_relu: out = relu(y), out2 = relu(y) Q      else: out = y, out2 = Q
+  const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var;
+  float bn_eps; int bn_relu;
   // halo-resident 3x3 variant (template HALO): a tile is th rows x tw (<= 14) columns of the image stack
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
@@ -862,6 +873,61 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
           }
         }
       } else if constexpr (EPI == EPI_FWD_DUAL) {
+        if (a.dual_il) {
+          // interleaved columns: tile column p -> block p / 32; even block = c of channels ch.., the odd block behind it =
+          // Z+ of the same channels.  The two threads that own a channel quad (one per block) share its rows by parity.
+          const int p = c4 * 4, half = (p >> 5) & 1;
+          const int ch = (n0 >> 1) + (p >> 6) * 32 + (p & 31);
+          if (ch < a.split) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + ch);
+            const int pc = (p & ~63) + (p & 31);          // the c column of the pair; Z+ sits 32 further
+            float unscale = 1.f, omax = 0.f;
+            if constexpr (PREC == PREC_F16X2) unscale = *a.in_unscale;
+#pragma unroll 2
+            for (int ps = half; ps < RH / RPP; ps += 2) {
+              const int ll = rin + ps * RPP;
+              int row, n_, h_, w_;
+              if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
+              f32x4 vc = *reinterpret_cast<const f32x4*>(Cs + ll * BN + pc);
+              f32x4 vz = *reinterpret_cast<const f32x4*>(Cs + ll * BN + pc + 32);
+              if constexpr (PREC == PREC_F16X2) { vc *= unscale; vz *= unscale; }
+              vc += bv; vz += bv;
+              if (!a.dual_norelu) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vc[q] = fmaxf(vc[q], 0.f);
+              }
+              if (a.dual_gate == 2) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(a.bn_gamma + ch), be = *reinterpret_cast<const f32x4*>(a.bn_beta + ch);
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(a.bn_mean + ch), va = *reinterpret_cast<const f32x4*>(a.bn_var + ch);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const float cv = vc[q];
+                  const float y = ga[q] * (cv - mu[q]) / sqrtf(va[q] + a.bn_eps) + be[q];
+                  const float d = (cv - mu[q]) * y;
+                  const float ds = d + (d >= 0.f ? 1e-7f : -1e-7f);                      // sign stabiliser, then SafeDivide
+                  const float qq = (cv * (y - be[q])) / (ds + (ds == 0.f ? 1e-7f : 0.f)) / (vz[q] + (vz[q] == 0.f ? 1e-7f : 0.f));
+                  const float av = a.bn_relu ? fmaxf(y, 0.f) : y;
+                  vc[q] = av;
+                  vz[q] = a.bn_relu ? av * qq : qq;
+                }
+              } else if (a.dual_gate) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vz[q] = vc[q] / (vz[q] + (vz[q] == 0.f ? 1e-7f : 0.f));
+              }
+              if constexpr (PREC == PREC_F16X2)
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3]))));
+              *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.split + ch) = vc;
+              *reinterpret_cast<f32x4*>(a.out2 + (size_t)row * a.split + ch) = vz;
+            }
+            if constexpr (PREC == PREC_F16X2) {
+              if (a.act_max_out) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+                if (lane == 0 && omax > 0.f) atomicMax(a.act_max_out + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)), __float_as_uint(omax));
+              }
+            }
+          }
+        } else
         // cols [0,split) -> out = relu(acc + bias)  (a_l);  cols [split,2 split) -> out2 = acc + bias  (Z+_l)
         if (col < 2 * a.split) {
           const bool isz = col >= a.split;
@@ -1170,6 +1236,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if ((EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) && (a.N & 3)) return hipErrorInvalidValue;
   if (PREC != PREC_FP32 && (a.Cin & 7)) return hipErrorInvalidValue;
   if (EPI == EPI_FWD_DUAL && (a.split & 3)) return hipErrorInvalidValue;
+  if (EPI == EPI_FWD_DUAL && a.dual_il && ((a.split & 31) || a.N != 2 * a.split)) return hipErrorInvalidValue;
   ConvTile t = conv_pick_tile(a.N);
   if (PREC == PREC_FP32 && t.BN == 128 && (a.N % 64) == 0) {
     // few M rows (the per-image forward at batch 32): 128 x 128 tiles leave CUs idle; halve the tile

@@ -38,6 +38,7 @@ struct ConvLayer {
   DevBuf w_bwd_h;     // w_bwd in fp16 split8 form [hi8 | lo8] (PREC_F16X2 reverse walk: only hi is read), and ...
   DevBuf w_bwd_frag_h;   // ... fragment-major for the weights-in-registers kernel
   DevBuf wbs, wfs;    // device records {2^k, 2^-k, norm, k} of the fp16 copies' power-of-two scales (backward / forward matrix)
+  DevBuf w_fwd_il;    // the dual forward matrix with its rows interleaved per 32 channels ([w | w+] side by side): fp32 source of w_fwd_h
   std::unique_ptr<TileOrder> order{new TileOrder};   // tile-row order of this layer's reverse launch (conv_igemm.h)
   DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
   DevBuf bias;
@@ -119,6 +120,13 @@ struct Encoder {
     const char* e = getenv("LRP_FWD_DUAL");
     return !e || atoi(e) != 0;
   }
+  // fp16-pair dual forward with interleaved weight rows: a_l and the gate G_l = a_l / safe(Z+_l) leave the conv's epilogue
+  // together where no pool follows (conv_igemm.h ConvArgs::dual_il) — no Z+ tensor, no gate pass.  LRP_FWD_IL=0: stacked rows.
+  static bool fwd_il() {
+    const char* e = getenv("LRP_FWD_IL");
+    return !e || atoi(e) != 0;
+  }
+  static bool dual_interleaved(const ConvLayer& L) { return fwd_il() && !(L.cout & 31) && conv_npad(2 * L.cout) == 2 * L.cout; }
   static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
     const char* e = getenv("LRP_FWD_X6");
     return !e || atoi(e) != 0;
@@ -270,7 +278,16 @@ struct Encoder {
       LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
       LRP_TRY(L.w_fwd_h.alloc(pk.size() * sizeof(float), total));
-      LRP_TRY(make_f16_operand(L.w_fwd.as<float>(), pk.size(), 0, 0, L.w_fwd_h, L.wds, total, nullptr));
+      if (dual_interleaved(L)) {
+        std::vector<float> il(pk.size(), 0.f);            // rows in blocks of 32: [w | w+] of the same 32 channels
+        for (int c = 0; c < L.cout; ++c)
+          for (int half = 0; half < 2; ++half)
+            memcpy(&il[(size_t)(64 * (c / 32) + 32 * half + (c & 31)) * K], &pk[(size_t)(half * L.cout + c) * K], (size_t)K * sizeof(float));
+        LRP_TRY(L.w_fwd_il.alloc(il.size() * sizeof(float), total));
+        LRP_HIP_CHECK(hipMemcpy(L.w_fwd_il.p, il.data(), il.size() * sizeof(float), hipMemcpyHostToDevice));
+      }
+      LRP_TRY(make_f16_operand(dual_interleaved(L) ? L.w_fwd_il.as<float>() : L.w_fwd.as<float>(), pk.size(), 0, 0, L.w_fwd_h, L.wds,
+                               total, nullptr));
       {  // mixed-precision forward: w (fp32) and w+ (split8) as separate N = cout matrices
         const int Npa = conv_npad(L.cout);
         std::vector<float> pa((size_t)Npa * K, 0.f), pz((size_t)Npa * K, 0.f), pzs((size_t)Npa * K);
@@ -357,6 +374,7 @@ struct Encoder {
     const size_t Kf = (size_t)9 * conv_cinp(L.cin), Kb = (size_t)9 * conv_cinp(L.cout);
     const size_t nf = (size_t)conv_npad(L.cout) * Kf, nb = (size_t)conv_npad(L.cin) * Kb;
     LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf)); LRP_TRY(mk(L.w_fwd_h, (size_t)conv_npad(2 * L.cout) * Kf));
+    if (dual_interleaved(L)) LRP_TRY(mk(L.w_fwd_il, (size_t)conv_npad(2 * L.cout) * Kf));
     LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
     LRP_TRY(mk(L.w_fwd_ah, nf));
     LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
@@ -390,7 +408,9 @@ struct Encoder {
     };
     const size_t nf = (size_t)Npa * 9 * CPi, nb = (size_t)Npb * 9 * CPo;
     pack(L.w_fwd.as<float>(), 0, Np2, 1, 0);
-    LRP_TRY(make_f16_operand(L.w_fwd.as<float>(), (size_t)Np2 * 9 * CPi, 0, 0, L.w_fwd_h, L.wds, nullptr, st, false));
+    if (dual_interleaved(L)) pack(L.w_fwd_il.as<float>(), 0, Np2, 2, 0);
+    LRP_TRY(make_f16_operand(dual_interleaved(L) ? L.w_fwd_il.as<float>() : L.w_fwd.as<float>(), (size_t)Np2 * 9 * CPi, 0, 0, L.w_fwd_h,
+                             L.wds, nullptr, st, false));
     pack(L.w_fwd_a.as<float>(), 0, Npa, 0, 0);
     pack(tmp, 0, Npa, 0, 1);
     split(tmp, L.w_fwd_zs.as<float>(), nf);
@@ -532,8 +552,17 @@ struct Encoder {
           cd.out = a_out; cd.out2 = top ? ztop.as<float>() : bufZ.as<float>();
           cd.in_unscale = act_unscale.as<float>() + li;
           cd.act_max_out = act_max.as<unsigned>() + li * ACT_MAX_SLOTS;
+          cd.dual_il = dual_interleaved(L) ? 1 : 0;
+          const bool fused_gate = cd.dual_il && !top && !L.pool_after;
+          if (fused_gate) {
+            // a_l and G_l leave the epilogue together: a_l into a ping-pong buffer its consumer (the next layer's split)
+            // reads once (or where the fine-tune step looks for it), the gate straight into its cache
+            if (!keep_acts) a_out = xin[li] == bufA.as<float>() ? bufX.as<float>() : bufA.as<float>();
+            cd.out = a_out; cd.out2 = L.G.as<float>(); cd.dual_gate = 1;
+          }
           LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2));
           if (top) break;
+          if (fused_gate) { xin[li + 1] = a_out; continue; }
           if (L.pool_after) {
             const size_t n = (size_t)B * L.act_elems();
             hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);

@@ -28,6 +28,7 @@ struct RnUnit {            // conv + BN
   DevBuf w_a, w_z, w_b, w_bs, bias, gamma, beta, mean, var;   // w_bs: w_b in split8 form (bf16x3 reverse walk)
   DevBuf w_dual;   // [w rows | w+ rows]: c and Z+ of the unit in one conv pass (EPI_FWD_DUAL without the relu)
   DevBuf w_dual_h, wds;    // w_dual as fp16 pairs scaled by a power of two + its scale record (f16_operand.h)
+  bool dual_il = false;    // ... with its rows interleaved per 32 channels ([w | w+] side by side): BN + gate in the conv's epilogue
   DevBuf gate;             // [B][Hout][Wout][cout]: act*Q (relu units) or Q (pre-Add units)
   size_t out_elems() const { return (size_t)Hout * Wout * cout; }
   size_t in_elems() const { return (size_t)Hin * Win * cin; }
@@ -196,8 +197,20 @@ struct ResNetEncoder {
       pack_conv_fwd(w, taps, u.cin, u.cout, 0, Nd, pk.data());
       pack_conv_fwd(wp.data(), taps, u.cin, u.cout, u.cout, Nd, pk.data());
       LRP_TRY(up(u.w_dual, pk, total));
-      if (!(u.cin & 7))
-        LRP_TRY(make_f16_operand(f16_slots, u.w_dual.as<float>(), pk.size(), 0, 0, u.w_dual_h, u.wds, total, nullptr));
+      if (!(u.cin & 7)) {
+        u.dual_il = fwd_il() && !(u.cout & 31) && Nd == 2 * u.cout;
+        if (u.dual_il) {                                  // rows in blocks of 32: [w | w+] of the same 32 channels
+          std::vector<float> il(pk.size(), 0.f);
+          for (int c = 0; c < u.cout; ++c)
+            for (int half = 0; half < 2; ++half)
+              memcpy(&il[(size_t)(64 * (c / 32) + 32 * half + (c & 31)) * K], &pk[(size_t)(half * u.cout + c) * K], (size_t)K * sizeof(float));
+          DevBuf tmp;
+          LRP_TRY(up(tmp, il, nullptr));
+          LRP_TRY(make_f16_operand(f16_slots, tmp.as<float>(), pk.size(), 0, 0, u.w_dual_h, u.wds, total, nullptr));
+        } else {
+          LRP_TRY(make_f16_operand(f16_slots, u.w_dual.as<float>(), pk.size(), 0, 0, u.w_dual_h, u.wds, total, nullptr));
+        }
+      }
     }
     const int Npb = conv_npad(u.cin), Kb = taps * conv_cinp(u.cout);
     pk.assign((size_t)Npb * Kb, 0.f);
@@ -245,6 +258,14 @@ struct ResNetEncoder {
       LRP_HIP_CHECK(hipGetLastError());
       ca.in = fxs.as<float>(); ca.wpk = u.w_dual_h.as<float>(); ca.N = 2 * u.cout; ca.split = u.cout; ca.dual_norelu = 1;
       ca.out = fc.as<float>(); ca.out2 = fz.as<float>(); ca.in_unscale = act_unscale.as<float>() + ui;
+      if (u.dual_il) {
+        // BatchNorm, ReLU and the unit's gate in the conv's epilogue: c and Z+ never go to memory (conv_igemm.h dual_gate = 2)
+        ca.dual_il = 1; ca.dual_gate = 2; ca.bn_gamma = u.gamma.as<float>(); ca.bn_beta = u.beta.as<float>();
+        ca.bn_mean = u.mean.as<float>(); ca.bn_var = u.var.as<float>(); ca.bn_eps = RN_BN_EPS; ca.bn_relu = u.relu ? 1 : 0;
+        ca.out = act; ca.out2 = u.gate.as<float>(); ca.act_max_out = slots_out;
+        LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st, PREC_F16X2));
+        return LRP_OK;
+      }
       LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st, PREC_F16X2));
     } else if (u.w_dual.p && dual_fwd()) {
       // c = conv(x, w) + b and Z = conv(x, w+) + b in ONE pass over x: the A tile is staged once for both
@@ -469,6 +490,10 @@ struct ResNetEncoder {
   }
   static bool fwd_f16() {                  // LRP_RN_F16=0: the forward convs on the fp32 MFMA
     const char* e = getenv("LRP_RN_F16");
+    return !e || atoi(e) != 0;
+  }
+  static bool fwd_il() {                   // LRP_RN_IL=0: stacked dual rows, separate BN + gate pass
+    const char* e = getenv("LRP_RN_IL");
     return !e || atoi(e) != 0;
   }
   static bool fuse_tail() {                // LRP_RN_FUSE=0: separate element-wise join / head kernels
