@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         f.b[2 * j] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st]);
-        if constexpr (PREC != PREC_F16X2 || (TERMS & 2) != 0)   // (fp16 weights, two-term form: their lo chunk is never read)
+        if (PREC != PREC_F16X2 || ((TERMS & 2) != 0 && !((TERMS & 16) != 0 && (j & 1))))   // (two-term form: the lo chunk is never read)
           f.b[2 * j + 1] = *reinterpret_cast<const u32x4*>(Bb + j * 32 * LDS_STRIDE + koff[2 * st + 1]);
       }
     } else {
@@ -541,7 +541,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
           const f16x8 ah = __builtin_bit_cast(f16x8, f.a[2 * i]), al = __builtin_bit_cast(f16x8, f.a[2 * i + 1]);
           const f16x8 bh = __builtin_bit_cast(f16x8, f.b[2 * j]);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[i][j], 0, 0, 0);    // small terms first
-          if constexpr ((TERMS & 2) != 0)                 // TERMS 7: the weights' lo half too (layers with a short K, below)
+          // TERMS 7: the weights' lo half too.  TERMS bit 4 (interleaved dual forward): not for the odd column tiles = Z+
+          if ((TERMS & 2) != 0 && !((TERMS & 16) != 0 && (j & 1)))          // (folds once the j loop is unrolled)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, f.b[2 * j + 1]), acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[i][j], 0, 0, 0);
         }
@@ -1333,6 +1334,10 @@ inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int pr
   if (prec == PREC_F16X2) {                            // reverse walk of the VGG encoder only
     // terms 7: S(hi + lo) x w(hi + lo) without lo*lo — three MFMAs; terms 5: the weights' lo half dropped — two.  Which
     // layers take which is the caller's rule (Encoder::explain: two-term up to the last pool, measured there).
+    if (terms == 23) {                                 // interleaved dual forward, Z+ column tiles two-term
+      if (epi == EPI_FWD_DUAL && a.dual_il) return conv_launch_epi<EPI_FWD_DUAL, PREC_F16X2, 23>(a, st);
+      return hipErrorInvalidValue;
+    }
     if (terms == 5) {
       if (epi == EPI_MUL) return conv_launch_epi<EPI_MUL, PREC_F16X2, 5>(a, st);
       if (epi == EPI_MUL_UP2) return conv_launch_epi<EPI_MUL_UP2, PREC_F16X2, 5>(a, st);

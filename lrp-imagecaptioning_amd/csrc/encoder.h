@@ -127,6 +127,10 @@ struct Encoder {
     return !e || atoi(e) != 0;
   }
   static bool dual_interleaved(const ConvLayer& L) { return fwd_il() && !(L.cout & 31) && conv_npad(2 * L.cout) == 2 * L.cout; }
+  static bool fwd_z2() {
+    const char* e = getenv("LRP_FWD_Z2");
+    return !e || atoi(e) != 0;
+  }
   static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
     const char* e = getenv("LRP_FWD_X6");
     return !e || atoi(e) != 0;
@@ -560,7 +564,19 @@ struct Encoder {
             if (!keep_acts) a_out = xin[li] == bufA.as<float>() ? bufX.as<float>() : bufA.as<float>();
             cd.out = a_out; cd.out2 = L.G.as<float>(); cd.dual_gate = 1;
           }
-          LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2));
+          // The denominators Z+_l of the layers whose reverse launch is two-term (explain(): up to the last pool, >= 576
+          // products) are computed two-term as well — with the SAME rounded weights hi(w+) the walk multiplies with.
+          // [MI355X: parity at the bench configuration 5.5e-6 -> 4.4e-6, 6 seeds median 4.2e-6 -> 3.3e-6: gate and
+          // transposed conv now belong to one (slightly perturbed) network and the rounding largely cancels in R / Z+;
+          // two-term Z+ in EVERY layer: 1.0e-4, the top block again.]  LRP_FWD_Z2=0: three-term everywhere.
+          int fterms = 7;
+          if (cd.dual_il && walk_f16 && fwd_z2() && 9 * L.cin >= 576) {
+            int last_pool = -1;
+            for (size_t q = 0; q < layers.size(); ++q)
+              if (layers[q].pool_after) last_pool = (int)q;
+            if ((int)li <= last_pool) fterms = 23;
+          }
+          LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2, fterms));
           if (top) break;
           if (fused_gate) { xin[li + 1] = a_out; continue; }
           if (L.pool_after) {
