@@ -210,13 +210,15 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  *                 maximum of its input and its weight norm); the weights are fp16 pairs scaled by a power of two per
  *                 matrix.  Layers after the last pool (VGG16: block5) take the full product hi*hi' + hi*lo' + lo*hi'
  *                 (three v_mfma_f32_32x32x16_f16, fp32 accumulation); every layer below with at least 64 output channels
- *                 (576 products per sum) reads only the hi half of the weights: TWO MFMAs per product.  Measured parity of the heat-maps vs the float64 reference graph:
- *                 2.7e-6 at the bench configuration, median 3.7e-6 / worst 2.4e-5 (one arg-max flip) over 13 seeds —
- *                 the same as LRP_PREC_BF16X3 (bar 1e-4).  Two-term products in the top block as well would cost
+ *                 (576 products per sum) reads only the hi half of the weights: TWO MFMAs per product — and the
+ *                 denominators Z+ of exactly those layers are computed in the forward with the same rounded weights,
+ *                 so gate and transposed conv belong to one network and the rounding largely cancels.  Measured parity
+ *                 of the heat-maps vs the float64 reference graph: 4.4e-6 at the bench configuration, median 3.3e-6 /
+ *                 worst 2.5e-5 (one arg-max flip) over 13 seeds — the same as LRP_PREC_BF16X3 (bar 1e-4).  Two-term products in the top block as well would cost
  *                 1e-4 (the relevance there is too concentrated for the weight rounding to average out) and are not
- *                 offered.  Conv widths % 8 != 0 silently use the fp32 path.  The per-image forward is fp32-grade in
- *                 every mode except _FAST (fp16 pairs on both operands, three MFMAs, blocked accumulation: 7e-7 on the
- *                 features like the fp32 MFMA).  The ResNet encoder's walk runs as LRP_PREC_BF16X3 in this mode.
+ *                 offered.  Conv widths % 8 != 0 silently use the fp32 path.  The per-image forward's activations are fp32-grade
+ *                 in every mode except _FAST (fp16 pairs on both operands, three MFMAs, blocked accumulation: 7e-7 on
+ *                 the features like the fp32 MFMA).  The ResNet encoder's walk runs as LRP_PREC_BF16X3 in this mode.
  * LRP_PREC_BF16X3 split-bf16 walk: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
  *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — three MFMAs
  *                 in every layer, no scaling state.  Parity as above; ~6 % slower than the default on MI355X (the
