@@ -43,12 +43,14 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //   (5.3x fewer matrix-pipe cycles).  Used for the per-token reverse walk only; the per-image forward
 //   stays exact fp32 (measured: forward fp32 + backward split = 2-3.5e-6 relative L1 vs the float64
 //   graph; splitting the forward too = 2.4e-5, because errors in Z / a are systematic, errors in S average out).
-// PREC_F16X2 : the relevance operand S as an fp16 pair hi + lo (22 mantissa bits) in the same split8 layout, the weights
-//   as ONE fp16 (11 bits; their lo half is not read): product = lo*w + hi*w, TWO MFMAs of v_mfma_f32_32x32x16_f16 per
-//   16 k.  fp16 has 5 exponent bits, so S is carried scaled by a per-token power of two, chosen per layer from the
-//   measured maximum of the layer's input and the layer's weight norm (ConvArgs::tok_*; Encoder::explain).  What it
-//   costs: the weight rounding (2^-12, systematic per weight) puts the heat-maps at ~2-3e-5 relative L1 from the float64
-//   graph (bf16x3: ~4e-6; bar 1e-4) [CPU emulation + MI355X, DESIGN 4.1].  Reverse walk of the VGG encoder only.
+// PREC_F16X2 : both operands as fp16 pairs hi + lo (22 mantissa bits) in the same split8 layout, carried scaled by powers
+//   of two taken from MEASURED maxima (fp16 has 5 exponent bits): per token for the relevance S of the reverse walk
+//   (ConvArgs::tok_*; Encoder::explain), per tensor for the forward's activations, per matrix for the weights.
+//   TERMS 7: hi*hi' + hi*lo' + lo*hi', three v_mfma_f32_32x32x16_f16 per 16 k — fp32-grade (forward; top block of the walk).
+//   TERMS 5: the weights' lo half is not read: lo*w + hi*w, TWO MFMAs — the walk's layers below the top block; the
+//   weight rounding (2^-12, the same for every token) averages out there and cancels against the denominators Z+, which
+//   the forward computes with the same rounded weights (TERMS bit 4) [MI355X: 4.4e-6 at the bench configuration vs
+//   3.3e-6 for bf16x3; DESIGN 4.1b].  The default arithmetic of the VGG path.
 enum ConvPrec { PREC_FP32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2 };
 
 __device__ __forceinline__ void split8h_store(const float* r, float* dst) {  // 8 fp32 -> 32 B [fp16 hi8 | fp16 lo8]
