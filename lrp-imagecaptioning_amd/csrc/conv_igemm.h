@@ -95,12 +95,13 @@ constexpr int IMG_PATCH = 16, IMG_TILE = 14;
 // multiplied with belongs to the token's IMAGE, and with several tokens per image (10 words per caption) the same gate rows
 // were fetched once per token — the stack order puts 25 tile rows of other traffic between two uses, far more than an
 // XCD's 4 MB of L2 [MI355X, block1_conv2: FETCH_SIZE 8.2 GB = S_in 4.1 + 10 x 0.41 of gates].  TileOrder is a per-layer
-// host cache of a permutation of the tile rows — sorted by (image, row band, token) — so that the tiles of an image's
-// tokens at the same height run back to back on one XCD; built from the call's token -> image map, rebuilt only when that
-// map changes.  Tiles are independent, so the order changes no result bit.
+// host cache of a permutation of the tiles — ordered by (image, column strip, row band, token) — so that the tiles of an
+// image's tokens at the same place run back to back on one XCD (they share the gate rows in its L2) and a strip's next
+// row band follows within a few dozen tiles (the vertical halo rows of S are still there); built from the call's
+// token -> image map, rebuilt only when that map changes.  Tiles are independent, so the order changes no result bit.
 struct TileOrder {
   std::vector<int> sig;                                 // token -> image map the table was built for
-  int H = 0, th = 0, nyh = 0;
+  int H = 0, th = 0, nyh = 0, cols_t = 0;
   bool identity = true;
   int* dev = nullptr;
   int* pinned = nullptr;
@@ -167,7 +168,7 @@ struct ConvArgs {
   // (all NB images on top of each other: Y = n*H + h), cols_t tiles per image row; hrows = rows of the
   // resident image (th + 2 + separator rows), each HALO_PITCH pixels wide
   int tw, th, hrows, cols_t, nyh;
-  const int* tile_rows;       // device: permutation of the tile rows (nullptr = stack order); filled by the launcher from:
+  const int* tile_map;        // device: launch position -> tile of the stack (nullptr = stack order); filled by the launcher from:
   TileOrder* order;           // host: the layer's cache (nullptr = never reorder)
   const int* row2img_host;    // host copy of row2img for this call (nullptr = identity: one token per image)
   // PREC_F16X2: per-token power-of-two scaling of the fp16 relevance tensors (indexed by the token slot n of a row).
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   }
   int Y0 = 0, x0 = 0, img0 = 0;                          // HALO: first stack row / column of the tile, its image
   if constexpr (HALO) {
-    int tyt = mt / a.cols_t;
-    x0 = (mt - tyt * a.cols_t) * a.tw;
-    if (a.tile_rows) tyt = a.tile_rows[tyt];
+    const int mtp = a.tile_map ? a.tile_map[mt] : mt;    // launch order -> tile of the stack (TileOrder)
+    const int tyt = mtp / a.cols_t;
+    x0 = (mtp - tyt * a.cols_t) * a.tw;
     Y0 = tyt * a.th;
     img0 = Y0 / a.H;
   }
@@ -1170,43 +1171,57 @@ inline const int* conv_tile_order(const ConvArgs& a, hipStream_t st) {
   if (!on || !a.order || !a.row2img_host || a.NB < 2 || a.th < 1) return nullptr;
   TileOrder& o = *a.order;
   const int tiles_y = (a.nyh + a.th - 1) / a.th;
-  const bool same = o.H == a.H && o.th == a.th && o.nyh == a.nyh && (int)o.sig.size() == a.NB &&
+  const bool same = o.H == a.H && o.th == a.th && o.nyh == a.nyh && o.cols_t == a.cols_t && (int)o.sig.size() == a.NB &&
                     memcmp(o.sig.data(), a.row2img_host, (size_t)a.NB * sizeof(int)) == 0;
   if (same) return o.identity ? nullptr : o.dev;
   o.sig.assign(a.row2img_host, a.row2img_host + a.NB);
-  o.H = a.H; o.th = a.th; o.nyh = a.nyh;
+  o.H = a.H; o.th = a.th; o.nyh = a.nyh; o.cols_t = a.cols_t;
+  static const int band = [] { const char* e = getenv("LRP_TILE_BAND"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
+  static const int strip = [] { const char* e = getenv("LRP_TILE_STRIP"); return e ? atoi(e) : 2; }();   // column tiles per strip; 0 = whole rows
   std::vector<long long> key((size_t)tiles_y);
   for (int ty = 0; ty < tiles_y; ++ty) {
     int Ym = ty * a.th + a.th / 2;
     if (Ym > a.nyh - 1) Ym = a.nyh - 1;
     const int t = Ym / a.H, hpos = Ym - t * a.H;
-    static const int band = [] { const char* e = getenv("LRP_TILE_BAND"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
     key[ty] = ((long long)o.sig[t] << 42) | ((long long)(hpos / (a.th * band)) << 21) | (long long)t;
   }
-  std::vector<int> perm((size_t)tiles_y);
-  for (int i = 0; i < tiles_y; ++i) perm[i] = i;
-  std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return key[x] < key[y]; });
+  std::vector<int> rows((size_t)tiles_y);
+  for (int i = 0; i < tiles_y; ++i) rows[i] = i;
+  std::stable_sort(rows.begin(), rows.end(), [&](int x, int y) { return key[x] < key[y]; });
+  // rows are now (image, band, token); within an image, walk the column strips outermost
+  const int sw = strip > 0 && strip < a.cols_t ? strip : a.cols_t;
+  const size_t m_tiles = (size_t)tiles_y * a.cols_t;
+  std::vector<int> map;
+  map.reserve(m_tiles);
+  for (int r0 = 0; r0 < tiles_y;) {
+    int r1 = r0;
+    while (r1 < tiles_y && (key[rows[r1]] >> 42) == (key[rows[r0]] >> 42)) ++r1;
+    for (int c0 = 0; c0 < a.cols_t; c0 += sw)
+      for (int r = r0; r < r1; ++r)
+        for (int c = c0; c < c0 + sw && c < a.cols_t; ++c) map.push_back(rows[r] * a.cols_t + c);
+    r0 = r1;
+  }
   o.identity = true;
-  for (int i = 0; i < tiles_y; ++i)
-    if (perm[i] != i) { o.identity = false; break; }
+  for (size_t i = 0; i < m_tiles; ++i)
+    if (map[i] != (int)i) { o.identity = false; break; }
   if (o.identity) return nullptr;
   if (o.ev) (void)hipEventSynchronize(o.ev);            // the staging buffer may still feed the previous upload
-  if (o.cap < (size_t)tiles_y) {
+  if (o.cap < m_tiles) {
     if (o.dev) (void)hipFree(o.dev);
     if (o.pinned) (void)hipHostFree(o.pinned);
     o.dev = o.pinned = nullptr;
     o.cap = 0;
-    if (hipMalloc((void**)&o.dev, (size_t)tiles_y * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void**)&o.pinned, (size_t)tiles_y * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+    if (hipMalloc((void**)&o.dev, m_tiles * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&o.pinned, m_tiles * sizeof(int), hipHostMallocDefault) != hipSuccess) {
       (void)hipGetLastError();
       o.sig.clear();                                    // (try again next call; this one runs in stack order)
       return nullptr;
     }
-    o.cap = (size_t)tiles_y;
+    o.cap = m_tiles;
   }
-  memcpy(o.pinned, perm.data(), (size_t)tiles_y * sizeof(int));
+  memcpy(o.pinned, map.data(), m_tiles * sizeof(int));
   if (!o.ev) (void)hipEventCreateWithFlags(&o.ev, hipEventDisableTiming);
-  if (hipMemcpyAsync(o.dev, o.pinned, (size_t)tiles_y * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) {
+  if (hipMemcpyAsync(o.dev, o.pinned, m_tiles * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) {
     (void)hipGetLastError();
     o.sig.clear();
     return nullptr;
@@ -1281,7 +1296,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-          a.tile_rows = conv_tile_order(a, st);
+          a.tile_map = conv_tile_order(a, st);
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true, TERMS>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }
@@ -1293,7 +1308,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
         a.nyh = a.NB * a.H;
         a.cols_t = (a.W + a.tw - 1) / a.tw;
         a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-        if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) a.tile_rows = conv_tile_order(a, st);
+        if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) a.tile_map = conv_tile_order(a, st);
         const dim3 hgrid(a.m_tiles * a.n_tiles);
         if (wide == 256)
           hipLaunchKernelGGL((conv_igemm_kernel<2, 4, 4, 2, EPI, PREC, true, false, TERMS>), hgrid, dim3(512), 0, st, a);
