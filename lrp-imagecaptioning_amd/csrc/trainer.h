@@ -50,6 +50,7 @@ struct Trainer {
   ~Trainer() {
     if (host_pinned) (void)hipHostFree(host_pinned);
     if (ev_fwd) (void)hipEventDestroy(ev_fwd);
+    if (cap_st) (void)hipStreamDestroy(cap_st);
   }
   float lr = 0.f, clip = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
   int64_t iter = 0;
@@ -189,6 +190,113 @@ struct Trainer {
     const float *m_if, *m_glob, *m_out, *m_lin, *m_lrec, *m_logits;
     float* grads; float* losses_dev; hipStream_t st;
   };
+
+  // ---- the decoder scans as hipGraphs.  A scan is T steps x ~10-20 launches of 5-16 us each (~450 launches per iteration
+  // for the adaptive decoder), queued by one host thread: at 8 images per GPU the launches, not the kernels, set its
+  // duration.  The sequence depends only on (B, T) and on the pointers in StepIn, so the second consecutive call with the
+  // same arguments is stream-captured and instantiated, and every later one is a single hipGraphLaunch; different arguments
+  // (or a capture the runtime refuses) run the plain launches.  LRP_TRAIN_GRAPH=0 disables.
+  struct ScanGraph {
+    std::vector<long long> key, last;
+    hipGraphExec_t exec = nullptr;
+    bool broken = false;
+    long launches = 0, plain = 0, captures = 0;
+    ~ScanGraph() {
+      if (getenv("LRP_TRAIN_GRAPH_DEBUG")) fprintf(stderr, "[scan graph] captures %ld, graph launches %ld, plain runs %ld, broken %d\n", captures, launches, plain, (int)broken);
+      if (exec) (void)hipGraphExecDestroy(exec);
+    }
+  };
+  ScanGraph g_fwd, g_bwd;
+  hipStream_t cap_st = nullptr;                          // capture stream of the scan graphs
+  // The scans' dropout masks are copied into buffers of the trainer (19 MB at B = 32, T = 21: ~10 us): the caller's fresh
+  // tensors would change the pointers — and with them the graph — every iteration, and the backward scan then reads
+  // exactly the masks its forward used, whatever the caller passes to lrp_train_step.
+  DevBuf Mlin, Mlrec, Mout;
+  const float *s_lin = nullptr, *s_lrec = nullptr, *s_out = nullptr;
+  int stage_masks(const StepIn& in, int64_t* total) {
+    const size_t cap = (size_t)Bm * Tm;
+    auto stage = [&](const float* src, DevBuf& buf, size_t cap_floats, size_t floats, const float*& dst) -> int {
+      if (!src) { dst = nullptr; return LRP_OK; }
+      if (!buf.p) LRP_TRY(buf.alloc(cap_floats * sizeof(float), total));
+      LRP_HIP_CHECK(hipMemcpyAsync(buf.p, src, floats * sizeof(float), hipMemcpyDeviceToDevice, in.st));
+      dst = buf.as<float>();
+      return LRP_OK;
+    };
+    const size_t TB = (size_t)in.T * in.B;
+    const size_t win = gridtd ? (size_t)2 * H : (size_t)2 * E;     // width of the masked LSTM input (language cell / adaptive cell)
+    LRP_TRY(stage(in.m_lin, Mlin, 4 * cap * win, 4 * TB * win, s_lin));
+    LRP_TRY(stage(in.m_lrec, Mlrec, 4 * cap * H, 4 * TB * H, s_lrec));
+    LRP_TRY(stage(in.m_out, Mout, cap * H, TB * H, s_out));
+    return LRP_OK;
+  }
+  StepIn staged(const StepIn& in) const {
+    StepIn si = in;
+    si.m_lin = s_lin; si.m_lrec = s_lrec; si.m_out = s_out;
+    return si;
+  }
+  static bool graphs_enabled() {
+    static const bool on = [] { const char* e = getenv("LRP_TRAIN_GRAPH"); return !e || atoi(e) != 0; }();
+    return on;
+  }
+  static std::vector<long long> scan_key(const StepIn& in) {
+    auto p = [](const void* q) { return (long long)reinterpret_cast<uintptr_t>(q); };
+    return {in.B, in.T, p(in.m_out), p(in.m_lin), p(in.m_lrec), p(in.grads), p(in.st)};     // everything the scans read from StepIn
+  }
+  template <class F>
+  int graph_or_run(ScanGraph& G, const StepIn& in, F&& fn) {
+    if (!graphs_enabled() || G.broken) { ++G.plain; return fn(in); }
+    const std::vector<long long> key = scan_key(in);
+    if (G.exec && key == G.key) {
+      ++G.launches;
+      LRP_HIP_CHECK(hipGraphLaunch(G.exec, in.st));
+      return LRP_OK;
+    }
+    if (key != G.last) {                                 // first sighting of these arguments: plain launches
+      G.last = key;
+      ++G.plain;
+      return fn(in);
+    }
+    if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; G.key.clear(); }
+    // recorded on a stream of our own (the caller's may be the legacy default stream, which cannot be captured); the
+    // kernel nodes carry no stream, the graph is launched on the caller's
+    if (!cap_st && hipStreamCreateWithFlags(&cap_st, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      G.broken = true;
+      ++G.plain;
+      return fn(in);
+    }
+    if (hipStreamBeginCapture(cap_st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      G.broken = true;
+      ++G.plain;
+      return fn(in);
+    }
+    StepIn rec = in;
+    rec.st = cap_st;
+    const int rc = fn(rec);                              // recorded, not executed
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(cap_st, &graph);
+    if (rc != LRP_OK || e != hipSuccess || !graph) {
+      (void)hipGetLastError();
+      if (graph) (void)hipGraphDestroy(graph);
+      G.broken = true;                                   // nothing ran: do it the plain way, and from now on
+      ++G.plain;
+      return fn(in);
+    }
+    const hipError_t ei = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !G.exec) {
+      (void)hipGetLastError();
+      G.exec = nullptr;
+      G.broken = true;
+      ++G.plain;
+      return fn(in);
+    }
+    G.key = key;
+    ++G.captures;
+    LRP_HIP_CHECK(hipGraphLaunch(G.exec, in.st));
+    return LRP_OK;
+  }
   const char* nm_proj() const { return gridtd ? "W_va" : "Wv"; }
   const char* nm_hatt() const { return gridtd ? "W_ha" : "Wg"; }
   const char* nm_satt() const { return gridtd ? "W_s" : "Ws"; }
@@ -246,7 +354,9 @@ struct Trainer {
     // X rows: [emb | glob] (adaptive input_x) or [glob | emb] (the non-recurrent part of the top-down LSTM's input)
     hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), in.cap_in, x, B, T, E,
                        gridtd ? E : 0, gridtd ? 0 : E);
-    LRP_TRY(gridtd ? scan_fwd_gridtd(in) : scan_fwd_adaptive(in));
+    LRP_TRY(stage_masks(in, total));
+    const StepIn si = staged(in);
+    LRP_TRY(graph_or_run(g_fwd, si, [&](const StepIn& q) -> int { return gridtd ? scan_fwd_gridtd(q) : scan_fwd_adaptive(q); }));
     LRP_HIP_CHECK(hipGetLastError());
     LRP_TRY(mm(false, false, (int)TB, V, H, OUTm.as<float>(), H, W("output_W"), V, logits.as<float>(), V, false, st));   // logits - bias
     if (!ev_fwd) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
@@ -284,7 +394,8 @@ struct Trainer {
     LRP_HIP_CHECK(hipMemsetAsync(dVacc.p, 0, BH * 4, st));
     LRP_HIP_CHECK(hipMemsetAsync(dC.p, 0, BH * 4, st));
     // ---------------- reverse scan + the weight gradients of the recurrent part (K = (t, b) rows); leaves dX
-    LRP_TRY(gridtd ? scan_bwd_gridtd(in) : scan_bwd_adaptive(in));
+    const StepIn si = staged(in);                        // the masks the forward ran with
+    LRP_TRY(graph_or_run(g_bwd, si, [&](const StepIn& q) -> int { return gridtd ? scan_bwd_gridtd(q) : scan_bwd_adaptive(q); }));
     LRP_HIP_CHECK(hipGetLastError());
     // ---------------- attention statics, embedding, global / image_features branches
     float* dx = dX.as<float>();

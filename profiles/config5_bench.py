@@ -50,7 +50,8 @@ def main():
 
     def timed(fn):
         torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return (time.perf_counter() - t) * 1e3, r
-    tr.train_on_batch([cap_in, X], y)                                   # warm-up
+    for _ in range(3):                                                  # warm-up (lazy allocations; the decoder scans are captured as hipGraphs on their second run)
+        tr.train_on_batch([cap_in, X], y)
     t_pred, y_pred = timed(lambda: tr.predict_on_batch([cap_in, X]))
     t_lrp, lw_dev = timed(lambda: tr._lrp_layer.call_device(X, y_pred, images_encoded=True))
     n_maps = int((lw_dev != 1).sum())
@@ -59,7 +60,7 @@ def main():
     from lrp_imagecaptioning_amd.parallel import average_gradients
     t_ar, _ = timed(lambda: average_gradients(g, losses))          # (no-op at world size 1)
     t_apply, _ = timed(lambda: eng.train_apply(g))
-    n = 3
+    n = int(os.environ.get("N", 6))
     t_all, _ = timed(lambda: [tr.train_on_batch([cap_in, X], y) for _ in range(n)])
     if world > 1:
         import torch.distributed as dist

@@ -408,6 +408,34 @@ def test_early_forward_gives_identical_gradients():
     assert torch.equal(g2, g_ref)
 
 
+def test_scan_graphs_replay_bit_identically():
+    """The decoder scans are stream-captured into hipGraphs on their second run with the same arguments and replayed from
+    the third on (trainer.h graph_or_run).  Plain launches, the capturing run and the replays must give the same bits —
+    with fresh mask tensors every call (the scans read staged copies), and again after the masks change."""
+    w, X, cap_in, y, lw, masks = _case(13)
+    eng = _engine(w, len(X))
+    eng.train_begin()
+    eng.encode_images(X)
+    grads = torch.empty_like(eng.train_step(cap_in, y, lw, masks)[0])     # one persistent gradient buffer, as training.py has
+    runs = []
+    for _ in range(5):                                   # 1: plain, 2: capture, 3-5: replay
+        fresh = {k: np.array(v) for k, v in masks.items()}      # (uploaded into new device tensors by every call)
+        g, l = eng.train_step(cap_in, y, lw, fresh, grads=grads)
+        runs.append((g.clone(), l.clone()))
+    for g, l in runs[1:]:
+        assert torch.equal(g, runs[0][0]) and torch.equal(l, runs[0][1])
+    # other masks through the SAME graph (the pointers it recorded are the staged copies): different, and right
+    w2, X2, cap2, y2, lw2, masks2 = _case(14)
+    g_new, _ = eng.train_step(cap_in, y, lw, masks2, grads=grads)
+    g_new = g_new.clone()
+    assert not torch.equal(g_new, runs[0][0])
+    eng2 = _engine(w, len(X))
+    eng2.train_begin()
+    eng2.encode_images(X)
+    g_ref, _ = eng2.train_step(cap_in, y, lw, masks2)                       # first call on a fresh handle: plain launches
+    assert torch.equal(g_new, g_ref)
+
+
 def test_early_forward_is_dropped_by_a_new_encode_or_weight():
     """lrp_train_forward(batch 0) followed by lrp_encode_images(batch 1) — e.g. a loop whose explanation raised between
     the two — must NOT let lrp_train_step(batch 1) back-propagate through batch 0's activations: same (B, T), new
