@@ -51,6 +51,8 @@ struct Trainer {
     if (host_pinned) (void)hipHostFree(host_pinned);
     if (ev_fwd) (void)hipEventDestroy(ev_fwd);
     if (cap_st) (void)hipStreamDestroy(cap_st);
+    if (ev_ga) (void)hipEventDestroy(ev_ga);
+    if (ev_gb) (void)hipEventDestroy(ev_gb);
   }
   float lr = 0.f, clip = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
   int64_t iter = 0;
@@ -195,7 +197,7 @@ struct Trainer {
   // for the adaptive decoder), queued by one host thread: at 8 images per GPU the launches, not the kernels, set its
   // duration.  The sequence depends only on (B, T) and on the pointers in StepIn, so the second consecutive call with the
   // same arguments is stream-captured and instantiated, and every later one is a single hipGraphLaunch; different arguments
-  // (or a capture the runtime refuses) run the plain launches.  LRP_TRAIN_GRAPH=0 disables.
+  // (or a capture the runtime refuses) run the plain launches.  Opt-in: LRP_TRAIN_GRAPH=1 (see graph_or_run).
   struct ScanGraph {
     std::vector<long long> key, last;
     hipGraphExec_t exec = nullptr;
@@ -234,24 +236,43 @@ struct Trainer {
     si.m_lin = s_lin; si.m_lrec = s_lrec; si.m_out = s_out;
     return si;
   }
-  static bool graphs_enabled() {
-    static const bool on = [] { const char* e = getenv("LRP_TRAIN_GRAPH"); return !e || atoi(e) != 0; }();
-    return on;
+  static int graphs_mode() {                             // read per call (the tests switch it): 0 off (default), 1 both scans, 2 forward only, 3 backward only
+    const char* e = getenv("LRP_TRAIN_GRAPH");
+    return e ? atoi(e) : 0;
   }
   static std::vector<long long> scan_key(const StepIn& in) {
     auto p = [](const void* q) { return (long long)reinterpret_cast<uintptr_t>(q); };
     return {in.B, in.T, p(in.m_out), p(in.m_lin), p(in.m_lrec), p(in.grads), p(in.st)};     // everything the scans read from StepIn
   }
+  // The graph runs on the trainer's own stream, fenced against the caller's with two events: the caller's stream is often the
+  // legacy default stream, and a graph launched INTO it was observed not to be ordered against later work of other streams
+  // [MI355X, ROCm 7.2: the next iteration's forward overwrote the staged masks under a still-running backward graph].
+  hipEvent_t ev_ga = nullptr, ev_gb = nullptr;
+  int launch_graph(hipGraphExec_t exec, hipStream_t st) {
+    if (!ev_ga) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_ga, hipEventDisableTiming));
+    if (!ev_gb) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_gb, hipEventDisableTiming));
+    LRP_HIP_CHECK(hipEventRecord(ev_ga, st));
+    LRP_HIP_CHECK(hipStreamWaitEvent(cap_st, ev_ga, 0));
+    LRP_HIP_CHECK(hipGraphLaunch(exec, cap_st));
+    LRP_HIP_CHECK(hipEventRecord(ev_gb, cap_st));
+    LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gb, 0));
+    return LRP_OK;
+  }
   template <class F>
   int graph_or_run(ScanGraph& G, const StepIn& in, F&& fn) {
-    if (!graphs_enabled() || G.broken) { ++G.plain; return fn(in); }
+    // OPT-IN, and never on the legacy default stream: there, replays of the backward scan produced wrong (and varying)
+    // gradients from the fifth iteration on at B = 32 with the grid-TD decoder [MI355X, ROCm 7.2; launching into the
+    // stream, or on a stream of our own fenced with events, made no difference; a fresh capture per iteration was right,
+    // and so was every run on a non-default stream].  The mechanism was not found, so the default stays plain launches.
+    const int which = graphs_mode();
+    if (which == 0 || in.st == nullptr || G.broken || (which == 2 && &G != &g_fwd) || (which == 3 && &G != &g_bwd)) { ++G.plain; return fn(in); }
     const std::vector<long long> key = scan_key(in);
-    if (G.exec && key == G.key) {
+    static const bool recapture = getenv("LRP_TRAIN_GRAPH_RECAPTURE") != nullptr;     // diagnostic: a fresh graph every time
+    if (G.exec && key == G.key && !recapture) {
       ++G.launches;
-      LRP_HIP_CHECK(hipGraphLaunch(G.exec, in.st));
-      return LRP_OK;
+      return launch_graph(G.exec, in.st);
     }
-    if (key != G.last) {                                 // first sighting of these arguments: plain launches
+    if (key != G.last && !recapture) {                   // first sighting of these arguments: plain launches
       G.last = key;
       ++G.plain;
       return fn(in);
@@ -294,8 +315,7 @@ struct Trainer {
     }
     G.key = key;
     ++G.captures;
-    LRP_HIP_CHECK(hipGraphLaunch(G.exec, in.st));
-    return LRP_OK;
+    return launch_graph(G.exec, in.st);
   }
   const char* nm_proj() const { return gridtd ? "W_va" : "Wv"; }
   const char* nm_hatt() const { return gridtd ? "W_ha" : "Wg"; }
