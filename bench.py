@@ -14,8 +14,9 @@ Prints ONE json line (rank 0).  See DESIGN.md §measurement for the roofline ter
 The line is self-certifying (N = 1): besides the timed default mode (fp16-pair reverse walk, two MFMAs per product below
 the top block) the same invocation
   * times the exact-fp32 mode on the same batch              -> "fp32_mode"  {value, ms_per_step, roofline}
+  * times the three-MFMA split-bf16 walk on the same batch   -> "bf16x3_mode" {value, ms_per_step}
   * checks sampled heat-maps of the timed batch, in both modes, against the CPU oracle
-    (outside the timed region)                               -> "parity"     {f16x2, fp32: worst relative L1}
+    (outside the timed region)                               -> "parity"     {f16x2, bf16x3, fp32: worst relative L1}
   * reads board power and shader clock while the steps run   -> "power"      {socket_power_w, sclk_mhz}
   * measures the fabric traffic of the dominant kernel live: two `rocprofv3 --pmc` child passes of this same
     script (FETCH_SIZE, WRITE_SIZE; started BEFORE this process touches the GPU) -> roofline.traffic
@@ -408,6 +409,21 @@ def main():
         pipe.reset()
         pipe.set_precision(args.precision)
 
+    # ---- and in the conservative split-bf16 walk (three MFMAs per product everywhere): what the default's two-MFMA
+    # products buy, and that they cost no parity, in the same invocation
+    bf16_block = None
+    if extras and not args.no_fp32_mode and args.precision == "f16x2":
+        pipe.reset()
+        pipe.set_precision("bf16x3")
+        kb = max(2, min(args.steps, 10))
+        dtb = timed_run(2, kb)
+        if not args.no_parity:
+            got["bf16x3"] = sampled("bf16x3")
+        bf16_block = {"value": round(B * T * kb / dtb, 2), "unit": "heatmaps/s", "steps": kb, "warmup": 2,
+                      "ms_per_step": round(dtb / kb * 1e3, 3), "dtype": "bf16x3"}
+        pipe.reset()
+        pipe.set_precision(args.precision)
+
     if live_traffic:
         traffic, traffic_src = live_traffic["bytes"], live_src
     else:
@@ -435,6 +451,8 @@ def main():
             res["roofline"]["traffic_detail"] = live_traffic
         if fp32_block:
             res["fp32_mode"] = fp32_block
+        if bf16_block:
+            res["bf16x3_mode"] = bf16_block
         if power_block:
             res["power"] = power_block
         if got:
