@@ -338,7 +338,7 @@ struct ResNetEncoder {
       const bool last = bi + 1 == blocks.size();
       float* o = last ? feat.as<float>() : blocks[bi + 1].t_in.as<float>();
       const size_t n = (size_t)B * b.H * b.W * 4 * b.f;
-      hipLaunchKernelGGL(rn_block_out_kernel, dim3(stream_grid(n)), dim3(256), 0, st, sc, fa.as<float>(),
+      hipLaunchKernelGGL(rn_block_out_kernel, dim3(stream_grid(n / 4)), dim3(256), 0, st, sc, fa.as<float>(),
                          units[b.u3].gate.as<float>(), b.u0 >= 0 ? units[b.u0].gate.as<float>() : (const float*)nullptr, o,
                          b.GA.as<float>(), b.GS.as<float>(), n, last ? (unsigned*)nullptr : block_slots(bi));
       LRP_HIP_CHECK(hipGetLastError());
@@ -467,7 +467,7 @@ struct ResNetEncoder {
     // stem: pool routing * Q_stem -> T = S . W (K = stem_c, N = 294) -> 7x7/2 stencil with the x+/x- selection
     const RnUnit& s = units[0];
     const size_t tot = (size_t)n * s.Hout * s.Wout * s.cout;
-    hipLaunchKernelGGL(rn_pool3_route_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
+    hipLaunchKernelGGL(rn_pool3_route_kernel, dim3(stream_grid(tot / 4)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
                        q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
     LRP_HIP_CHECK(hipGetLastError());
     ConvArgs ca{};

@@ -51,14 +51,26 @@ __global__ __launch_bounds__(256) void rn_block_out_kernel(const float* __restri
                                                            float* __restrict__ o, float* __restrict__ GA,
                                                            float* __restrict__ GS, size_t n,
                                                            unsigned* __restrict__ max_slots) {
+  // 16 B per lane and tensor (n is a multiple of 4: channel counts are)
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float s = sc[i], y = y3[i];
-    const float den = safe_den(s + y);
-    o[i] = fmaxf(s + y, 0.f);
-    m = fmaxf(m, s + y);
-    GA[i] = y / den * Q3[i];
-    GS[i] = Q0 ? s / den * Q0[i] : s / den;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 s = reinterpret_cast<const f32x4*>(sc)[i], y = reinterpret_cast<const f32x4*>(y3)[i];
+    const f32x4 q3 = reinterpret_cast<const f32x4*>(Q3)[i];
+    f32x4 q0 = {1.f, 1.f, 1.f, 1.f};
+    if (Q0) q0 = reinterpret_cast<const f32x4*>(Q0)[i];
+    f32x4 ov, ga, gs;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float den = safe_den(s[q] + y[q]);
+      ov[q] = fmaxf(s[q] + y[q], 0.f);
+      m = fmaxf(m, s[q] + y[q]);
+      ga[q] = y[q] / den * q3[q];
+      gs[q] = Q0 ? s[q] / den * q0[q] : s[q] / den;
+    }
+    reinterpret_cast<f32x4*>(o)[i] = ov;
+    reinterpret_cast<f32x4*>(GA)[i] = ga;
+    reinterpret_cast<f32x4*>(GS)[i] = gs;
   }
   if (max_slots) rn_flush_max(m, max_slots);
 }
@@ -173,28 +185,34 @@ __global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __restrict__ R, const unsigned char* __restrict__ win,
                                                              const float* __restrict__ Q, const int* __restrict__ row2img,
                                                              float* __restrict__ S, int ntok, int H, int W, int C) {
-  const int Ho = H / 2, Wo = W / 2;
-  const size_t total = (size_t)ntok * H * W * C;
+  // four channels per thread (C % 4 == 0): 16 B relevance / gate loads and stores, 4 B of winners per window
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const size_t total = (size_t)ntok * H * W * C4;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int c = (int)(idx % C);
-    size_t r = idx / C;
+    const int c = (int)(idx % C4) * 4;
+    size_t r = idx / C4;
     const int j = (int)(r % W);
     r /= W;
     const int i = (int)(r % H);
     const int t = (int)(r / H);
     const int img = row2img ? row2img[t] : t;
-    float acc = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     // windows containing padded position (i+1, j+1): oh in [ceil((i-1)/2), floor((i+1)/2)]
     for (int oh = (i) / 2; oh <= (i + 1) / 2; ++oh) {
       if (oh < 0 || oh >= Ho || 2 * oh - 1 > i || 2 * oh + 1 < i) continue;
       for (int ow = (j) / 2; ow <= (j + 1) / 2; ++ow) {
         if (ow < 0 || ow >= Wo || 2 * ow - 1 > j || 2 * ow + 1 < j) continue;
         // (i, j) is position (kh, kw) = (i - 2 oh + 1, j - 2 ow + 1) of this window: did it win?
-        const int mine = (i - 2 * oh + 1) * 3 + (j - 2 * ow + 1);
-        if (win[(((size_t)img * Ho + oh) * Wo + ow) * C + c] == mine) acc += R[(((size_t)t * Ho + oh) * Wo + ow) * C + c];
+        const unsigned mine = (unsigned)((i - 2 * oh + 1) * 3 + (j - 2 * ow + 1));
+        const unsigned w4 = *reinterpret_cast<const unsigned*>(win + (((size_t)img * Ho + oh) * Wo + ow) * C + c);
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (((size_t)t * Ho + oh) * Wo + ow) * C + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (((w4 >> (8 * q)) & 0xFFu) == mine) acc[q] += rv[q];
       }
     }
-    S[idx] = acc * Q[(((size_t)img * H + i) * W + j) * C + c];
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(Q + (((size_t)img * H + i) * W + j) * C + c);
+    *reinterpret_cast<f32x4*>(S + idx * 4) = acc * qv;
   }
 }
 
