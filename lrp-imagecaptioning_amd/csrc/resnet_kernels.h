@@ -111,43 +111,46 @@ __global__ __launch_bounds__(256) void rn_mul_gate_kernel(const float* __restric
 
 __global__ __launch_bounds__(256) void rn_add_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                      float* __restrict__ out, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = a[i] + b[i];
+  const size_t n4 = n / 4;                               // (element counts are multiples of the channel count, itself % 4 == 0)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
 }
 
-// stride-2 gather: xs[n][ho][wo][c] = x[n][2ho][2wo][c]   (input of a strided 1x1 conv)
+// stride-2 gather: xs[n][ho][wo][c] = x[n][2ho][2wo][c]   (input of a strided 1x1 conv); four channels per thread
 __global__ __launch_bounds__(256) void rn_subsample2_kernel(const float* __restrict__ x, float* __restrict__ xs, int NB,
                                                             int H, int W, int C) {
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const size_t total = (size_t)NB * Ho * Wo * C;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C / 4;
+  const size_t total = (size_t)NB * Ho * Wo * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    size_t r = i / C;
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
     const int wo = (int)(r % Wo);
     r /= Wo;
     const int ho = (int)(r % Ho);
     const int n = (int)(r / Ho);
-    xs[i] = x[(((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c];
+    reinterpret_cast<f32x4*>(xs)[i] = *reinterpret_cast<const f32x4*>(x + (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c);
   }
 }
 
-// stride-2 scatter of relevance: fine[n][h][w][c] = (h,w both even) ? (a[..] (+ b[..])) : 0
+// stride-2 scatter of relevance: fine[n][h][w][c] = (h,w both even) ? (a[..] (+ b[..])) : 0; four channels per thread
 __global__ __launch_bounds__(256) void rn_scatter2_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           float* __restrict__ fine, int NB, int H, int W, int C) {
-  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
-  const size_t total = (size_t)NB * H * W * C;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C4 = C / 4;
+  const size_t total = (size_t)NB * H * W * C4;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    size_t r = i / C;
+    const int c = (int)(i % C4) * 4;
+    size_t r = i / C4;
     const int w = (int)(r % W);
     r /= W;
     const int h = (int)(r % H);
     const int n = (int)(r / H);
-    float v = 0.f;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (!(h & 1) && !(w & 1)) {
       const size_t j = (((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c;
-      v = a[j] + (b ? b[j] : 0.f);
+      v = *reinterpret_cast<const f32x4*>(a + j);
+      if (b) v += *reinterpret_cast<const f32x4*>(b + j);
     }
-    fine[i] = v;
+    reinterpret_cast<f32x4*>(fine)[i] = v;
   }
 }
 
