@@ -181,7 +181,13 @@ struct ResNetEncoder {
             pk[(size_t)(t * 6 + c) * Kb + co] = wp[((size_t)t * 3 + c) * u.cout + co];
             pk[(size_t)(t * 6 + 3 + c) * Kb + co] = wn[((size_t)t * 3 + c) * u.cout + co];
           }
-      return up(u.w_b, pk, total);
+      LRP_TRY(up(u.w_b, pk, total));
+      if (!(u.cout & 7)) {                               // split-bf16 copy: the tap GEMM of the walk as bf16x3
+        std::vector<float> sp(pk.size());
+        pack_split8(pk.data(), pk.size(), sp.data());
+        LRP_TRY(up(u.w_bs, sp, total));
+      }
+      return LRP_OK;
     }
     const int taps = u.k * u.k;
     const int Np = conv_npad(u.cout), K = taps * conv_cinp(u.cin);
@@ -467,13 +473,21 @@ struct ResNetEncoder {
     // stem: pool routing * Q_stem -> T = S . W (K = stem_c, N = 294) -> 7x7/2 stencil with the x+/x- selection
     const RnUnit& s = units[0];
     const size_t tot = (size_t)n * s.Hout * s.Wout * s.cout;
-    hipLaunchKernelGGL(rn_pool3_route_kernel, dim3(stream_grid(tot / 4)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
-                       q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
+    // the stem's tap GEMM (K = stem channels -> 49 taps x 6 columns) as bf16x3 like the other convs of the walk: the pool
+    // routing writes its operand in split8 form (LRP_RN_STEM_SPLIT=0 / fp32 mode: plain fp32 on the fp32 MFMA)
+    static const bool stem_split_on = [] { const char* e = getenv("LRP_RN_STEM_SPLIT"); return !e || atoi(e) != 0; }();
+    const bool ssplit = stem_split_on && prec == PREC_BF16X3 && s.w_bs.p && !(s.cout & 7);
+    if (ssplit)
+      hipLaunchKernelGGL(rn_pool3_route_kernel<true>, dim3(stream_grid(tot / 8)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
+                         q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
+    else
+      hipLaunchKernelGGL(rn_pool3_route_kernel<false>, dim3(stream_grid(tot / 4)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
+                         q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
     LRP_HIP_CHECK(hipGetLastError());
     ConvArgs ca{};
     ca.in = r1.as<float>(); ca.NB = n * s.Hout * s.Wout; ca.H = 1; ca.W = 1; ca.Cin = s.cout; ca.CinP = conv_cinp(s.cout);
-    ca.taps = 1; ca.wpk = s.w_b.as<float>(); ca.N = RN_STEM_TCOLS; ca.out = r2.as<float>();
-    LRP_HIP_CHECK(conv_launch(EPI_STORE, ca, st));
+    ca.taps = 1; ca.wpk = ssplit ? s.w_bs.as<float>() : s.w_b.as<float>(); ca.N = RN_STEM_TCOLS; ca.out = r2.as<float>();
+    LRP_HIP_CHECK(conv_launch(EPI_STORE, ca, st, ssplit ? PREC_BF16X3 : PREC_FP32));
     hipLaunchKernelGGL(rn_stem_stencil_kernel, dim3(stream_grid((size_t)n * img_h * img_w)), dim3(256), 0, st, r2.as<float>(),
                        images.as<float>(), row2img, R_img_dev, n, img_h, img_w);
     LRP_HIP_CHECK(hipGetLastError());

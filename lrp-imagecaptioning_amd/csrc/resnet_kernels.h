@@ -185,21 +185,26 @@ __global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__
 
 // Relevance routing through that pool (gradient of max-pool = first arg-max of each window, windows overlap),
 // fused with the stem gate:  S[n][i][j][c] = Q[img][i][j][c] * sum_{windows (oh,ow) whose arg-max is (i,j)} R[n][oh][ow][c]
+// SPLIT: eight channels per thread, written in the split-bf16 operand format of the conv kernel (the stem's tap GEMM then
+// runs as bf16x3); otherwise four channels per thread, plain fp32.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __restrict__ R, const unsigned char* __restrict__ win,
                                                              const float* __restrict__ Q, const int* __restrict__ row2img,
                                                              float* __restrict__ S, int ntok, int H, int W, int C) {
-  // four channels per thread (C % 4 == 0): 16 B relevance / gate loads and stores, 4 B of winners per window
-  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
-  const size_t total = (size_t)ntok * H * W * C4;
+  constexpr int CW = SPLIT ? 8 : 4;                      // (C % CW == 0): 16 B relevance / gate loads, 4 B of winners per window
+  const int Ho = H / 2, Wo = W / 2, CG = C / CW;
+  const size_t total = (size_t)ntok * H * W * CG;
   for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-    const int c = (int)(idx % C4) * 4;
-    size_t r = idx / C4;
+    const int c = (int)(idx % CG) * CW;
+    size_t r = idx / CG;
     const int j = (int)(r % W);
     r /= W;
     const int i = (int)(r % H);
     const int t = (int)(r / H);
     const int img = row2img ? row2img[t] : t;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float acc[CW];
+#pragma unroll
+    for (int q = 0; q < CW; ++q) acc[q] = 0.f;
     // windows containing padded position (i+1, j+1): oh in [ceil((i-1)/2), floor((i+1)/2)]
     for (int oh = (i) / 2; oh <= (i + 1) / 2; ++oh) {
       if (oh < 0 || oh >= Ho || 2 * oh - 1 > i || 2 * oh + 1 < i) continue;
@@ -207,15 +212,26 @@ __global__ __launch_bounds__(256) void rn_pool3_route_kernel(const float* __rest
         if (ow < 0 || ow >= Wo || 2 * ow - 1 > j || 2 * ow + 1 < j) continue;
         // (i, j) is position (kh, kw) = (i - 2 oh + 1, j - 2 ow + 1) of this window: did it win?
         const unsigned mine = (unsigned)((i - 2 * oh + 1) * 3 + (j - 2 * ow + 1));
-        const unsigned w4 = *reinterpret_cast<const unsigned*>(win + (((size_t)img * Ho + oh) * Wo + ow) * C + c);
-        const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (((size_t)t * Ho + oh) * Wo + ow) * C + c);
+        const size_t wo = (((size_t)img * Ho + oh) * Wo + ow) * C + c, ro = (((size_t)t * Ho + oh) * Wo + ow) * C + c;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (((w4 >> (8 * q)) & 0xFFu) == mine) acc[q] += rv[q];
+        for (int g = 0; g < CW / 4; ++g) {
+          const unsigned w4 = *reinterpret_cast<const unsigned*>(win + wo + 4 * g);
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(R + ro + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (((w4 >> (8 * q)) & 0xFFu) == mine) acc[4 * g + q] += rv[q];
+        }
       }
     }
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(Q + (((size_t)img * H + i) * W + j) * C + c);
-    *reinterpret_cast<f32x4*>(S + idx * 4) = acc * qv;
+    const float* qp = Q + (((size_t)img * H + i) * W + j) * C + c;
+#pragma unroll
+    for (int g = 0; g < CW / 4; ++g) {
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[4 * g + q] *= qv[q];
+    }
+    if constexpr (SPLIT) split8_store(acc, S + idx * 8);
+    else *reinterpret_cast<f32x4*>(S + idx * 4) = *reinterpret_cast<const f32x4*>(acc);
   }
 }
 
