@@ -11,12 +11,15 @@ images sharded per rank, no data-path collective (weak scaling).
 
 Prints ONE json line (rank 0).  See DESIGN.md §measurement for the roofline terms.
 
-The line is self-certifying (N = 1): besides the timed default mode (fp16-pair reverse walk, two MFMAs per product below
-the top block) the same invocation
+The line is self-certifying (N = 1): besides the timed default mode (split-bf16 reverse walk: hi*hi' + hi*lo' + lo*hi' in
+every layer, 16 mantissa bits on both operands — parity independent of the weight statistics) the same invocation
   * times the exact-fp32 mode on the same batch              -> "fp32_mode"  {value, ms_per_step, roofline}
-  * times the three-MFMA split-bf16 walk on the same batch   -> "bf16x3_mode" {value, ms_per_step}
-  * checks sampled heat-maps of the timed batch, in both modes, against the CPU oracle
-    (outside the timed region)                               -> "parity"     {f16x2, bf16x3, fp32: worst relative L1}
+  * times the opt-in two-MFMA fp16 walk on the same batch    -> "fast_mode"  {value, ms_per_step, parity}
+    (one fp16 per weight below the top block: faster, but its error depends on the weights; lrp_hip.h)
+  * checks sampled heat-maps of the timed batch, in every mode, against the CPU oracle
+    (outside the timed region)                               -> "parity"     {bf16x3, fp32, f16x2: worst relative L1}
+  * explains ONE image's 10-word caption on a B = 1 handle   -> "latency"    {ms, launches}  (the reference's own call,
+    explain_image.py:152-161)
   * reads board power and shader clock while the steps run   -> "power"      {socket_power_w, sclk_mhz}
   * measures the fabric traffic of the dominant kernel live: two `rocprofv3 --pmc` child passes of this same
     script (FETCH_SIZE, WRITE_SIZE; started BEFORE this process touches the GPU) -> roofline.traffic
@@ -246,16 +249,17 @@ def main():
     ap.add_argument("--vocab", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-tokens", type=int, default=10, help="tokens of one caption the CPU port explains (~1 s each)")
-    ap.add_argument("--precision", default="f16x2", choices=["f16x2", "bf16x3", "fp32", "bf16x3_fast"],
-                    help="arithmetic of the per-token reverse walk: fp16 pairs, 2 MFMAs per product below the top block "
-                         "(library default), split-bf16 x3 MFMA, or exact fp32 MFMA")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32", "f16x2", "bf16x3_fast"],
+                    help="arithmetic of the per-token reverse walk: split-bf16 x3 MFMA (library default), exact fp32 MFMA, or "
+                         "the opt-in fast mode: fp16 pairs with ONE fp16 per weight below the top block (2 MFMAs per product)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock reading")
     ap.add_argument("--handles", type=int, default=2,
                     help="batches in flight per GPU: consecutive steps alternate between this many lrp_handles on their own "
                          "HIP streams (pipeline.py); 1 = strictly one step after the other")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                                                         "the N>1 control path with several ranks on one GPU)")
-    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the exact-fp32 block of the line")
+    ap.add_argument("--no-fp32-mode", action="store_true", help="skip the exact-fp32 and fast-mode blocks of the line")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-image latency block")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of sampled heat-maps")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 traffic passes (use the committed summary)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)    # one plain step under rocprofv3 (live_pmc_traffic)
@@ -409,20 +413,29 @@ def main():
         pipe.reset()
         pipe.set_precision(args.precision)
 
-    # ---- and in the conservative split-bf16 walk (three MFMAs per product everywhere): what the default's two-MFMA
-    # products buy, and that they cost no parity, in the same invocation
-    bf16_block = None
-    if extras and not args.no_fp32_mode and args.precision == "f16x2":
+    # ---- and in the opt-in fast mode (fp16 pairs, one fp16 per weight below the top block: two MFMAs per product): what it
+    # would buy on THESE weights and what it costs in parity on them — its error depends on the weight statistics (dense
+    # Gaussian kernels average the per-weight rounding out; sparse heavy-tailed ones do not: tests/test_gpu_stress_parity.py)
+    fast_block = None
+    if extras and not args.no_fp32_mode and args.precision == "bf16x3":
         pipe.reset()
-        pipe.set_precision("bf16x3")
+        pipe.set_precision("f16x2")
         kb = max(2, min(args.steps, 10))
         dtb = timed_run(2, kb)
         if not args.no_parity:
-            got["bf16x3"] = sampled("bf16x3")
-        bf16_block = {"value": round(B * T * kb / dtb, 2), "unit": "heatmaps/s", "steps": kb, "warmup": 2,
-                      "ms_per_step": round(dtb / kb * 1e3, 3), "dtype": "bf16x3"}
+            got["f16x2"] = sampled("f16x2")
+        fast_block = {"value": round(B * T * kb / dtb, 2), "unit": "heatmaps/s", "steps": kb, "warmup": 2,
+                      "ms_per_step": round(dtb / kb * 1e3, 3), "dtype": "f16x2",
+                      "note": "opt-in lrp_set_precision(LRP_PREC_F16X2): ONE fp16 per weight (11 bits) in 9 of the 13 reverse "
+                              "launches; parity below is for these synthetic He-normal weights only"}
         pipe.reset()
         pipe.set_precision(args.precision)
+
+    # ---- the reference's actual call: ONE image, explain every word of its caption (explain_image.py:152-161 ->
+    # E:183-189): host clock around encode -> decoder replay -> T heat-maps -> device synchronise, on a B = 1 handle
+    latency_block = None
+    if extras and not args.no_latency:
+        latency_block = latency_probe(w_host, X[:1], caps[:1], T, V, local, args.precision, torch)
 
     if live_traffic:
         traffic, traffic_src = live_traffic["bytes"], live_src
@@ -432,7 +445,7 @@ def main():
             traffic_src += " (%s)" % live_src
     if rank == 0:
         heatmaps = world * B * T * args.steps
-        dtype = {"fp32": "f32", "f16x2": "f16x2"}.get(args.precision, "bf16x3")
+        dtype = {"fp32": "f32", "f16x2": "f16x2"}.get(args.precision, "bf16x3")   # the arithmetic type the walk computes in
         res = {
             "metric": METRIC, "value": round(heatmaps / dt, 2), "unit": "heatmaps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -451,8 +464,10 @@ def main():
             res["roofline"]["traffic_detail"] = live_traffic
         if fp32_block:
             res["fp32_mode"] = fp32_block
-        if bf16_block:
-            res["bf16x3_mode"] = bf16_block
+        if fast_block:
+            res["fast_mode"] = fast_block
+        if latency_block:
+            res["latency"] = latency_block
         if power_block:
             res["power"] = power_block
         if got:
@@ -466,8 +481,11 @@ def main():
             for mode, maps in got.items():
                 par[mode] = max(rel_l1(maps[k], refs[k]) for k in refs)
             par["oracle_seconds"] = round(time.time() - t0, 1)
-            par["ok"] = all(par[m] < par["tolerance"] for m in got)
+            # the verdict is about the timed arithmetic and the exact one; the opt-in fast mode is reported beside them
+            par["ok"] = all(par[m] < par["tolerance"] for m in got if m != "f16x2" or args.precision == "f16x2")
             res["parity"] = par
+            if fast_block and "f16x2" in par:
+                fast_block["parity"] = par["f16x2"]
         if not args.no_cpu_baseline and args.cpu_sample_tokens > 0:
             if world == 1:                                       # (rank 0 at N = 1 only: the other ranks would idle behind it)
                 res["cpu_baseline"] = cpu_baseline(w_host, V, T, args.cpu_sample_tokens)
@@ -479,13 +497,48 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic_per_launch(precision="f16x2"):
+def latency_probe(w_host, X1, caps1, T, V, device, precision, torch, reps=7):
+    """Single-image latency: a handle sized for ONE image and its T words (the small-tile kernels), weights resident,
+    image resident in HBM; per repetition encode_images -> decoder_forward -> explain_tokens(T) -> synchronise, host clock.
+    Reports the median, the best, and the kernel launches behind one repetition (lrp_launch_count)."""
+    from lrp_imagecaptioning_amd import _capi
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    eng = LRPEngine(decoder="adaptive", V=V, max_images=1, max_tokens=T, max_caption_len=T + 1, device=device)
+    eng.set_precision(precision)
+    eng.set_weights(w_host)
+    out = torch.empty((T, 224, 224, 3), dtype=torch.float32, device=X1.device)
+    idx, tpos = [0] * T, list(range(1, T + 1))
+    lib = _capi.load()
+    ms, launches = [], None
+    for r in range(reps + 2):
+        torch.cuda.synchronize()
+        n0 = int(lib.lrp_launch_count())
+        t0 = time.perf_counter()
+        eng.encode_images(X1)
+        eng.decoder_forward(caps1)
+        eng.explain_tokens(idx, tpos, out=out)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        if r >= 2:                                              # two warm-up repetitions (lazy allocations, code objects)
+            ms.append(dt)
+            launches = int(lib.lrp_launch_count()) - n0
+    assert bool(torch.isfinite(out).all())
+    eng.close()
+    ms.sort()
+    return {"ms": round(ms[len(ms) // 2], 3), "best_ms": round(ms[0], 3), "launches": launches, "heatmaps": T,
+            "reps": reps, "dtype": {"fp32": "f32"}.get(precision, precision),
+            "what": "1 image resident in HBM, B = 1 handle: encode + decoder replay + %d per-word heat-maps + synchronise, "
+                    "host clock (median of %d); explain_image.py:152-161" % (T, reps)}
+
+
+def pmc_traffic_per_launch(precision="bf16x3"):
     """Fallback when the live rocprofv3 passes cannot run (no profiler, N > 1): the per-launch fabric traffic of the
     reverse-walk conv launches from the newest committed PMC summary (profiles/run_profile.sh: separate --pmc
     FETCH_SIZE / WRITE_SIZE passes of this same command; profiles/summarize.py)."""
     import glob
     # the committed summaries are of the default-precision run; an fp32-mode profile would be r*_pmc_summary_fp32.json
-    suffix = {"f16x2": "", "bf16x3": "_bf16x3", "bf16x3_fast": "_bf16x3", "fp32": "_fp32"}[precision]
+    # (the un-suffixed summaries of rounds 1-2 are of those rounds' default runs; from round 3 on every summary is suffixed)
+    suffix = {"f16x2": "_f16x2", "bf16x3": "_bf16x3", "bf16x3_fast": "_bf16x3", "fp32": "_fp32"}[precision]
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary%s.json" % suffix)))
     if not files:
         return None, None

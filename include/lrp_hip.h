@@ -11,9 +11,15 @@
  *  - plain C types only; every `*_dev` pointer is DEVICE memory owned by the
  *    caller (e.g. a torch tensor's data_ptr()); every `*_host` pointer is host
  *    memory read before the call returns.
- *  - the library allocates only its own workspace (in lrp_create, freed in
- *    lrp_destroy); it never allocates or synchronises inside a compute call
- *    except for copying the small host index arrays.
+ *  - the library allocates only its own workspace, freed in lrp_destroy: the
+ *    caches and walk buffers in lrp_create, operand copies in lrp_set_weight[_dev],
+ *    the trainer's state in lrp_train_begin; a few buffers whose need depends on
+ *    which entry points a caller uses (decoder scan / gradient operand packs,
+ *    per-token scale records of the fp16 fast mode, per-gate dropout products)
+ *    are allocated by the FIRST call that needs them and kept.  A compute call
+ *    never synchronises the device or a stream; the host side may wait on an
+ *    event for the PREVIOUS call's small pinned staging copy (index arrays, the
+ *    tile-order table of a reverse-walk launch) before reusing that buffer.
  *  - `stream` is a hipStream_t passed as void* (NULL = the null stream).
  *  - return value: 0 = LRP_OK, negative = error; text via lrp_last_error().
  *  - one handle per GPU / stream; a handle is stateful and not re-entrant
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 3
+#define LRP_ABI_VERSION 4
 
 enum {
   LRP_OK = 0,
@@ -204,29 +210,27 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
                  int32_t walk, void* stream);
 
 /* Arithmetic of the per-token reverse walk through the encoder (lrp_cnn_explain / lrp_explain_tokens).
- * LRP_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32).
- * LRP_PREC_F16X2  DEFAULT (for VGG-style encoders; ABI v3).  The relevance tensors are fp16 pairs hi + lo (22 mantissa
- *                 bits, carried scaled by a per-token power of two that every layer re-derives from the measured
- *                 maximum of its input and its weight norm); the weights are fp16 pairs scaled by a power of two per
- *                 matrix.  Layers after the last pool (VGG16: block5) take the full product hi*hi' + hi*lo' + lo*hi'
- *                 (three v_mfma_f32_32x32x16_f16, fp32 accumulation); every layer below with at least 64 output channels
- *                 (576 products per sum) reads only the hi half of the weights: TWO MFMAs per product — and the
- *                 denominators Z+ of exactly those layers are computed in the forward with the same rounded weights,
- *                 so gate and transposed conv belong to one network and the rounding largely cancels.  Measured parity
- *                 of the heat-maps vs the float64 reference graph: 4.4e-6 at the bench configuration, median 3.3e-6 /
- *                 worst 2.5e-5 (one arg-max flip) over 13 seeds — the same as LRP_PREC_BF16X3 (bar 1e-4).  Two-term products in the top block as well would cost
- *                 1e-4 (the relevance there is too concentrated for the weight rounding to average out) and are not
- *                 offered.  Conv widths % 8 != 0 silently use the fp32 path.  The per-image forward's activations are fp32-grade
- *                 in every mode except _FAST (fp16 pairs on both operands, three MFMAs, blocked accumulation: 7e-7 on
- *                 the features like the fp32 MFMA).  The ResNet encoder's walk runs as LRP_PREC_BF16X3 in this mode.
- * LRP_PREC_BF16X3 split-bf16 walk: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
+ * LRP_PREC_BF16X3 DEFAULT.  Split-bf16 walk: every fp32 operand is carried as hi + lo bf16 (16 mantissa bits) and every
  *                 product is hi*hi' + hi*lo' + lo*hi' on v_mfma_f32_32x32x16_bf16 with fp32 accumulation — three MFMAs
- *                 in every layer, no scaling state.  Parity as above; ~6 % slower than the default on MI355X (the
- *                 walk is power-bound: it is the MFMA count that is paid for).
- * LRP_PREC_BF16X3_FAST  LRP_PREC_BF16X3 with two-way split activation convs in the forward as well: 10 % faster, but
- *                 the arg-max flips put the heat-map parity at 2e-5 ... 9e-5 (five seeds) — inside the 1e-4 bar
- *                 without margin.  Opt-in, not recommended.
- * The decoder is fp32 / fp64 in every mode. */
+ *                 in every layer, no scaling state.  Worst case per product 2^-16 (8e-6 << the 1e-4 relative-L1 bar)
+ *                 whatever the weights look like; measured 3e-6 ... 7e-6 on dense Gaussian and on sparse heavy-tailed
+ *                 (trained-like) kernels alike (tests/test_gpu_stress_parity.py).  The per-image forward's activations
+ *                 are fp32-grade (fp16 pairs on both operands, three MFMAs, blocked accumulation: 7e-7 on the features
+ *                 like the fp32 MFMA); the denominators Z+ are three-term as well.
+ * LRP_PREC_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: the reference's own arithmetic (TF float32).
+ * LRP_PREC_F16X2  OPT-IN fast mode (VGG-style encoders; ABI v3).  The relevance tensors are fp16 pairs hi + lo carried
+ *                 scaled by a per-token power of two; layers after the last pool take the full three-MFMA product, every
+ *                 layer below with >= 64 output channels reads only the hi half of the weights: ONE fp16 (11 bits) per
+ *                 weight, TWO MFMAs per product, and the denominators Z+ of those layers are computed with the same
+ *                 rounded weights.  ~12 % faster than the default — but the weight rounding is the same for every token
+ *                 and only averages out when a sum has many comparable products: 3-5e-6 on dense Gaussian kernels,
+ *                 1e-4 ... 5e-4 (OUTSIDE the bar) on sparse heavy-tailed ones.  Worst case 2^-12 = 2.4e-4 per product.
+ *                 Use it only after checking it on the model at hand (bench.py reports it as `fast_mode` with its own
+ *                 in-run parity).  Conv widths % 8 != 0 silently use the fp32 path; the ResNet walk runs as BF16X3.
+ * LRP_PREC_BF16X3_FAST  LRP_PREC_BF16X3 with two-way split activation convs in the forward as well: faster encode, but
+ *                 arg-max flips put the heat-map parity at 2e-5 ... 9e-5 (five seeds).  Opt-in, not recommended.
+ * The decoder is fp32 / fp64 in every mode.  A mode CHANGE drops the encode caches (the gates were computed in the old
+ * arithmetic): lrp_encode_images must run again before the next explain call (LRP_ERR_STATE otherwise). */
 enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2, LRP_PREC_F16X2 = 3 };
 int lrp_set_precision(lrp_handle* h, int32_t mode);
 
@@ -350,12 +354,20 @@ int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_de
                    const float* mask_logits_dev, float* grads_dev, float* losses_dev, void* stream);
 /* Optional: the training-mode decoder forward of lrp_train_step ahead of time (it needs neither lrp_weight nor the labels),
  * e.g. on a second stream under the explanation that produces lrp_weight.  A following lrp_train_step with the same B, T
- * (and the same cap_in / masks) waits for it and starts at the loss. */
+ * waits for it and starts at the loss.  Contract: the kernels read cap_in and the masks straight from the caller's device
+ * buffers (nothing is staged), in the forward AND in the backward scan of lrp_train_step — so that step must be handed the
+ * SAME cap_in / mask pointers (they must stay alive and unchanged until the step's work has completed); other pointers are
+ * refused with LRP_ERR_INVALID rather than back-propagated through masks the forward did not use.  lrp_encode_images,
+ * lrp_set_features, lrp_set_weight[_dev] and lrp_set_precision drop a pending early forward. */
 int lrp_train_forward(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const float* mask_image_features_dev,
                       const float* mask_global_dev, const float* mask_output_dev, const float* mask_lstm_in_dev,
                       const float* mask_lstm_rec_dev, void* stream);
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream);
 int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
+
+/* ABI v4.  Kernel launches issued by this library since it was loaded (all handles, this process; copies and memsets not
+ * counted): bench.py brackets one single-image explanation with it (`latency.launches`). */
+int64_t lrp_launch_count(void);
 
 const char* lrp_last_error(void);
 int lrp_abi_version(void);

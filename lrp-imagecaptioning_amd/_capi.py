@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrp_hip.so")
 
-LRP_ABI_VERSION = 3
+LRP_ABI_VERSION = 4
 LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANGE, LRP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
 LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
@@ -79,6 +79,7 @@ SYMBOLS = {
     "lrp_heatmap_scores": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "lrp_last_error": (C.c_char_p, []),
     "lrp_abi_version": (C.c_int, []),
+    "lrp_launch_count": (C.c_int64, []),
 }
 
 _lib = None

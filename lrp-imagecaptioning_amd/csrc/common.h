@@ -10,6 +10,16 @@
 
 namespace lrp {
 
+// Every kernel launch of the library goes through hipLaunchKernelGGL; this wrapper counts them (lrp_launch_count: bench.py
+// reports the launches behind one single-image explanation next to its latency).  Memsets / copies are not counted.
+inline unsigned long long g_launch_count = 0;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                  \
+  do {                                                                                                    \
+    ++::lrp::g_launch_count;                                                                              \
+    kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                   \
+  } while (0)
+
 std::string& last_error_ref();
 
 inline int fail(int code, const char* fmt, ...) {

@@ -103,6 +103,7 @@ static int with_handle(const lrp_handle* h, F&& body) noexcept {
 extern "C" {
 
 int lrp_abi_version(void) { return LRP_ABI_VERSION; }
+int64_t lrp_launch_count(void) { return (int64_t)lrp::g_launch_count; }
 const char* lrp_last_error(void) { return last_error_ref().c_str(); }
 
 int lrp_create(const lrp_config* cfg, lrp_handle** out) {
@@ -370,9 +371,18 @@ int lrp_set_precision(lrp_handle* h, int32_t mode) {
     if (mode != LRP_PREC_FP32 && mode != LRP_PREC_BF16X3 && mode != LRP_PREC_BF16X3_FAST && mode != LRP_PREC_F16X2)
       return fail(LRP_ERR_INVALID, "unknown precision mode %d", mode);
     const int km = mode == LRP_PREC_FP32 ? PREC_FP32 : PREC_BF16X3;
+    const bool fast = mode == LRP_PREC_BF16X3_FAST, f16 = mode == LRP_PREC_F16X2;
+    // The encode caches belong to the arithmetic they were computed in (the gates' denominators Z+ follow the walk's
+    // products; the fp32 mode takes another forward altogether): a mode change drops them, so that an explain call
+    // without a new lrp_encode_images returns LRP_ERR_STATE instead of walking with gates of the other arithmetic.
+    if (h->enc.prec != km || h->enc.fwd_fast != fast || h->enc.walk_f16 != f16) {
+      LRP_TRY(h->trainer.drop_early_forward(nullptr));
+      h->enc.encoded = 0;
+      h->rn.encoded = 0;
+    }
     h->enc.prec = km;
-    h->enc.fwd_fast = mode == LRP_PREC_BF16X3_FAST;
-    h->enc.walk_f16 = mode == LRP_PREC_F16X2;         // (forward, decoder and the ResNet encoder stay as in LRP_PREC_BF16X3)
+    h->enc.fwd_fast = fast;
+    h->enc.walk_f16 = f16;                            // (forward, decoder and the ResNet encoder stay as in LRP_PREC_BF16X3)
     h->rn.prec = km;
     h->dec.prec = km;
     return LRP_OK;

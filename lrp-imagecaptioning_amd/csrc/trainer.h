@@ -50,9 +50,6 @@ struct Trainer {
   ~Trainer() {
     if (host_pinned) (void)hipHostFree(host_pinned);
     if (ev_fwd) (void)hipEventDestroy(ev_fwd);
-    if (cap_st) (void)hipStreamDestroy(cap_st);
-    if (ev_ga) (void)hipEventDestroy(ev_ga);
-    if (ev_gb) (void)hipEventDestroy(ev_gb);
   }
   float lr = 0.f, clip = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f;
   int64_t iter = 0;
@@ -193,130 +190,10 @@ struct Trainer {
     float* grads; float* losses_dev; hipStream_t st;
   };
 
-  // ---- the decoder scans as hipGraphs.  A scan is T steps x ~10-20 launches of 5-16 us each (~450 launches per iteration
-  // for the adaptive decoder), queued by one host thread: at 8 images per GPU the launches, not the kernels, set its
-  // duration.  The sequence depends only on (B, T) and on the pointers in StepIn, so the second consecutive call with the
-  // same arguments is stream-captured and instantiated, and every later one is a single hipGraphLaunch; different arguments
-  // (or a capture the runtime refuses) run the plain launches.  Opt-in: LRP_TRAIN_GRAPH=1 (see graph_or_run).
-  struct ScanGraph {
-    std::vector<long long> key, last;
-    hipGraphExec_t exec = nullptr;
-    bool broken = false;
-    long launches = 0, plain = 0, captures = 0;
-    ~ScanGraph() {
-      if (getenv("LRP_TRAIN_GRAPH_DEBUG")) fprintf(stderr, "[scan graph] captures %ld, graph launches %ld, plain runs %ld, broken %d\n", captures, launches, plain, (int)broken);
-      if (exec) (void)hipGraphExecDestroy(exec);
-    }
-  };
-  ScanGraph g_fwd, g_bwd;
-  hipStream_t cap_st = nullptr;                          // capture stream of the scan graphs
-  // The scans' dropout masks are copied into buffers of the trainer (19 MB at B = 32, T = 21: ~10 us): the caller's fresh
-  // tensors would change the pointers — and with them the graph — every iteration, and the backward scan then reads
-  // exactly the masks its forward used, whatever the caller passes to lrp_train_step.
-  DevBuf Mlin, Mlrec, Mout;
-  const float *s_lin = nullptr, *s_lrec = nullptr, *s_out = nullptr;
-  int stage_masks(const StepIn& in, int64_t* total) {
-    const size_t cap = (size_t)Bm * Tm;
-    auto stage = [&](const float* src, DevBuf& buf, size_t cap_floats, size_t floats, const float*& dst) -> int {
-      if (!src) { dst = nullptr; return LRP_OK; }
-      if (!buf.p) LRP_TRY(buf.alloc(cap_floats * sizeof(float), total));
-      LRP_HIP_CHECK(hipMemcpyAsync(buf.p, src, floats * sizeof(float), hipMemcpyDeviceToDevice, in.st));
-      dst = buf.as<float>();
-      return LRP_OK;
-    };
-    const size_t TB = (size_t)in.T * in.B;
-    const size_t win = gridtd ? (size_t)2 * H : (size_t)2 * E;     // width of the masked LSTM input (language cell / adaptive cell)
-    LRP_TRY(stage(in.m_lin, Mlin, 4 * cap * win, 4 * TB * win, s_lin));
-    LRP_TRY(stage(in.m_lrec, Mlrec, 4 * cap * H, 4 * TB * H, s_lrec));
-    LRP_TRY(stage(in.m_out, Mout, cap * H, TB * H, s_out));
-    return LRP_OK;
-  }
-  StepIn staged(const StepIn& in) const {
-    StepIn si = in;
-    si.m_lin = s_lin; si.m_lrec = s_lrec; si.m_out = s_out;
-    return si;
-  }
-  static int graphs_mode() {                             // read per call (the tests switch it): 0 off (default), 1 both scans, 2 forward only, 3 backward only
-    const char* e = getenv("LRP_TRAIN_GRAPH");
-    return e ? atoi(e) : 0;
-  }
-  static std::vector<long long> scan_key(const StepIn& in) {
-    auto p = [](const void* q) { return (long long)reinterpret_cast<uintptr_t>(q); };
-    return {in.B, in.T, p(in.m_out), p(in.m_lin), p(in.m_lrec), p(in.grads), p(in.st)};     // everything the scans read from StepIn
-  }
-  // The graph runs on the trainer's own stream, fenced against the caller's with two events: the caller's stream is often the
-  // legacy default stream, and a graph launched INTO it was observed not to be ordered against later work of other streams
-  // [MI355X, ROCm 7.2: the next iteration's forward overwrote the staged masks under a still-running backward graph].
-  hipEvent_t ev_ga = nullptr, ev_gb = nullptr;
-  int launch_graph(hipGraphExec_t exec, hipStream_t st) {
-    if (!ev_ga) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_ga, hipEventDisableTiming));
-    if (!ev_gb) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_gb, hipEventDisableTiming));
-    LRP_HIP_CHECK(hipEventRecord(ev_ga, st));
-    LRP_HIP_CHECK(hipStreamWaitEvent(cap_st, ev_ga, 0));
-    LRP_HIP_CHECK(hipGraphLaunch(exec, cap_st));
-    LRP_HIP_CHECK(hipEventRecord(ev_gb, cap_st));
-    LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gb, 0));
-    return LRP_OK;
-  }
-  template <class F>
-  int graph_or_run(ScanGraph& G, const StepIn& in, F&& fn) {
-    // OPT-IN, and never on the legacy default stream: there, replays of the backward scan produced wrong (and varying)
-    // gradients from the fifth iteration on at B = 32 with the grid-TD decoder [MI355X, ROCm 7.2; launching into the
-    // stream, or on a stream of our own fenced with events, made no difference; a fresh capture per iteration was right,
-    // and so was every run on a non-default stream].  The mechanism was not found, so the default stays plain launches.
-    const int which = graphs_mode();
-    if (which == 0 || in.st == nullptr || G.broken || (which == 2 && &G != &g_fwd) || (which == 3 && &G != &g_bwd)) { ++G.plain; return fn(in); }
-    const std::vector<long long> key = scan_key(in);
-    static const bool recapture = getenv("LRP_TRAIN_GRAPH_RECAPTURE") != nullptr;     // diagnostic: a fresh graph every time
-    if (G.exec && key == G.key && !recapture) {
-      ++G.launches;
-      return launch_graph(G.exec, in.st);
-    }
-    if (key != G.last && !recapture) {                   // first sighting of these arguments: plain launches
-      G.last = key;
-      ++G.plain;
-      return fn(in);
-    }
-    if (G.exec) { (void)hipGraphExecDestroy(G.exec); G.exec = nullptr; G.key.clear(); }
-    // recorded on a stream of our own (the caller's may be the legacy default stream, which cannot be captured); the
-    // kernel nodes carry no stream, the graph is launched on the caller's
-    if (!cap_st && hipStreamCreateWithFlags(&cap_st, hipStreamNonBlocking) != hipSuccess) {
-      (void)hipGetLastError();
-      G.broken = true;
-      ++G.plain;
-      return fn(in);
-    }
-    if (hipStreamBeginCapture(cap_st, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      (void)hipGetLastError();
-      G.broken = true;
-      ++G.plain;
-      return fn(in);
-    }
-    StepIn rec = in;
-    rec.st = cap_st;
-    const int rc = fn(rec);                              // recorded, not executed
-    hipGraph_t graph = nullptr;
-    const hipError_t e = hipStreamEndCapture(cap_st, &graph);
-    if (rc != LRP_OK || e != hipSuccess || !graph) {
-      (void)hipGetLastError();
-      if (graph) (void)hipGraphDestroy(graph);
-      G.broken = true;                                   // nothing ran: do it the plain way, and from now on
-      ++G.plain;
-      return fn(in);
-    }
-    const hipError_t ei = hipGraphInstantiate(&G.exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess || !G.exec) {
-      (void)hipGetLastError();
-      G.exec = nullptr;
-      G.broken = true;
-      ++G.plain;
-      return fn(in);
-    }
-    G.key = key;
-    ++G.captures;
-    return launch_graph(G.exec, in.st);
-  }
+  // (Round 2 carried the two decoder scans as stream-captured hipGraphs behind an env switch.  Replays produced wrong
+  //  gradients in one configuration (grid-TD, B = 32, caller on the legacy default stream) and the mechanism was never
+  //  found; the measured gain was 1.5 %.  The path was removed in round 3 rather than shipped behind a switch: the scans
+  //  are plain launches on the caller's stream, and they read the caller's mask tensors directly.)
   const char* nm_proj() const { return gridtd ? "W_va" : "Wv"; }
   const char* nm_hatt() const { return gridtd ? "W_ha" : "Wg"; }
   const char* nm_satt() const { return gridtd ? "W_s" : "Ws"; }
@@ -327,6 +204,9 @@ struct Trainer {
   // (a chain of small launches under an MFMA-bound walk); lrp_train_step then picks it up (same B, T) and starts at the loss.
   bool fwd_valid = false;
   int fwd_B = 0, fwd_T = 0;
+  // what that forward read: lrp_train_step back-propagates through THESE masks, so it insists on being handed the same ones
+  const int* fwd_cap = nullptr;
+  const float *fwd_m_if = nullptr, *fwd_m_glob = nullptr, *fwd_m_out = nullptr, *fwd_m_lin = nullptr, *fwd_m_lrec = nullptr;
   hipEvent_t ev_fwd = nullptr;
   // An early forward is only valid for the features / weights it ran on.  lrp_encode_images, lrp_set_features and
   // lrp_set_weight call this: a following lrp_train_step then runs its own forward (inline) instead of back-propagating
@@ -374,14 +254,13 @@ struct Trainer {
     // X rows: [emb | glob] (adaptive input_x) or [glob | emb] (the non-recurrent part of the top-down LSTM's input)
     hipLaunchKernelGGL(tr_build_x_kernel, dim3((unsigned)TB), dim3(256), 0, st, W("embedding"), glob.as<float>(), in.cap_in, x, B, T, E,
                        gridtd ? E : 0, gridtd ? 0 : E);
-    LRP_TRY(stage_masks(in, total));
-    const StepIn si = staged(in);
-    LRP_TRY(graph_or_run(g_fwd, si, [&](const StepIn& q) -> int { return gridtd ? scan_fwd_gridtd(q) : scan_fwd_adaptive(q); }));
+    LRP_TRY(gridtd ? scan_fwd_gridtd(in) : scan_fwd_adaptive(in));
     LRP_HIP_CHECK(hipGetLastError());
     LRP_TRY(mm(false, false, (int)TB, V, H, OUTm.as<float>(), H, W("output_W"), V, logits.as<float>(), V, false, st));   // logits - bias
     if (!ev_fwd) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
     LRP_HIP_CHECK(hipEventRecord(ev_fwd, st));
     fwd_valid = true; fwd_B = B; fwd_T = T;
+    fwd_cap = in.cap_in; fwd_m_if = in.m_if; fwd_m_glob = in.m_glob; fwd_m_out = in.m_out; fwd_m_lin = in.m_lin; fwd_m_lrec = in.m_lrec;
     return LRP_OK;
   }
 
@@ -390,8 +269,15 @@ struct Trainer {
     const int B = in.B, T = in.T;
     hipStream_t st = in.st;
     const size_t TB = (size_t)T * B, BH = (size_t)B * H;
-    if (fwd_valid && fwd_B == B && fwd_T == T) LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_fwd, 0));    // ran early (lrp_train_forward)
-    else LRP_TRY(forward(enc, in, total));
+    if (fwd_valid && fwd_B == B && fwd_T == T) {           // ran early (lrp_train_forward)
+      // the backward scan must see the captions and dropout masks its forward saw (include/lrp_hip.h: lrp_train_forward)
+      if (in.cap_in != fwd_cap || in.m_if != fwd_m_if || in.m_glob != fwd_m_glob || in.m_out != fwd_m_out || in.m_lin != fwd_m_lin ||
+          in.m_lrec != fwd_m_lrec)
+        return fail(LRP_ERR_INVALID, "lrp_train_step: cap_in / dropout masks differ from the ones the pending lrp_train_forward ran with");
+      LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_fwd, 0));
+    } else {
+      LRP_TRY(forward(enc, in, total));
+    }
     fwd_valid = false;
     const float* feat = in.feat;
     float* grads = in.grads;
@@ -414,8 +300,7 @@ struct Trainer {
     LRP_HIP_CHECK(hipMemsetAsync(dVacc.p, 0, BH * 4, st));
     LRP_HIP_CHECK(hipMemsetAsync(dC.p, 0, BH * 4, st));
     // ---------------- reverse scan + the weight gradients of the recurrent part (K = (t, b) rows); leaves dX
-    const StepIn si = staged(in);                        // the masks the forward ran with
-    LRP_TRY(graph_or_run(g_bwd, si, [&](const StepIn& q) -> int { return gridtd ? scan_bwd_gridtd(q) : scan_bwd_adaptive(q); }));
+    LRP_TRY(gridtd ? scan_bwd_gridtd(in) : scan_bwd_adaptive(in));
     LRP_HIP_CHECK(hipGetLastError());
     // ---------------- attention statics, embedding, global / image_features branches
     float* dx = dX.as<float>();

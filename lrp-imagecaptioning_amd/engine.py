@@ -64,7 +64,7 @@ class LRPEngine(object):
             _capi.check(self._lib.lrp_create(C.byref(cfg), C.byref(self._h)))
         self.captions = None
         self.n_images = 0
-        self.precision = "f16x2"                        # library default for the reverse walk (set_precision)
+        self.precision = "bf16x3"                       # library default for the reverse walk (set_precision)
 
     # ------------------------------------------------------------------ lifetime
     def close(self):
@@ -224,10 +224,18 @@ class LRPEngine(object):
         _capi.check(self._lib.lrp_train_set_precision(self._h, m))
         self.train_precision = mode
 
-    def _train_inputs(self, cap_in, masks):
-        """Device copies + checks of what the decoder's training forward reads: cap_in (B, T) and the dropout masks."""
+    def _train_inputs(self, cap_in, masks, pending=None):
+        """Device copies + checks of what the decoder's training forward reads: cap_in (B, T) and the dropout masks.
+        pending: what a not yet consumed train_forward converted — the same source OBJECT maps to the same device tensor
+        (lrp_train_step insists on the pointers lrp_train_forward read)."""
         masks = masks or {}
-        ci = self._dev(cap_in, torch.int32)
+        cache = pending or {}
+        made = {}
+        hit = cache.get("cap_in")
+        ci = hit[1] if hit is not None and hit[0] is cap_in else self._dev(cap_in, torch.int32)
+        if hit is not None and hit[0] is cap_in:
+            ci.record_stream(torch.cuda.current_stream(self.device))
+        made["cap_in"] = (cap_in, ci)
         if ci.dim() != 2:
             raise ValueError("cap_in must be (B, T)")
         B, T = ci.shape
@@ -239,11 +247,19 @@ class LRPEngine(object):
         for k in masks:
             if k not in ("image_features", "global", "output", "lstm_in", "lstm_rec", "logits"):
                 raise ValueError("unknown dropout mask '%s'" % k)
+        self._train_made = made
+
         def m(key, shape):
-            v = masks.get(key)
-            if v is None:
+            src = masks.get(key)
+            if src is None:
                 return None
-            v = self._dev(v)
+            hit = cache.get(key)
+            if hit is not None and hit[0] is src:
+                v = hit[1]
+                v.record_stream(torch.cuda.current_stream(self.device))      # (made under the early forward's stream)
+            else:
+                v = self._dev(src)
+            made[key] = (src, v)
             if tuple(v.shape) != shape:
                 raise ValueError("mask '%s' must be %s" % (key, shape))
             return v
@@ -259,7 +275,7 @@ class LRPEngine(object):
         B, T = ci.shape
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         _capi.check(self._lib.lrp_train_forward(self._h, B, T, p(ci), p(mi), p(mg), p(mo), p(ml), p(mr), self._stream()))
-        self._train_fwd_keep = (ci, mi, mg, mo, ml, mr)                     # alive until the step has consumed them
+        self._train_fwd_keep = self._train_made                             # alive (and reused) until the step has consumed them
 
     def train_step(self, cap_in, y_idx, lrp_weight, masks=None, grads=None):
         """Gradients of the two-headed loss for the images last encoded.  cap_in / y_idx (B, T) ints (y -1 = no label),
@@ -267,7 +283,8 @@ class LRPEngine(object):
         'lstm_in' (T, 4, B, 2E), 'lstm_rec' (T, 4, B, H) (the LSTM cell's per-gate, per-step dropout).
         Returns (grads flat float32 device tensor, losses (5,) device tensor = total, loss head 1, loss head 2,
         accuracy head 1, accuracy head 2: the list `train_on_batch` returns)."""
-        ci, (mi, mg, mo, ml, mr, mz) = self._train_inputs(cap_in, masks)
+        ci, (mi, mg, mo, ml, mr, mz) = self._train_inputs(cap_in, masks, getattr(self, "_train_fwd_keep", None))
+        self._train_fwd_keep = None
         yi = self._dev(y_idx, torch.int32)
         B, T = ci.shape
         lw = self._dev(lrp_weight).reshape(B, T, self.V)
@@ -368,14 +385,19 @@ class LRPEngine(object):
         return out, R, att, rw
 
     def set_precision(self, mode):
-        """'f16x2' (fp16-pair reverse walk, two MFMAs per product below the top block; default), 'bf16x3' (split-bf16
-        walk, three everywhere), 'fp32' (exact fp32 MFMA) or 'bf16x3_fast' (split forward activations too; see
-        include/lrp_hip.h)."""
+        """'bf16x3' (default: split-bf16 walk, hi*hi' + hi*lo' + lo*hi' in every layer, 16 mantissa bits on both operands —
+        parity independent of the weight statistics), 'fp32' (exact fp32 MFMA, the reference's arithmetic), 'f16x2'
+        (opt-in fast mode: fp16-pair relevance, ONE fp16 per weight below the top block — two MFMAs per product; its error
+        depends on how concentrated the weights are, see include/lrp_hip.h) or 'bf16x3_fast' (split forward activations
+        too).  A mode change drops the encode caches: call encode_images again."""
         m = {"fp32": _capi.LRP_PREC_FP32, "bf16x3": _capi.LRP_PREC_BF16X3, "bf16x3_fast": _capi.LRP_PREC_BF16X3_FAST,
              "f16x2": _capi.LRP_PREC_F16X2}.get(mode)
         if m is None:
             raise ValueError("precision must be 'fp32', 'bf16x3', 'bf16x3_fast' or 'f16x2'")
         _capi.check(self._lib.lrp_set_precision(self._h, m))
+        if mode != self.precision:
+            self.n_images = 0                            # the library dropped the caches of the other arithmetic
+            self.captions = None
         self.precision = mode
 
     # ------------------------------------------------------------------ profiling hooks (bench.py)

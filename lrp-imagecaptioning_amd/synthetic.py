@@ -115,6 +115,39 @@ def vgg_weights(rs, cfg=VGG16_CFG, bias_std=0.05):
     return w
 
 
+def vgg_weights_trained_like(rs, cfg=VGG16_CFG, density=0.05, sigma=1.5, active_frac=0.2, calib_image=None):
+    """Kernels with the statistics of a TRAINED network instead of an initialisation: only `density` of the entries are
+    non-zero and their magnitudes are heavy-tailed (He-normal x lognormal(0, sigma)), rescaled to the He variance
+    2 / (9 C_in) (then per layer so that the post-ReLU rms on the calibration image is 1); biases are pushed negative channel by channel until only `active_frac` of a channel's post-ReLU
+    activations on `calib_image` (1, H, W, 3) are non-zero (sparse activations, mostly-dead windows).  A sum of an
+    alpha1beta0 layer then has a few dominant products instead of thousands of comparable ones — the case in which
+    per-weight rounding errors do not average out (tests/test_gpu_stress_parity.py).  The calibration is a float32
+    torch-CPU forward, layer by layer."""
+    import torch
+    import torch.nn.functional as F
+    w = {}
+    x = None if calib_image is None else torch.as_tensor(np.ascontiguousarray(calib_image)).permute(0, 3, 1, 2).contiguous()
+    for name, cin, cout, pool in cfg:
+        k = rs.standard_normal((3, 3, cin, cout))
+        k *= (rs.uniform(size=k.shape) < density) * np.exp(sigma * rs.standard_normal(k.shape))
+        k *= np.sqrt(2.0 / (9 * cin)) / max(float(k.std()), 1e-30)
+        w[name + "_W"] = k.astype(np.float32)
+        b = (rs.standard_normal((cout,)) * 0.05).astype(np.float32)
+        if x is not None:
+            z = F.conv2d(x, torch.as_tensor(w[name + "_W"]).permute(3, 2, 0, 1).contiguous(), None, padding=1)
+            q = torch.quantile(z.permute(1, 0, 2, 3).reshape(cout, -1)[:, ::max(1, z[0, 0].numel() // 4096)], 1.0 - active_frac, dim=1)
+            b = (-q).numpy().astype(np.float32)
+            x = F.relu(z + torch.as_tensor(b).view(1, -1, 1, 1))
+            g = 1.0 / max(float(x.pow(2).mean().sqrt()), 1e-30)      # keep the activations' scale: post-ReLU rms = 1
+            w[name + "_W"] = (w[name + "_W"] * g).astype(np.float32)
+            b = (b * g).astype(np.float32)
+            x = x * g
+            if pool:
+                x = F.max_pool2d(x, 2, 2)
+        w[name + "_b"] = b
+    return w
+
+
 def images(rs, B, H=224, W=224):
     """BGR 'caffe'-mode preprocessed images: U[0,255] - mean (preprocessors.py:43-44)."""
     mean = np.array([103.939, 116.779, 123.68], dtype=np.float32)

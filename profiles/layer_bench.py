@@ -18,7 +18,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=10)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--vocab", type=int, default=10000)
-    ap.add_argument("--precision", default="f16x2", choices=["fp32", "bf16x3", "f16x2"])
+    ap.add_argument("--precision", default="bf16x3", choices=["fp32", "bf16x3", "f16x2"])
     a = ap.parse_args()
     import torch
     from bench import synth_weights

@@ -86,7 +86,7 @@ def test_config1_b32_two_handles_matches_oracle_and_small_batch(config1, prec):
     for (k, b, t), ref in refs.items():
         errs[(k, b, t)] = rel_l1(outs[k][b * T + t - 1].cpu().numpy(), ref)
     report("config1_b32_oracle_" + prec, max_rel_l1=max(errs.values()), samples=len(errs))
-    # (f16x2, the default: 3.1e-6 here with three-term products in block5 only; two-term there as well measured 1.0e-4)
+    # (f16x2, the opt-in fast mode: 3.1e-6 here with three-term products in block5 only; two-term there as well measured 1.0e-4)
     assert max(errs.values()) < TOL, errs
     # (b) every heat-map vs its image explained alone on a B = 1 handle (small-tile kernels)
     solo = LRPEngine(decoder="adaptive", V=V, max_images=1, max_tokens=T, max_caption_len=T + 1)

@@ -408,36 +408,23 @@ def test_early_forward_gives_identical_gradients():
     assert torch.equal(g2, g_ref)
 
 
-def test_scan_graphs_replay_bit_identically(monkeypatch):
-    """Opt-in (LRP_TRAIN_GRAPH=1, non-default stream): the decoder scans are stream-captured into hipGraphs on their second
-    run with the same arguments and replayed from the third on (trainer.h graph_or_run).  Plain launches, the capturing
-    run and the replays must give the same bits — with fresh mask tensors every call (the scans read staged copies) — and
-    other masks through the same graph must give what a fresh handle computes with plain launches."""
+def test_step_refuses_masks_other_than_the_early_forwards():
+    """lrp_train_forward reads the caller's mask buffers and lrp_train_step's backward scan reads them again (nothing is
+    staged, include/lrp_hip.h): a step handed OTHER mask pointers than its pending early forward ran with must be refused
+    (LRP_ERR_INVALID -> ValueError), not back-propagated through masks the forward never applied; the same objects pass."""
     w, X, cap_in, y, lw, masks = _case(13)
-    w2, X2, cap2, y2, lw2, masks2 = _case(14)
-    eng2 = _engine(w, len(X))                            # reference: plain launches (the default)
-    eng2.train_begin()
-    eng2.encode_images(X)
-    g_plain = eng2.train_step(cap_in, y, lw, masks)[0].clone()
-    g_plain2 = eng2.train_step(cap_in, y, lw, masks2)[0].clone()
-    monkeypatch.setenv("LRP_TRAIN_GRAPH", "1")
     eng = _engine(w, len(X))
     eng.train_begin()
     eng.encode_images(X)
-    main = torch.cuda.Stream()
-    main.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(main):
-        grads = torch.empty_like(g_plain)                # one persistent gradient buffer, as training.py has
-        runs = []
-        for _ in range(5):                               # 1: plain, 2: capture, 3-5: replay
-            fresh = {k: np.array(v) for k, v in masks.items()}      # (uploaded into new device tensors by every call)
-            g, l = eng.train_step(cap_in, y, lw, fresh, grads=grads)
-            runs.append(g.clone())
-        g_new = eng.train_step(cap_in, y, lw, masks2, grads=grads)[0].clone()
-    main.synchronize()
-    for g in runs:
-        assert torch.equal(g, g_plain)
-    assert not torch.equal(g_new, g_plain) and torch.equal(g_new, g_plain2)
+    g_ref = eng.train_step(cap_in, y, lw, masks)[0].clone()
+    eng.train_forward(cap_in, masks)
+    other = {k: np.array(v) for k, v in masks.items()}    # equal values, other objects -> other device buffers
+    with pytest.raises(ValueError):
+        eng.train_step(cap_in, y, lw, other)
+    eng.encode_images(X)                                   # drops the pending forward
+    eng.train_forward(cap_in, masks)
+    g = eng.train_step(cap_in, y, lw, masks)[0]
+    assert torch.equal(g, g_ref)
 
 
 def test_early_forward_is_dropped_by_a_new_encode_or_weight():
