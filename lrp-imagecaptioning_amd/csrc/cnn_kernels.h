@@ -237,6 +237,130 @@ __global__ __launch_bounds__(256) void split_h_scaled_kernel(const float* __rest
     split8h_store(v, xs + i * 8);
   }
 }
+// ---- pairs straight from the producer (no split pass between two convs of the fp16-pair forward) -------------------
+// The scale of a layer's OUTPUT pairs has to be known before its conv runs, so it comes from a bound instead of the
+// measured maximum: |a_l| <= max|x_l| * (largest absolute row sum of w_l) + max|b_l|, with max|x_l| the maximum the
+// producer of x_l measured (exact).  The bound overshoots the true maximum by the factor a row sum overshoots a typical
+// dot product (20 ... 100 for VGG-sized layers) — and since every layer starts again from a MEASURED maximum the overshoot
+// does not compound.  What it costs: a pair keeps 22 bits down to |value| = 2^-3 of the scaled range's floor; below that
+// its absolute error stays 2^-25 of the SCALED unit, i.e. (overshoot / 30000) * 2^-25 relative to the tensor's maximum
+// — 1e-10 at an overshoot of 100, far below the pair's own 2^-22.
+// norm = { largest row sum of |w| over the output channels, max|b| } of the layer (conv_norm_kernel).
+// Per IMAGE (one block each): out_scale[n] <- 2^k, k = floor(log2(30000 / bound_n)), bound_n from the maximum image n's rows
+// raised in in_slots[n][ACT_MAX_SLOTS];  unscale_next[n] <- 2^-k * (scale record of the CONSUMER's weights)[1].
+__global__ __launch_bounds__(64) void fwd_scale_kernel(const unsigned* __restrict__ in_slots, const float* __restrict__ norm,
+                                                       const float* __restrict__ wsc_next, float* __restrict__ out_scale,
+                                                       float* __restrict__ unscale_next) {
+  const int n = blockIdx.x;
+  float m = __uint_as_float(in_slots[(size_t)n * ACT_MAX_SLOTS + (threadIdx.x & (ACT_MAX_SLOTS - 1))]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (threadIdx.x != 0) return;
+  const float bound = m * norm[0] + norm[1];
+  int k = 0;
+  if (bound > 0.f && bound < 3.0e38f) {
+    k = (int)floorf(log2f(30000.f / bound));
+    k = k < -120 ? -120 : k > 120 ? 120 : k;
+  }
+  out_scale[n] = ldexpf(1.f, k);
+  if (unscale_next) unscale_next[n] = ldexpf(1.f, -k) * wsc_next[1];
+}
+// max|x| per image into slots[n][ACT_MAX_SLOTS]; grid (blocks per image, images)
+__global__ __launch_bounds__(256) void absmax_img_slots_kernel(const f32x4* __restrict__ x, size_t per_img4, unsigned* __restrict__ slots) {
+  const f32x4* xi = x + (size_t)blockIdx.y * per_img4;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_img4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = xi[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f)
+    atomicMax(slots + (size_t)blockIdx.y * ACT_MAX_SLOTS + ((blockIdx.x + (threadIdx.x >> 6)) & (ACT_MAX_SLOTS - 1)), __float_as_uint(m));
+}
+// norm[0] = max over rows of sum_k |w[row][k]| (blocks 0 .. rows-1), norm[1] = max|b| (block `rows`); norm zeroed before
+__global__ __launch_bounds__(256) void conv_norm_kernel(const float* __restrict__ w, int rows, int K, const float* __restrict__ b,
+                                                        int nb, float* __restrict__ norm) {
+  __shared__ float red[256];
+  float s = 0.f;
+  if ((int)blockIdx.x < rows) {
+    const float* r = w + (size_t)blockIdx.x * K;
+    for (int k = threadIdx.x; k < K; k += 256) s += fabsf(r[k]);
+  } else {
+    for (int k = threadIdx.x; k < nb; k += 256) s = fmaxf(s, fabsf(b[k]));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = (int)blockIdx.x < rows ? red[threadIdx.x] + red[threadIdx.x + o] : fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned*>(norm + ((int)blockIdx.x < rows ? 0 : 1)), __float_as_uint(red[0] * ((int)blockIdx.x < rows ? 1.0001f : 1.f)));
+}
+// stacked dual matrix [a rows (C) | Z rows (C)][K] -> rows interleaved per 32 channels ([w | w+] of the same channels side by side)
+__global__ __launch_bounds__(256) void dual_interleave_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int K) {
+  const size_t total = (size_t)2 * C * K;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / K), k = (int)(i % K);
+    const int half = row >= C ? 1 : 0, c = row - half * C;
+    dst[(size_t)(64 * (c / 32) + 32 * half + (c & 31)) * K + k] = src[i];
+  }
+}
+// 2x2/2 max-pool + first-arg-max gate (pool_gate_kernel) + the pooled activations as the next conv's operand (fp16 pairs
+// scaled by scale[image]) in ONE pass over (a_l, Z+_l): replaces maxpool2_kernel + pool_gate_kernel + split_h_scaled_kernel.
+// 8 channels per thread; a may alias g; xnext (fp32 pooled activations: the fine-tune step's kept input) may be null.
+__global__ __launch_bounds__(256) void pool_gate_split_kernel(const float* a, const float* __restrict__ z, float* g,
+                                                              float* __restrict__ pairs, float* __restrict__ xnext,
+                                                              const float* __restrict__ scale, int NB, int H, int W, int C) {
+  const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)NB * Ho * Wo * C8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    size_t r = i / C8;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float av[4][8], zv[4][8];
+    size_t off[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      off[p] = ((((size_t)n * H + 2 * ho + (p >> 1)) * W + 2 * wo + (p & 1)) * C) + 8 * c8;
+      *reinterpret_cast<f32x4*>(av[p]) = *reinterpret_cast<const f32x4*>(a + off[p]);
+      *reinterpret_cast<f32x4*>(av[p] + 4) = *reinterpret_cast<const f32x4*>(a + off[p] + 4);
+      *reinterpret_cast<f32x4*>(zv[p]) = *reinterpret_cast<const f32x4*>(z + off[p]);
+      *reinterpret_cast<f32x4*>(zv[p] + 4) = *reinterpret_cast<const f32x4*>(z + off[p] + 4);
+    }
+    float mx[8];
+    int arg[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { mx[c] = av[0][c]; arg[c] = 0; }
+#pragma unroll
+    for (int p = 1; p < 4; ++p)
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (av[p][c] > mx[c]) { mx[c] = av[p][c]; arg[c] = p; }
+    const size_t po = (((size_t)n * Ho + ho) * Wo + wo) * C + 8 * c8;
+    if (xnext) {
+      *reinterpret_cast<f32x4*>(xnext + po) = *reinterpret_cast<const f32x4*>(mx);
+      *reinterpret_cast<f32x4*>(xnext + po + 4) = *reinterpret_cast<const f32x4*>(mx + 4);
+    }
+    float sv[8];
+    const float sc = scale[n];                          // per image (fwd_scale_kernel)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sv[c] = mx[c] * sc;
+    split8h_store(sv, pairs + po);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = (arg[c] == p) ? av[p][c] / safe_den(zv[p][c]) : 0.f;
+      *reinterpret_cast<f32x4*>(g + off[p]) = *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(g + off[p] + 4) = *reinterpret_cast<const f32x4*>(o + 4);
+    }
+  }
+}
 // max|x| of a tensor into ACT_MAX_SLOTS slots (the image layer's activations come from the fp32 kernel, which keeps no maximum)
 __global__ __launch_bounds__(256) void absmax_slots_kernel(const f32x4* __restrict__ x, size_t n4, unsigned* __restrict__ slots) {
   float m = 0.f;

@@ -185,6 +185,18 @@ struct ConvArgs {
   // largest |out| (slot = block id mod slots: spreads the atomics; the consumer takes the maximum over the slots).
   const float* in_unscale;
   unsigned* act_max_out;
+  // EPI_FWD_DUAL, interleaved rows, PREC_F16X2: the epilogue also writes a_l as the NEXT conv's operand — fp16 pairs
+  // [hi8 | lo8] of a_l * *pairs_scale (a power of two chosen BEFORE the launch from a bound on |a_l|: the measured maximum
+  // of this conv's input x its weights' largest absolute row sum + max|b|; cnn_kernels.h fwd_scale_kernel) — so no split
+  // pass runs between two convs.  skip_out: a_l itself (fp32) is not written (nobody else reads it).
+  float* pairs_out;
+  const float* pairs_scale;
+  int skip_out;
+  // scale_per_img (interleaved dual forward): in_unscale, pairs_scale and act_max_out are arrays indexed by the IMAGE of a row
+  // (row / img_rows; act_max_out[image][ACT_MAX_SLOTS]) instead of one record for the call — an image's rows only ever gather
+  // from that image, so a scale per image is as legal as one per call, and the result for an image no longer depends on
+  // which other images share its batch.
+  int scale_per_img, img_rows;
 };
 constexpr int ACT_MAX_SLOTS = 64;
 
@@ -885,13 +897,21 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
           if (ch < a.split) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const int pc = (p & ~63) + (p & 31);          // the c column of the pair; Z+ sits 32 further
-            float unscale = 1.f, omax = 0.f;
-            if constexpr (PREC == PREC_F16X2) unscale = *a.in_unscale;
+            float unscale = 1.f, omax = 0.f, pscale = 1.f;
+            int cur_img = -1;                             // image whose scales are loaded / whose maximum omax is collecting
+            auto max_slot = [&](int img) { return a.act_max_out + (size_t)img * ACT_MAX_SLOTS + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)); };
 #pragma unroll 2
             for (int ps = half; ps < RH / RPP; ps += 2) {
               const int ll = rin + ps * RPP;
               int row, n_, h_, w_;
               if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
+              const int img = !a.scale_per_img ? 0 : HALO ? n_ : row / a.img_rows;
+              if (img != cur_img) {                       // (a tile rarely straddles two images)
+                if (cur_img >= 0 && a.act_max_out && omax > 0.f) atomicMax(max_slot(cur_img), __float_as_uint(omax));
+                cur_img = img; omax = 0.f;
+                if constexpr (PREC == PREC_F16X2) unscale = a.in_unscale[img];
+                if (a.pairs_out) pscale = a.pairs_scale[img];
+              }
               f32x4 vc = *reinterpret_cast<const f32x4*>(Cs + ll * BN + pc);
               f32x4 vz = *reinterpret_cast<const f32x4*>(Cs + ll * BN + pc + 32);
               if constexpr (PREC == PREC_F16X2) { vc *= unscale; vz *= unscale; }
@@ -918,16 +938,39 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
                 for (int q = 0; q < 4; ++q) vz[q] = vc[q] / (vz[q] + (vz[q] == 0.f ? 1e-7f : 0.f));
               }
-              if constexpr (PREC == PREC_F16X2)
+              if (PREC == PREC_F16X2 || a.act_max_out)
                 omax = fmaxf(omax, fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3]))));
-              *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.split + ch) = vc;
+              if (!a.skip_out) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.split + ch) = vc;
               *reinterpret_cast<f32x4*>(a.out2 + (size_t)row * a.split + ch) = vz;
+              {
+                if (a.pairs_out) {
+                  // this thread's 4 channels are one half of a split8 group [8 x fp16 hi | 8 x fp16 lo]: two 8-byte stores
+                  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                  f16x4 hi, lo;
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    const float sv = vc[q] * pscale;
+                    hi[q] = (_Float16)sv;
+                    lo[q] = (_Float16)(sv - (float)hi[q]);
+                  }
+                  float* grp = a.pairs_out + (size_t)row * a.split + (ch & ~7);
+                  const int hq = (ch >> 2) & 1;
+                  reinterpret_cast<f16x4*>(grp)[hq] = hi;
+                  reinterpret_cast<f16x4*>(grp + 4)[hq] = lo;
+                }
+              }
             }
-            if constexpr (PREC == PREC_F16X2) {
-              if (a.act_max_out) {
+            if (a.act_max_out) {                            // (any PREC: the image layer's fp32 GEMM raises its maximum here too)
+              // one atomic per wave when all its lanes ended on the same image (nearly always), one per lane otherwise
+              int iref = cur_img;
+#pragma unroll
+              for (int o = 32; o > 0; o >>= 1) iref = max(iref, __shfl_xor(iref, o));
+              if (__all(cur_img == iref || cur_img < 0)) {
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-                if (lane == 0 && omax > 0.f) atomicMax(a.act_max_out + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)), __float_as_uint(omax));
+                if (lane == 0 && omax > 0.f && iref >= 0) atomicMax(max_slot(iref), __float_as_uint(omax));
+              } else if (cur_img >= 0 && omax > 0.f) {
+                atomicMax(max_slot(cur_img), __float_as_uint(omax));
               }
             }
           }

@@ -46,6 +46,8 @@ struct ConvLayer {
   DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
   std::vector<float> raw_w, raw_b;   // host copies as set (HWIO / (cout,)): the fine-tune step's master weights start here
   DevBuf raw_w_dev, raw_b_dev;       // the same when the weights arrived through lrp_set_weight_dev (no host copy exists then)
+  DevBuf fnorm;    // {largest absolute row sum of w, max|b|}: bound behind the scale of the pairs this layer emits (fwd_scale_kernel)
+  bool norm_dirty = true;
   DevBuf Akeep;    // fine-tune step only: a_l of the layers whose output is the next conv's input (no pool after); the
                    // LRP path turns that storage into the gate in place
   size_t act_elems() const { return (size_t)H * W * cout; }
@@ -78,6 +80,11 @@ struct Encoder {
                            // Its parity depends on the weight statistics (one fp16 per weight: worst case 2^-12 per product, above the
                            // 1e-4 bar; tests/test_gpu_stress_parity.py), so the default is the three-MFMA split-bf16 walk.
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
+  DevBuf out_scale;                   // ... and 2^k of the pairs a layer emits for its consumer (no split pass in between)
+  static bool fwd_emit() {            // LRP_FWD_EMIT=0: split passes between the convs as in round 2
+    const char* e = getenv("LRP_FWD_EMIT");
+    return !e || atoi(e) != 0;
+  }
   DevBuf tok_exp, tok_max, tok_fac;   // its per-token scale exponents / measured maxima [layers + 1][max_tokens], factors [max_tokens]
   std::vector<ProfileRec> prof;
   // Overlapped encode (mixed-precision mode): the caller's stream runs only the activation chain a_1..a_top (what
@@ -128,6 +135,8 @@ struct Encoder {
     const char* e = getenv("LRP_FWD_IL");
     return !e || atoi(e) != 0;
   }
+  // the image layer's fp32 dual GEMM with interleaved rows: gate, pairs and maximum leave its epilogue (no gate / absmax / split pass)
+  static bool image_layer_interleaved(const ConvLayer& L) { return fwd_il() && !(L.cout & 31) && conv_npad(2 * L.cout) == 2 * L.cout && !L.pool_after; }
   static bool dual_interleaved(const ConvLayer& L) { return fwd_il() && !(L.cout & 31) && conv_npad(2 * L.cout) == 2 * L.cout; }
   static bool fwd_z2() {
     const char* e = getenv("LRP_FWD_Z2");
@@ -249,6 +258,13 @@ struct Encoder {
         }
       LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (image_layer_interleaved(L)) {
+        LRP_TRY(L.w_fwd_il.alloc(pk.size() * sizeof(float), total));
+        hipLaunchKernelGGL(dual_interleave_rows_kernel, dim3(stream_grid((size_t)2 * L.cout * K)), dim3(256), 0, nullptr, L.w_fwd.as<float>(),
+                           L.w_fwd_il.as<float>(), L.cout, K);
+        LRP_HIP_CHECK(hipGetLastError());
+        LRP_HIP_CHECK(hipStreamSynchronize(nullptr));
+      }
       // backward at the image: tap-expanded channel reduction, 54 = 9 taps x (3 with w+ | 3 with w-)
       // columns, K = cout; the 3x3 shift-and-add happens in img_stencil_kernel.
       const int Npb = conv_npad(IMG_T_COLS), Kb = conv_cinp(L.cout);
@@ -352,6 +368,7 @@ struct Encoder {
       }
     }
     L.have_w = true;
+    L.norm_dirty = true;
     return LRP_OK;
   }
 
@@ -374,6 +391,7 @@ struct Encoder {
     if (li == 0) {
       const size_t nb = (size_t)conv_npad(IMG_T_COLS) * conv_cinp(L.cout);
       LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * 64));
+      if (image_layer_interleaved(L)) LRP_TRY(mk(L.w_fwd_il, (size_t)conv_npad(2 * L.cout) * 64));
       LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_h, nb));
       return LRP_OK;
     }
@@ -397,6 +415,9 @@ struct Encoder {
       hipLaunchKernelGGL(pack_image_layer_dev_kernel, dim3((27 * L.cout + 255) / 256), dim3(256), 0, st, w_dev, L.w_fwd.as<float>(),
                          L.w_bwd.as<float>(), L.w_bwd_full.as<float>(), L.cout, Kb);
       const size_t nb = (size_t)Npb * Kb;
+      if (L.w_fwd_il.p)
+        hipLaunchKernelGGL(dual_interleave_rows_kernel, dim3(stream_grid((size_t)2 * L.cout * 64)), dim3(256), 0, st, L.w_fwd.as<float>(),
+                           L.w_fwd_il.as<float>(), L.cout, 64);
       hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb / 8);
       LRP_TRY(make_f16_operand(L.w_bwd.as<float>(), nb, 0, 0, L.w_bwd_h, L.wbs, nullptr, st, false));
       LRP_HIP_CHECK(hipGetLastError());
@@ -442,6 +463,7 @@ struct Encoder {
     ConvLayer& L = layers[li];
     if (!L.have_w || !L.have_b) return fail(LRP_ERR_STATE, "layer %d has no operand copies to rebuild", li);
     LRP_TRY(repack_conv_weight_from_device(li, w_dev, tmp, st));
+    L.norm_dirty = true;
     LRP_HIP_CHECK(hipMemcpyAsync(L.bias.p, b_dev, (size_t)L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     L.raw_w.clear(); L.raw_b.clear();               // stale from here on (the trainer's master buffer is the truth)
     L.raw_w_dev.release(); L.raw_b_dev.release();
@@ -461,6 +483,7 @@ struct Encoder {
     LRP_TRY(alloc_conv_operands(li, total, st));
     LRP_TRY(repack_conv_weight_from_device(li, L.raw_w_dev.as<float>(), pack_tmp.as<float>(), st));
     L.have_w = true;
+    L.norm_dirty = true;
     encoded = 0;                                       // caches belong to the old weights
     return LRP_OK;
   }
@@ -472,6 +495,7 @@ struct Encoder {
     LRP_HIP_CHECK(hipMemcpyAsync(L.bias.p, b_dev, (size_t)L.cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     L.raw_b.clear();
     L.have_b = true;
+    L.norm_dirty = true;
     encoded = 0;
     return LRP_OK;
   }
@@ -483,6 +507,7 @@ struct Encoder {
     LRP_TRY(L.bias.alloc((size_t)L.cout * sizeof(float), total));
     LRP_HIP_CHECK(hipMemcpy(L.bias.p, b, (size_t)L.cout * sizeof(float), hipMemcpyHostToDevice));
     L.have_b = true;
+    L.norm_dirty = true;
     return LRP_OK;
   }
 
@@ -503,8 +528,10 @@ struct Encoder {
     }
     if (!act_max.p) {
       int64_t dummy = 0;
-      LRP_TRY(act_max.alloc(layers.size() * ACT_MAX_SLOTS * sizeof(unsigned), &dummy));
-      LRP_TRY(act_unscale.alloc(layers.size() * sizeof(float), &dummy));
+      // per layer AND image (the emitting forward scales every image by its own maxima; +1 layer: the images themselves)
+      LRP_TRY(act_max.alloc((layers.size() + 1) * (size_t)max_images * ACT_MAX_SLOTS * sizeof(unsigned), &dummy));
+      LRP_TRY(act_unscale.alloc((layers.size() + 1) * (size_t)max_images * sizeof(float), &dummy));
+      LRP_TRY(out_scale.alloc(layers.size() * (size_t)max_images * sizeof(float), &dummy));
     }
     LRP_HIP_CHECK(hipMemsetAsync(act_max.p, 0, act_max.bytes, st));
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, B * img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -525,6 +552,31 @@ struct Encoder {
     bool dual = overlap && fwd_f16() && fwd_dual() && fwd_split_from() >= 1000;
     for (size_t li = 1; li < layers.size(); ++li)
       if (((layers[li].cin | layers[li].cout) & 7) || !layers[li].w_fwd_h.p) dual = false;
+    // dual path: the producer hands its consumer the fp16 pairs directly (conv epilogue where no pool follows, the fused
+    // pool kernel where one does) — `in_pairs`: pin already holds the operand of the conv about to run
+    bool in_pairs = false;
+    float *pin = bufXs.as<float>(), *pout = bufXl.as<float>();
+    // ... which needs every layer on the interleaved dual matrix (the pairs and the gate leave one epilogue); scales, maxima
+    // and unscale records are then kept per IMAGE, so an image's result does not depend on the rest of its batch
+    bool emit = dual && fwd_emit() && layers.size() > 1 && layers[0].w_fwd_il.p && !layers[0].pool_after && !(img_elems & 3);
+    for (size_t li = 1; li < layers.size(); ++li)
+      if (!dual_interleaved(layers[li])) emit = false;
+    const size_t per = emit ? (size_t)max_images : 1;    // records per layer
+    auto slots_of = [&](size_t lev) { return act_max.as<unsigned>() + lev * per * ACT_MAX_SLOTS; };
+    auto unscale_of = [&](size_t li) { return act_unscale.as<float>() + li * per; };
+    auto oscale_of = [&](size_t li) { return out_scale.as<float>() + li * per; };
+    if (emit)
+      for (size_t li = 0; li < layers.size(); ++li) {
+        ConvLayer& L = layers[li];
+        if (!L.norm_dirty) continue;
+        if (!L.fnorm.p) { int64_t dummy = 0; LRP_TRY(L.fnorm.alloc(2 * sizeof(float), &dummy)); }
+        LRP_HIP_CHECK(hipMemsetAsync(L.fnorm.p, 0, 2 * sizeof(float), st));
+        // (image layer: the a rows of its 64-wide im2col matrix hold w twice, against x+ and x-: the row sum is 2x the bound)
+        hipLaunchKernelGGL(conv_norm_kernel, dim3(L.cout + 1), dim3(256), 0, st, li == 0 ? L.w_fwd.as<float>() : L.w_fwd_a.as<float>(), L.cout,
+                           li == 0 ? 64 : 9 * conv_cinp(L.cin), L.bias.as<float>(), L.cout, L.fnorm.as<float>());
+        LRP_HIP_CHECK(hipGetLastError());
+        L.norm_dirty = false;
+      }
     int gate_due = -1;                                 // dual path: layer whose gate waits for the next layer's split (it reads a_l)
     auto launch_gate = [&](int gl) {
       ConvLayer& Lg = layers[gl];
@@ -545,19 +597,22 @@ struct Encoder {
         ca.out = a_out;
         if (dual) {
           const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
-          unsigned* slots_in = act_max.as<unsigned>() + (li - 1) * ACT_MAX_SLOTS;
-          if (li == 1)
-            hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n8 * 2)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(xin[li]),
-                               n8 * 2, slots_in);
-          hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8, slots_in,
-                             act_unscale.as<float>() + li, L.wds.as<float>());
+          unsigned* slots_in = slots_of(li - 1);
+          if (!in_pairs) {
+            if (li == 1)
+              hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n8 * 2)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(xin[li]),
+                                 n8 * 2, slots_in);
+            hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], pin, n8, slots_in,
+                               unscale_of(li), L.wds.as<float>());
+          }
           if (gate_due >= 0) { launch_gate(gate_due); gate_due = -1; }       // a_{l-1} has been read: it may become G_{l-1} now
           LRP_HIP_CHECK(hipGetLastError());
           ConvArgs cd = ca;
-          cd.in = bufXs.as<float>(); cd.wpk = L.w_fwd_h.as<float>(); cd.N = 2 * L.cout; cd.split = L.cout;
+          cd.in = pin; cd.wpk = L.w_fwd_h.as<float>(); cd.N = 2 * L.cout; cd.split = L.cout;
           cd.out = a_out; cd.out2 = top ? ztop.as<float>() : bufZ.as<float>();
-          cd.in_unscale = act_unscale.as<float>() + li;
-          cd.act_max_out = act_max.as<unsigned>() + li * ACT_MAX_SLOTS;
+          cd.in_unscale = unscale_of(li);
+          cd.act_max_out = slots_of(li);
+          cd.scale_per_img = emit ? 1 : 0; cd.img_rows = L.H * L.W;
           cd.dual_il = dual_interleaved(L) ? 1 : 0;
           const bool fused_gate = cd.dual_il && !top && !L.pool_after;
           if (fused_gate) {
@@ -566,6 +621,15 @@ struct Encoder {
             if (!keep_acts) a_out = xin[li] == bufA.as<float>() ? bufX.as<float>() : bufA.as<float>();
             cd.out = a_out; cd.out2 = L.G.as<float>(); cd.dual_gate = 1;
           }
+          // pairs for the next conv from THIS layer's epilogue (no pool behind it) or from the fused pool kernel below;
+          // their scale comes from a bound that is known now (fwd_scale_kernel), the consumer's unscale with it
+          const bool emit_conv = emit && fused_gate, emit_pool = emit && !top && L.pool_after;
+          if (emit_conv || emit_pool) {
+            hipLaunchKernelGGL(fwd_scale_kernel, dim3(B), dim3(64), 0, st, slots_in, L.fnorm.as<float>(), layers[li + 1].wds.as<float>(),
+                               oscale_of(li), unscale_of(li + 1));
+            LRP_HIP_CHECK(hipGetLastError());
+          }
+          if (emit_conv) { cd.pairs_out = pout; cd.pairs_scale = oscale_of(li); cd.skip_out = keep_acts ? 0 : 1; }
           // The denominators Z+_l of the layers whose reverse launch is two-term (explain(): up to the last pool, >= 576
           // products) are computed two-term as well — with the SAME rounded weights hi(w+) the walk multiplies with.
           // [MI355X: parity at the bench configuration 5.5e-6 -> 4.4e-6, 6 seeds median 4.2e-6 -> 3.3e-6: gate and
@@ -580,12 +644,20 @@ struct Encoder {
           }
           LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2, fterms));
           if (top) break;
+          in_pairs = emit_conv || emit_pool;
+          if (in_pairs) { float* t = pin; pin = pout; pout = t; }
           if (fused_gate) { xin[li + 1] = a_out; continue; }
           if (L.pool_after) {
             const size_t n = (size_t)B * L.act_elems();
-            hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);
-            hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
-                               (float*)nullptr, L.G.as<float>(), B, L.H, L.W, L.cout);
+            if (emit_pool) {
+              // pooled activations as pairs (and fp32 only where the fine-tune step looks for them), arg-max gate: one pass
+              hipLaunchKernelGGL(pool_gate_split_kernel, dim3(stream_grid(n / 32)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
+                                 L.G.as<float>(), pin, keep_acts ? L.P.as<float>() : (float*)nullptr, oscale_of(li), B, L.H, L.W, L.cout);
+            } else {
+              hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);
+              hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
+                                 (float*)nullptr, L.G.as<float>(), B, L.H, L.W, L.cout);
+            }
             LRP_HIP_CHECK(hipGetLastError());
             xin[li + 1] = L.P.as<float>();
           } else {
@@ -598,18 +670,18 @@ struct Encoder {
           // fp32-grade product on the f16 matrix cores: x_l -> fp16 pairs scaled by 2^k (k from the maximum the producer
           // measured), ONE conv pass, the epilogue undoes the scale, adds the bias and measures max|a_l| for the next layer
           const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
-          unsigned* slots_in = act_max.as<unsigned>() + (li - 1) * ACT_MAX_SLOTS;
+          unsigned* slots_in = slots_of(li - 1);
           if (li == 1) {                                // (a_1 comes from the fp32 im2col GEMM, which keeps no maximum)
             hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n8 * 2)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(xin[li]),
                                n8 * 2, slots_in);
           }
           hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8, slots_in,
-                             act_unscale.as<float>() + li, L.wfs.as<float>());
+                             unscale_of(li), L.wfs.as<float>());
           LRP_HIP_CHECK(hipGetLastError());
           ConvArgs c1 = ca;
           c1.in = bufXs.as<float>(); c1.wpk = L.w_fwd_ah.as<float>();
-          c1.in_unscale = act_unscale.as<float>() + li;
-          c1.act_max_out = act_max.as<unsigned>() + li * ACT_MAX_SLOTS;
+          c1.in_unscale = unscale_of(li);
+          c1.act_max_out = slots_of(li);
           LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, c1, st, PREC_F16X2));
         } else if (fwd_x6() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
           // fp32-grade product on the bf16 matrix cores: three-way split operands, two passes (see conv_igemm.h TERMS)
@@ -642,6 +714,29 @@ struct Encoder {
         } else {
           xin[li + 1] = a_out;
         }
+        continue;
+      }
+      if (li == 0 && emit) {
+        // image layer of the dual forward: the fp32 GEMM over the im2col matrix with interleaved (w | w+-) rows — its epilogue
+        // writes the gate G_1, a_1 as the next conv's fp16 pairs (scale from the images' measured maximum) and raises max|a_1|:
+        // no gate / absmax / split pass, a_1 itself only where the fine-tune step looks for it
+        unsigned* img_slots = slots_of(layers.size());
+        hipLaunchKernelGGL(absmax_img_slots_kernel, dim3(64, B), dim3(256), 0, st, images.as<f32x4>(), img_elems / 4, img_slots);
+        hipLaunchKernelGGL(fwd_scale_kernel, dim3(B), dim3(64), 0, st, img_slots, L.fnorm.as<float>(), layers[1].wds.as<float>(), oscale_of(0),
+                           unscale_of(1));
+        LRP_HIP_CHECK(hipGetLastError());
+        ConvArgs c0{};
+        c0.in = a1.as<float>(); c0.NB = B * L.H * L.W; c0.H = 1; c0.W = 1; c0.Cin = 64; c0.CinP = 64; c0.taps = 1;
+        c0.bias = L.bias.as<float>(); c0.wpk = L.w_fwd_il.as<float>(); c0.N = 2 * L.cout; c0.split = L.cout;
+        c0.dual_il = 1; c0.dual_gate = 1;
+        c0.out = keep_acts ? L.Akeep.as<float>() : nullptr; c0.skip_out = keep_acts ? 0 : 1;
+        c0.out2 = L.G.as<float>();
+        c0.pairs_out = pin; c0.pairs_scale = oscale_of(0);
+        c0.act_max_out = slots_of(0);
+        c0.scale_per_img = 1; c0.img_rows = L.H * L.W;
+        LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, c0, st));
+        in_pairs = true;
+        xin[1] = keep_acts ? L.Akeep.as<float>() : nullptr;
         continue;
       }
       if (li == 0) {
