@@ -196,7 +196,7 @@ struct ConvArgs {
   // (row / img_rows; act_max_out[image][ACT_MAX_SLOTS]) instead of one record for the call — an image's rows only ever gather
   // from that image, so a scale per image is as legal as one per call, and the result for an image no longer depends on
   // which other images share its batch.
-  int scale_per_img, img_rows;
+  int scale_per_img, img_rows, n_imgs;
 };
 constexpr int ACT_MAX_SLOTS = 64;
 
@@ -282,6 +282,22 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   };
   const float inv_tw = HALO ? 1.0f / (float)a.tw : 0.f, inv_H = HALO ? 1.0f / (float)a.H : 0.f;
   const float inv_H1 = HALO ? 1.0f / (float)(a.H + 1) : 0.f;
+  // interleaved dual forward: the scale records of the (at most two, for all but tiny images) images this tile's rows belong
+  // to are requested HERE, a main loop ahead of the epilogue that needs them — loaded there, indexed by the row's image,
+  // their latency sat on every tile's critical path [MI355X: the forward convs 7 % slower]
+  int simg0 = 0;
+  float us0 = 1.f, us1 = 1.f, ps0 = 1.f, ps1 = 1.f;
+  if constexpr (EPI == EPI_FWD_DUAL) {
+    if (a.dual_il) {
+      int simg1 = 0;
+      if (a.scale_per_img) {
+        simg0 = HALO ? img0 : m0 / a.img_rows;
+        simg1 = simg0 + 1 < a.n_imgs ? simg0 + 1 : simg0;
+      }
+      if constexpr (PREC == PREC_F16X2) { us0 = a.in_unscale[simg0]; us1 = a.in_unscale[simg1]; }
+      if (a.pairs_out) { ps0 = a.pairs_scale[simg0]; ps1 = a.pairs_scale[simg1]; }
+    }
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -897,20 +913,19 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
           if (ch < a.split) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const int pc = (p & ~63) + (p & 31);          // the c column of the pair; Z+ sits 32 further
-            float unscale = 1.f, omax = 0.f, pscale = 1.f;
-            int cur_img = -1;                             // image whose scales are loaded / whose maximum omax is collecting
+            float omax0 = 0.f, omax1 = 0.f;               // running max|a_l| of this thread's rows of image simg0 / simg0 + 1
             auto max_slot = [&](int img) { return a.act_max_out + (size_t)img * ACT_MAX_SLOTS + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)); };
+            static_assert((RH / RPP) % 4 == 0, "constant, even trip count: the loop holds lane shuffles (no remainder loop)");
 #pragma unroll 2
-            for (int ps = half; ps < RH / RPP; ps += 2) {
-              const int ll = rin + ps * RPP;
+            for (int pi = 0; pi < RH / RPP / 2; ++pi) {
+              const int ll = rin + (half + 2 * pi) * RPP;
               int row, n_, h_, w_;
               if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
-              const int img = !a.scale_per_img ? 0 : HALO ? n_ : row / a.img_rows;
-              if (img != cur_img) {                       // (a tile rarely straddles two images)
-                if (cur_img >= 0 && a.act_max_out && omax > 0.f) atomicMax(max_slot(cur_img), __float_as_uint(omax));
-                cur_img = img; omax = 0.f;
-                if constexpr (PREC == PREC_F16X2) unscale = a.in_unscale[img];
-                if (a.pairs_out) pscale = a.pairs_scale[img];
+              const int rel = (!a.scale_per_img ? 0 : HALO ? n_ : row / a.img_rows) - simg0;
+              float unscale = rel == 0 ? us0 : us1, pscale = rel == 0 ? ps0 : ps1;
+              if (__builtin_expect(rel > 1, 0)) {         // (a tile over three or more images: images smaller than half a tile)
+                if constexpr (PREC == PREC_F16X2) unscale = a.in_unscale[simg0 + rel];
+                if (a.pairs_out) pscale = a.pairs_scale[simg0 + rel];
               }
               f32x4 vc = *reinterpret_cast<const f32x4*>(Cs + ll * BN + pc);
               f32x4 vz = *reinterpret_cast<const f32x4*>(Cs + ll * BN + pc + 32);
@@ -938,14 +953,22 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
                 for (int q = 0; q < 4; ++q) vz[q] = vc[q] / (vz[q] + (vz[q] == 0.f ? 1e-7f : 0.f));
               }
-              if (PREC == PREC_F16X2 || a.act_max_out)
-                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3]))));
+              if (a.act_max_out) {
+                const float m4 = fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3])));
+                if (rel == 0) omax0 = fmaxf(omax0, m4);
+                else if (rel == 1) omax1 = fmaxf(omax1, m4);
+                else if (m4 > 0.f) atomicMax(max_slot(simg0 + rel), __float_as_uint(m4));
+              }
               if (!a.skip_out) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.split + ch) = vc;
               *reinterpret_cast<f32x4*>(a.out2 + (size_t)row * a.split + ch) = vz;
               {
                 if (a.pairs_out) {
-                  // this thread's 4 channels are one half of a split8 group [8 x fp16 hi | 8 x fp16 lo]: two 8-byte stores
+                  // This thread's 4 channels are one half of a split8 group [8 x fp16 hi | 8 x fp16 lo]; the other half sits
+                  // in the neighbouring lane (same row, next channel quad: c4 ^ 1).  The two swap halves so that each issues
+                  // ONE 16-byte store (the even lane the group's hi half, the odd lane its lo half) — as 8-byte stores the
+                  // epilogue was store-issue-bound [MI355X: the forward convs 8-10 % slower].
                   typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                   f16x4 hi, lo;
 #pragma unroll
                   for (int q = 0; q < 4; ++q) {
@@ -953,25 +976,28 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
                     hi[q] = (_Float16)sv;
                     lo[q] = (_Float16)(sv - (float)hi[q]);
                   }
+                  const bool odd = (ch >> 2) & 1;
+                  const u32x2 mine = __builtin_bit_cast(u32x2, odd ? lo : hi);      // what this lane keeps
+                  const u32x2 give = __builtin_bit_cast(u32x2, odd ? hi : lo);      // what the neighbour stores
+                  u32x2 got;
+                  got[0] = __shfl_xor(give[0], 1);
+                  got[1] = __shfl_xor(give[1], 1);
+                  u32x4 v16;
+                  v16[0] = odd ? got[0] : mine[0]; v16[1] = odd ? got[1] : mine[1];     // channels 0-3 of the group first
+                  v16[2] = odd ? mine[0] : got[0]; v16[3] = odd ? mine[1] : got[1];
                   float* grp = a.pairs_out + (size_t)row * a.split + (ch & ~7);
-                  const int hq = (ch >> 2) & 1;
-                  reinterpret_cast<f16x4*>(grp)[hq] = hi;
-                  reinterpret_cast<f16x4*>(grp + 4)[hq] = lo;
+                  *reinterpret_cast<u32x4*>(grp + (odd ? 4 : 0)) = v16;
                 }
               }
             }
             if (a.act_max_out) {                            // (any PREC: the image layer's fp32 GEMM raises its maximum here too)
-              // one atomic per wave when all its lanes ended on the same image (nearly always), one per lane otherwise
-              int iref = cur_img;
 #pragma unroll
-              for (int o = 32; o > 0; o >>= 1) iref = max(iref, __shfl_xor(iref, o));
-              if (__all(cur_img == iref || cur_img < 0)) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
-                if (lane == 0 && omax > 0.f && iref >= 0) atomicMax(max_slot(iref), __float_as_uint(omax));
-              } else if (cur_img >= 0 && omax > 0.f) {
-                atomicMax(max_slot(cur_img), __float_as_uint(omax));
+              for (int o = 32; o > 0; o >>= 1) {
+                omax0 = fmaxf(omax0, __shfl_xor(omax0, o));
+                omax1 = fmaxf(omax1, __shfl_xor(omax1, o));
               }
+              if (lane == 0 && omax0 > 0.f) atomicMax(max_slot(simg0), __float_as_uint(omax0));
+              if (lane == 0 && omax1 > 0.f) atomicMax(max_slot(simg0 + 1), __float_as_uint(omax1));
             }
           }
         } else

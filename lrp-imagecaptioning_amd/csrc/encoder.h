@@ -612,7 +612,7 @@ struct Encoder {
           cd.out = a_out; cd.out2 = top ? ztop.as<float>() : bufZ.as<float>();
           cd.in_unscale = unscale_of(li);
           cd.act_max_out = slots_of(li);
-          cd.scale_per_img = emit ? 1 : 0; cd.img_rows = L.H * L.W;
+          cd.scale_per_img = emit ? 1 : 0; cd.img_rows = L.H * L.W; cd.n_imgs = B;
           cd.dual_il = dual_interleaved(L) ? 1 : 0;
           const bool fused_gate = cd.dual_il && !top && !L.pool_after;
           if (fused_gate) {
@@ -733,7 +733,7 @@ struct Encoder {
         c0.out2 = L.G.as<float>();
         c0.pairs_out = pin; c0.pairs_scale = oscale_of(0);
         c0.act_max_out = slots_of(0);
-        c0.scale_per_img = 1; c0.img_rows = L.H * L.W;
+        c0.scale_per_img = 1; c0.img_rows = L.H * L.W; c0.n_imgs = B;
         LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, c0, st));
         in_pairs = true;
         xin[1] = keep_acts ? L.Akeep.as<float>() : nullptr;
