@@ -81,6 +81,7 @@ struct Encoder {
                            // 1e-4 bar; tests/test_gpu_stress_parity.py), so the default is the three-MFMA split-bf16 walk.
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
   DevBuf out_scale;                   // ... and 2^k of the pairs a layer emits for its consumer (no split pass in between)
+  DevBuf unit_norm;                   // {1, 0}: fwd_scale_kernel's "bound" is then the measured maximum itself (the images' pairs)
   static bool fwd_emit() {            // LRP_FWD_EMIT=0: split passes between the convs as in round 2
     const char* e = getenv("LRP_FWD_EMIT");
     return !e || atoi(e) != 0;
@@ -264,6 +265,8 @@ struct Encoder {
                            L.w_fwd_il.as<float>(), L.cout, K);
         LRP_HIP_CHECK(hipGetLastError());
         LRP_HIP_CHECK(hipStreamSynchronize(nullptr));
+        LRP_TRY(L.w_fwd_h.alloc(pk.size() * sizeof(float), total));
+        LRP_TRY(make_f16_operand(L.w_fwd_il.as<float>(), pk.size(), 0, 0, L.w_fwd_h, L.wds, total, nullptr));
       }
       // backward at the image: tap-expanded channel reduction, 54 = 9 taps x (3 with w+ | 3 with w-)
       // columns, K = cout; the 3x3 shift-and-add happens in img_stencil_kernel.
@@ -391,7 +394,10 @@ struct Encoder {
     if (li == 0) {
       const size_t nb = (size_t)conv_npad(IMG_T_COLS) * conv_cinp(L.cout);
       LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * 64));
-      if (image_layer_interleaved(L)) LRP_TRY(mk(L.w_fwd_il, (size_t)conv_npad(2 * L.cout) * 64));
+      if (image_layer_interleaved(L)) {
+        LRP_TRY(mk(L.w_fwd_il, (size_t)conv_npad(2 * L.cout) * 64));
+        LRP_TRY(mk(L.w_fwd_h, (size_t)conv_npad(2 * L.cout) * 64));
+      }
       LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_h, nb));
       return LRP_OK;
     }
@@ -415,9 +421,11 @@ struct Encoder {
       hipLaunchKernelGGL(pack_image_layer_dev_kernel, dim3((27 * L.cout + 255) / 256), dim3(256), 0, st, w_dev, L.w_fwd.as<float>(),
                          L.w_bwd.as<float>(), L.w_bwd_full.as<float>(), L.cout, Kb);
       const size_t nb = (size_t)Npb * Kb;
-      if (L.w_fwd_il.p)
+      if (L.w_fwd_il.p) {
         hipLaunchKernelGGL(dual_interleave_rows_kernel, dim3(stream_grid((size_t)2 * L.cout * 64)), dim3(256), 0, st, L.w_fwd.as<float>(),
                            L.w_fwd_il.as<float>(), L.cout, 64);
+        LRP_TRY(make_f16_operand(L.w_fwd_il.as<float>(), (size_t)conv_npad(2 * L.cout) * 64, 0, 0, L.w_fwd_h, L.wds, nullptr, st, false));
+      }
       hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(nb / 8)), dim3(256), 0, st, L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb / 8);
       LRP_TRY(make_f16_operand(L.w_bwd.as<float>(), nb, 0, 0, L.w_bwd_h, L.wbs, nullptr, st, false));
       LRP_HIP_CHECK(hipGetLastError());
@@ -531,16 +539,21 @@ struct Encoder {
       // per layer AND image (the emitting forward scales every image by its own maxima; +1 layer: the images themselves)
       LRP_TRY(act_max.alloc((layers.size() + 1) * (size_t)max_images * ACT_MAX_SLOTS * sizeof(unsigned), &dummy));
       LRP_TRY(act_unscale.alloc((layers.size() + 1) * (size_t)max_images * sizeof(float), &dummy));
-      LRP_TRY(out_scale.alloc(layers.size() * (size_t)max_images * sizeof(float), &dummy));
+      LRP_TRY(out_scale.alloc((layers.size() + 1) * (size_t)max_images * sizeof(float), &dummy));   // (+1: the images' own pairs)
+      LRP_TRY(unit_norm.alloc(2 * sizeof(float), &dummy));
+      const float un[2] = {1.f, 0.f};
+      LRP_HIP_CHECK(hipMemcpyAsync(unit_norm.p, un, sizeof(un), hipMemcpyHostToDevice, st));
+      LRP_HIP_CHECK(hipStreamSynchronize(st));           // (first encode only; `un` lives on this stack frame)
     }
     LRP_HIP_CHECK(hipMemsetAsync(act_max.p, 0, act_max.bytes, st));
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, B * img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
-    {
-      const size_t total = (size_t)B * img_h * img_w * 64;
+    auto im2col_fp32 = [&]() -> int {
+      const size_t total = (size_t)B * img_h * img_w * 8;
       hipLaunchKernelGGL(im2col_image_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                          images.as<float>(), a1.as<float>(), B, img_h, img_w);
       LRP_HIP_CHECK(hipGetLastError());
-    }
+      return LRP_OK;
+    };
     float* x = bufX.as<float>();
     float* a = bufA.as<float>();
     float* z = bufZ.as<float>();
@@ -724,22 +737,37 @@ struct Encoder {
         hipLaunchKernelGGL(absmax_img_slots_kernel, dim3(64, B), dim3(256), 0, st, images.as<f32x4>(), img_elems / 4, img_slots);
         hipLaunchKernelGGL(fwd_scale_kernel, dim3(B), dim3(64), 0, st, img_slots, L.fnorm.as<float>(), layers[1].wds.as<float>(), oscale_of(0),
                            unscale_of(1));
+        // the im2col matrix as fp16 pairs (scaled per image by its own maximum) and the GEMM on the f16 MFMA — unless the
+        // fine-tune step is on: its weight gradient of this layer is a product over the fp32 im2col matrix (trainer.h)
+        static const bool l0_f16 = [] { const char* e = getenv("LRP_FWD_L0_F16"); return e && atoi(e) != 0; }();   // opt-in: cnn_kernels.h
+        const bool l0_pairs = l0_f16 && !keep_acts && L.w_fwd_h.p && L.wds.p;
+        if (l0_pairs) {
+          hipLaunchKernelGGL(fwd_scale_kernel, dim3(B), dim3(64), 0, st, img_slots, unit_norm.as<float>(), L.wds.as<float>(),
+                             oscale_of(layers.size()), unscale_of(0));
+          const size_t total = (size_t)B * img_h * img_w * 8;
+          hipLaunchKernelGGL(im2col_image_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, images.as<float>(),
+                             a1.as<float>(), oscale_of(layers.size()), B, img_h, img_w);
+        } else {
+          LRP_TRY(im2col_fp32());
+        }
         LRP_HIP_CHECK(hipGetLastError());
         ConvArgs c0{};
         c0.in = a1.as<float>(); c0.NB = B * L.H * L.W; c0.H = 1; c0.W = 1; c0.Cin = 64; c0.CinP = 64; c0.taps = 1;
-        c0.bias = L.bias.as<float>(); c0.wpk = L.w_fwd_il.as<float>(); c0.N = 2 * L.cout; c0.split = L.cout;
+        c0.bias = L.bias.as<float>(); c0.wpk = l0_pairs ? L.w_fwd_h.as<float>() : L.w_fwd_il.as<float>(); c0.N = 2 * L.cout; c0.split = L.cout;
+        c0.in_unscale = unscale_of(0);
         c0.dual_il = 1; c0.dual_gate = 1;
         c0.out = keep_acts ? L.Akeep.as<float>() : nullptr; c0.skip_out = keep_acts ? 0 : 1;
         c0.out2 = L.G.as<float>();
         c0.pairs_out = pin; c0.pairs_scale = oscale_of(0);
         c0.act_max_out = slots_of(0);
         c0.scale_per_img = 1; c0.img_rows = L.H * L.W; c0.n_imgs = B;
-        LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, c0, st));
+        LRP_HIP_CHECK(l0_pairs ? conv_launch(EPI_FWD_DUAL, c0, st, PREC_F16X2) : conv_launch(EPI_FWD_DUAL, c0, st));
         in_pairs = true;
         xin[1] = keep_acts ? L.Akeep.as<float>() : nullptr;
         continue;
       }
       if (li == 0) {
+        LRP_TRY(im2col_fp32());
         ca.in = a1.as<float>(); ca.NB = B * L.H * L.W; ca.H = 1; ca.W = 1; ca.Cin = 64; ca.CinP = 64; ca.taps = 1;
       } else {
         ca.in = x; ca.NB = B; ca.H = L.H; ca.W = L.W; ca.Cin = L.cin; ca.CinP = conv_cinp(L.cin); ca.taps = 9;
