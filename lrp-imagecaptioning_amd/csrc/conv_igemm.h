@@ -197,6 +197,14 @@ struct ConvArgs {
   // from that image, so a scale per image is as legal as one per call, and the result for an image no longer depends on
   // which other images share its batch.
   int scale_per_img, img_rows, n_imgs;
+  // Compact pool interface (weights-in-registers kernel, PREC_BF16X3, Cin <= 64): the relevance entering this layer came
+  // through a 2x2 max-pool, i.e. S_in[n][y][x][c] = P[n][y/2][x/2][c] * G_up[img(n)][y][x][c] with exactly one non-zero per
+  // window and channel.  Instead of reading that 4x-expanded, 75 %-zero tensor (which its producer would have had to write),
+  // the tile's resident image is BUILT from P (fp32, pooled resolution, written by the producer with gate_none) and the
+  // pool gate of this layer's output (fp32 per image, shared by an image's tokens in L2): `in` is then unused.
+  const float* up2_src;        // P  [NB][H/2][W/2][Cin] fp32
+  const float* up2_gate;       // G_up [images][H][W][Cin] fp32
+  int gate_none;               // EPI_MUL: out = acc (no gate: the consumer applies it, see up2_src)
 };
 constexpr int ACT_MAX_SLOTS = 64;
 
@@ -461,6 +469,59 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   // iteration (48 MFMAs per wave on the 8-wave tile) to land — launching it at the top of iteration kc+1 instead
   // left it half of that, which the HBM / MALL latency of the A rows did not fit into in the bf16x3 mode.
   if constexpr (BREG) {
+    if (PREC == PREC_BF16X3 && a.up2_src) {
+      // compact pool interface: resident image = P (pooled resolution) x pool gate, built here through registers.
+      // item = (LDS row, 8-channel group of the 64 channels); chunk cc = group / 4 goes to LDS buffer cc.
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+      const int items = a.hrows * HALO_PITCH * 8;
+      const int ri0 = a.row2img ? a.row2img[img0 < a.NB ? img0 : a.NB - 1] : img0;
+      const int ri1 = a.row2img ? a.row2img[img0 + 1 < a.NB ? img0 + 1 : a.NB - 1] : img0 + 1;
+      constexpr int UB = 6;                              // items in flight per thread (4 x 16 B loads each): one round for the 128-row tile
+      for (int it0 = tid; it0 < items; it0 += NT * UB) {
+        f32x4 pv[UB][2], gv[UB][2];
+        int dst[UB];
+        bool okv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int item = it0 + u * NT;
+          const int row = item >> 3, cg = item & 7, hy = row / HALO_PITCH, hx = row - hy * HALO_PITCH;
+          const int E = Y0 + img0 - 1 + hy;
+          int n, h;
+          divmod(E < 0 ? 0 : E, a.H + 1, inv_H1, n, h);
+          const int x = x0 - 1 + hx;
+          okv[u] = item < items && E >= 0 && h < a.H && n < a.NB && hx < a.tw + 2 && x >= 0 && x < a.W && cg * 8 < a.Cin;
+          const int swzu = ((hy * a.tw + hx - 1) >> 1) & 7;
+          // hi chunk of group g = cg & 3 is logical chunk 2g, lo chunk 2g + 1; physical = logical ^ swizzle (see set_tap)
+          dst[u] = (cg >> 2) * STAGE + row * LDS_STRIDE + (((2 * (cg & 3)) ^ swzu) << 2);
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          pv[u][0] = pv[u][1] = gv[u][0] = gv[u][1] = z4;
+          if (okv[u]) {
+            const int rel = n - img0;
+            const int img = rel == 0 ? ri0 : rel == 1 ? ri1 : (a.row2img ? a.row2img[n] : n);
+            const float* pp = a.up2_src + (((size_t)n * Hp + (h >> 1)) * Wp + (x >> 1)) * a.Cin + cg * 8;
+            const float* gp = a.up2_gate + (((size_t)img * a.H + h) * a.W + x) * a.Cin + cg * 8;
+            pv[u][0] = *reinterpret_cast<const f32x4*>(pp); pv[u][1] = *reinterpret_cast<const f32x4*>(pp + 4);
+            gv[u][0] = *reinterpret_cast<const f32x4*>(gp); gv[u][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (it0 + u * NT >= items) continue;
+          float r[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { r[e] = pv[u][0][e] * gv[u][0][e]; r[4 + e] = pv[u][1][e] * gv[u][1][e]; }
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            hi[q] = (__bf16)r[q];
+            lo[q] = (__bf16)(r[q] - (float)hi[q]);
+          }
+          // lo sits in the logical chunk next to hi: physical index differs in bit 0 only (the swizzle XORs whole indices)
+          *reinterpret_cast<u32x4*>(smem + dst[u]) = __builtin_bit_cast(u32x4, hi);
+          *reinterpret_cast<u32x4*>(smem + (dst[u] ^ 4)) = __builtin_bit_cast(u32x4, lo);
+        }
+      }
+    } else
     for (int p = wave_s; p < halo_np; p += NW) {         // channel chunks 0 and 1 -> LDS buffers 0 and 1
       fire_halo_piece(prep_halo_piece(p, 0, true), p, 0);
       fire_halo_piece(prep_halo_piece(p, 1, cpt > 1), p, 1);
@@ -1072,10 +1133,12 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
               return a.aux + (((size_t)imgv[ps] * H2 + 2 * hv[ps] + (q >> 1)) * W2 + 2 * wv[ps] + (q & 1)) * a.N + col;
           };
           auto load_gates = [&](Gates& G, int ps) {
+            const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int q = 0; q < UPN; ++q)
 #pragma unroll
-              for (int q4 = 0; q4 < CW / 4; ++q4) G.g[q][q4] = *reinterpret_cast<const f32x4*>(gate_ptr(ps, q) + 4 * q4);
+              for (int q4 = 0; q4 < CW / 4; ++q4)
+                G.g[q][q4] = (EPI == EPI_MUL && a.gate_none) ? one4 : *reinterpret_cast<const f32x4*>(gate_ptr(ps, q) + 4 * q4);
             if constexpr (EPI == EPI_MUL) {
               const size_t go = ((size_t)imgv[ps] * HW + hv[ps] * a.W + wv[ps]) * a.N + col;
 #pragma unroll
@@ -1234,6 +1297,15 @@ inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) 
   return best;
 }
 
+// Would a 3x3 MUL launch with N = n_out, input H x W, take the weights-in-registers kernel?  (Encoder::explain asks before it
+// chooses the compact pool interface, which only that kernel reads.)
+inline bool conv_takes_breg(int n_out, int H, int W, bool have_frag) {
+  static const int breg = [] { const char* e = getenv("LRP_CONV_BREG"); return e ? atoi(e) : 1; }();
+  if (!breg || !have_frag || conv_halo_mode() <= 0 || n_out > 64 || n_out <= 32) return false;
+  int tw, th, hrows;
+  return conv_halo_geom(128, H, W, tw, th, hrows) >= 0.9f;
+}
+
 // device table of a.order for this call's token -> image map (see TileOrder); nullptr when the stack order is as good
 inline const int* conv_tile_order(const ConvArgs& a, hipStream_t st) {
   static const int on = [] { const char* e = getenv("LRP_TILE_ORDER"); return e ? atoi(e) : 1; }();
@@ -1366,11 +1438,13 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
           a.tile_map = conv_tile_order(a, st);
+          if (a.up2_src && (PREC != PREC_BF16X3 || a.CinP > 64 || !a.up2_gate || (a.H & 1) || (a.W & 1))) return hipErrorInvalidValue;
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true, TERMS>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }
       }
     }
+    if (a.up2_src) return hipErrorInvalidValue;          // the compact pool interface exists for the weights-in-registers kernel only
     if (a.taps == 9 && mode > 0 && (t.BN >= 128 || (mode == 2 && t.BN >= 64)) && wide != 128) {
       const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
       if (u >= 0.9f || (mode == 2 && u > 0.f)) {

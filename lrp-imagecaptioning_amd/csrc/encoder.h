@@ -927,6 +927,14 @@ struct Encoder {
                          reinterpret_cast<f32x4*>(S), n, per4);
       LRP_HIP_CHECK(hipGetLastError());
     }
+    // Compact pool interface (conv_igemm.h ConvArgs::up2_src): where the consumer of a pooled boundary runs on the
+    // weights-in-registers kernel (VGG16: block2_conv1 -> pool -> block1_conv2, the 4.1 GB interface), the producer writes
+    // its plain fp32 product at POOLED resolution and the consumer builds S = P x gate itself: the 4x-expanded, 75 %-zero
+    // tensor is neither written nor read [MI355X, same box: block2_conv1 2.19 -> 1.48 ms (its store stream shrinks 4x, no gate
+    // loads), block1_conv2 3.87 -> 4.14 ms (its prologue now multiplies and splits in registers instead of a plain LDS-DMA),
+    // walk 26.3 -> 25.7-25.9 ms; heat-map parity unchanged].  LRP_UP2_COMPACT=0 disables.
+    static const bool up2_on = [] { const char* e = getenv("LRP_UP2_COMPACT"); return !e || atoi(e) != 0; }();
+    bool compact_in = false;                             // S (the current layer's input) is in the compact form
     for (int li = (int)layers.size() - 1; li >= 0; --li) {
       const ConvLayer& L = layers[li];
       if (layer_hook) {
@@ -969,6 +977,16 @@ struct Encoder {
         const ConvLayer& P = layers[li - 1];
         ca.N = L.cin; ca.aux = P.G.as<float>(); ca.out = Snext;
         epi = P.pool_after ? EPI_MUL_UP2 : EPI_MUL;
+        if (compact_in) {                                 // this layer reads the compact form its producer left
+          ca.up2_src = S; ca.up2_gate = L.G.as<float>();     // (ca.in = S stays a valid pointer; it is not read)
+          compact_in = false;
+        }
+        // does THIS launch write the compact form?  Its consumer is layer li - 1 (N = P.cin, at 2x this resolution)
+        if (P.pool_after && up2_on && split && !f16 && walk == 0 && !layer_hook && li >= 2 && P.cin <= 64 && conv_cinp(P.cout) <= 64 &&
+            !(P.cout & 7) && conv_takes_breg(P.cin, P.H, P.W, P.w_bwd_frag.p != nullptr)) {
+          epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
+          compact_in = true;
+        }
       }
       ProfileRec pr{};
       if (profile) {
