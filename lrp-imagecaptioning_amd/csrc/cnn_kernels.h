@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void split3_copy_kernel(const float* __restric
 //   bwd = 0: row = output channel, k = tap * CP + ci       (dual: rows [Cout, 2 Cout) hold w+ of row - Cout)
 //   bwd = 1: row = input channel,  k = tap' * CP + co with the taps flipped (transposed conv as a conv)
 __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restrict__ w, float* __restrict__ dst, int bwd, int Cin,
-                                                            int Cout, int CP, int rows_total, int dual, int pos_only) {
-  const int K = 9 * CP;
+                                                            int Cout, int CP, int rows_total, int dual, int pos_only, int taps = 9) {
+  const int K = taps * CP;
   const size_t total = (size_t)rows_total * K;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     int row = (int)(i / K);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void pack_conv_dev_kernel(const float* __restr
       if (dual && row >= Cout) { row -= Cout; pos = true; }
       if (row < Cout && c < Cin) v = w[((size_t)t * Cin + c) * Cout + row];
     } else {
-      if (row < Cin && c < Cout) v = w[((size_t)(8 - t) * Cin + row) * Cout + c];
+      if (row < Cin && c < Cout) v = w[((size_t)(taps - 1 - t) * Cin + row) * Cout + c];
     }
     dst[i] = (pos && !(v >= 0.f)) ? 0.f : v;
   }

@@ -208,13 +208,10 @@ int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev, i
       return h->dec.set_weight_dev(nm, data_dev, ndim, shape, &h->ws_bytes, st);
     }
     if (h->dec.known_weight(nm)) return h->dec.set_weight_dev(nm, data_dev, ndim, shape, &h->ws_bytes, st);
-    // ResNet encoder units (conv + BatchNorm folding is a host packer): staged through the host, once per weight
-    size_t n = 1;
-    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-    std::vector<float> host(n);
-    LRP_HIP_CHECK(hipMemcpyAsync(host.data(), data_dev, n * sizeof(float), hipMemcpyDeviceToHost, st));
-    LRP_HIP_CHECK(hipStreamSynchronize(st));
-    return set_weight_host(h, name, host.data(), ndim, shape);
+    // ResNet encoder units: packed on the device as well (resnet_encoder.h pack_unit_dev)
+    const int rc = h->rn.set_weight_dev(nm, data_dev, ndim, shape, &h->ws_bytes, st);
+    if (rc != 1) return rc;
+    return fail(LRP_ERR_INVALID, "unknown weight '%s'", name);
   });
 }
 

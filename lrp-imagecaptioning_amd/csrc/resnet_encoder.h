@@ -156,6 +156,98 @@ struct ResNetEncoder {
     return 1;
   }
 
+  // lrp_set_weight_dev for the encoder units: the array is already in HBM (RCCL broadcast); vectors are D2D copies, kernels
+  // are packed by device kernels — no device-to-host copy, no stream synchronisation.  Returns 1 if the name is not ours.
+  DevBuf pack_tmp, raw_tmp;                              // largest interleaved dual matrix / largest HWIO kernel of any unit
+  int set_weight_dev(const std::string& nm, const float* data_dev, int ndim, const int64_t* shape, int64_t* total, hipStream_t st) {
+    static const char* suf[6] = {"_conv_W", "_conv_b", "_bn_gamma", "_bn_beta", "_bn_mean", "_bn_var"};
+    for (int s = 0; s < 6; ++s) {
+      const std::string sf(suf[s]);
+      if (nm.size() <= sf.size() || nm.compare(nm.size() - sf.size(), sf.size(), sf) != 0) continue;
+      const int ui = find_unit(nm.substr(0, nm.size() - sf.size()));
+      if (ui < 0) return 1;
+      RnUnit& u = units[ui];
+      if (s == 0) {
+        if (ndim != 4 || shape[0] != u.k || shape[1] != u.k || shape[2] != u.cin || shape[3] != u.cout)
+          return fail(LRP_ERR_INVALID, "%s: expected HWIO (%d,%d,%d,%d)", nm.c_str(), u.k, u.k, u.cin, u.cout);
+        // own copy first: the packers run asynchronously, the caller's buffer need not outlive this call
+        if (!raw_tmp.p) {
+          size_t mx = 0, mxd = 0;
+          for (const RnUnit& q : units) {
+            mx = std::max(mx, (size_t)q.k * q.k * q.cin * q.cout);
+            mxd = std::max(mxd, (size_t)conv_npad(2 * q.cout) * q.k * q.k * conv_cinp(q.cin));
+          }
+          LRP_TRY(raw_tmp.alloc(mx * 4, total));
+          LRP_TRY(pack_tmp.alloc(mxd * 4, total));
+        }
+        const size_t nW = (size_t)u.k * u.k * u.cin * u.cout;
+        LRP_HIP_CHECK(hipMemcpyAsync(raw_tmp.p, data_dev, nW * 4, hipMemcpyDeviceToDevice, st));
+        LRP_TRY(pack_unit_dev(u, raw_tmp.as<float>(), total, st));
+      } else {
+        if (ndim != 1 || shape[0] != u.cout) return fail(LRP_ERR_INVALID, "%s: expected (%d,)", nm.c_str(), u.cout);
+        DevBuf* dst[6] = {nullptr, &u.bias, &u.gamma, &u.beta, &u.mean, &u.var};
+        if (!dst[s]->p || dst[s]->bytes != (size_t)u.cout * 4) LRP_TRY(dst[s]->alloc((size_t)u.cout * 4, total));
+        LRP_HIP_CHECK(hipMemcpyAsync(dst[s]->p, data_dev, (size_t)u.cout * 4, hipMemcpyDeviceToDevice, st));
+      }
+      u.have[s] = true;
+      encoded = 0;                                       // caches belong to the old weights
+      return LRP_OK;
+    }
+    return 1;
+  }
+  int pack_unit_dev(RnUnit& u, const float* w_dev, int64_t* total, hipStream_t st) {
+    auto mk = [&](DevBuf& d, size_t floats) -> int {
+      if (d.p && d.bytes == floats * 4) return LRP_OK;
+      return d.alloc(floats * 4, total);
+    };
+    auto split = [&](const float* src, float* dst, size_t n) {
+      hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n / 8)), dim3(256), 0, st, src, dst, n / 8);
+    };
+    if (u.k == 7) {
+      const int Np = conv_npad(u.cout), K = 2 * RN_STEM_K, Npb = conv_npad(RN_STEM_TCOLS), Kb = conv_cinp(u.cout);
+      LRP_TRY(mk(u.w_a, (size_t)Np * K)); LRP_TRY(mk(u.w_z, (size_t)Np * K)); LRP_TRY(mk(u.w_b, (size_t)Npb * Kb));
+      hipLaunchKernelGGL(rn_pack_stem_dev_kernel, dim3(stream_grid((size_t)Np * K + (size_t)Npb * Kb)), dim3(256), 0, st, w_dev,
+                         u.w_a.as<float>(), u.w_z.as<float>(), u.w_b.as<float>(), u.cout, Np, Npb, Kb);
+      if (!(u.cout & 7)) {
+        LRP_TRY(mk(u.w_bs, (size_t)Npb * Kb));
+        split(u.w_b.as<float>(), u.w_bs.as<float>(), (size_t)Npb * Kb);
+      }
+      LRP_HIP_CHECK(hipGetLastError());
+      return LRP_OK;
+    }
+    const int taps = u.k * u.k, CPi = conv_cinp(u.cin), CPo = conv_cinp(u.cout);
+    const int Np = conv_npad(u.cout), Npb = conv_npad(u.cin);
+    const size_t nf = (size_t)Np * taps * CPi, nb = (size_t)Npb * taps * CPo;
+    auto pack = [&](float* dst, int bwd, int rows, int dual, int pos) {
+      const size_t tot = (size_t)rows * taps * (bwd ? CPo : CPi);
+      hipLaunchKernelGGL(pack_conv_dev_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, w_dev, dst, bwd, u.cin, u.cout, bwd ? CPo : CPi,
+                         rows, dual, pos, taps);
+    };
+    LRP_TRY(mk(u.w_a, nf)); LRP_TRY(mk(u.w_z, nf));
+    pack(u.w_a.as<float>(), 0, Np, 0, 0);
+    pack(u.w_z.as<float>(), 0, Np, 0, 1);                // inputs are post-ReLU: Z = conv(x, w+) + b
+    if (!(u.cout & 3)) {
+      const int Nd = conv_npad(2 * u.cout);
+      const size_t nd = (size_t)Nd * taps * CPi;
+      LRP_TRY(mk(u.w_dual, nd));
+      pack(u.w_dual.as<float>(), 0, Nd, 1, 0);
+      if (!(u.cin & 7)) {
+        u.dual_il = fwd_il() && !(u.cout & 31) && Nd == 2 * u.cout;
+        const float* src = u.w_dual.as<float>();
+        if (u.dual_il) {                                  // rows in blocks of 32: [w | w+] of the same 32 channels
+          pack(pack_tmp.as<float>(), 0, Nd, 2, 0);
+          src = pack_tmp.as<float>();
+        }
+        LRP_TRY(make_f16_operand(f16_slots, src, nd, 0, 0, u.w_dual_h, u.wds, total, st, false));
+      }
+    }
+    LRP_TRY(mk(u.w_b, nb)); LRP_TRY(mk(u.w_bs, nb));
+    pack(u.w_b.as<float>(), 1, Npb, 0, 1);
+    split(u.w_b.as<float>(), u.w_bs.as<float>(), nb);
+    LRP_HIP_CHECK(hipGetLastError());
+    return LRP_OK;
+  }
+
   int pack_unit(RnUnit& u, const float* w, int64_t* total) {
     const size_t nW = (size_t)u.k * u.k * u.cin * u.cout;
     std::vector<float> wp(nW), wn(nW), pk;

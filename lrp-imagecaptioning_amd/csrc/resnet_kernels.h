@@ -266,6 +266,36 @@ __global__ __launch_bounds__(256) void rn_stem_im2col_kernel(const float* __rest
 // Stem reverse: T[q][tap*6 + c] = sum_co S[q][co] w+[tap][c][co] (c<3) / w-[..] (c>=3) came from one K = C_stem GEMM;
 // R_img[p][c] = x+[p][c] * sum_{tap} T+[q(p,tap)][tap][c] + x-[p][c] * sum T-[...],  q = ((i+3-kh)/2, (j+3-kw)/2) when integral
 constexpr int RN_STEM_TCOLS = 294;
+
+// Device twin of RnEncoder::pack_unit's stem branch (lrp_set_weight_dev: the weights arrive in HBM and stay there).
+// w: HWIO (7,7,3,cout).  wa / wz [Np][2 * RN_STEM_K]: a rows hold w against the x+ and the x- patch, z rows w+ / w-;
+// wb [Npb][Kb]: row t*6 + c = w+[t][c][:], row t*6 + 3 + c = w-[t][c][:] (the tap GEMM of the walk).  All zero padded.
+__global__ __launch_bounds__(256) void rn_pack_stem_dev_kernel(const float* __restrict__ w, float* __restrict__ wa, float* __restrict__ wz,
+                                                               float* __restrict__ wb, int cout, int Np, int Npb, int Kb) {
+  const int K = 2 * RN_STEM_K;
+  const size_t nf = (size_t)Np * K, nb = (size_t)Npb * Kb;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf + nb; i += (size_t)gridDim.x * 256) {
+    if (i < nf) {
+      const int co = (int)(i / K), k = (int)(i % K), kk = k % RN_STEM_K, neg = k / RN_STEM_K;
+      float va = 0.f, vz = 0.f;
+      if (co < cout && kk < 147) {
+        const float v = w[(size_t)kk * cout + co];
+        va = v;
+        vz = neg ? (v < 0.f ? v : 0.f) : (v >= 0.f ? v : 0.f);
+      }
+      wa[i] = va; wz[i] = vz;
+    } else {
+      const size_t q = i - nf;
+      const int row = (int)(q / Kb), co = (int)(q % Kb), t = row / 6, c6 = row % 6, c = c6 % 3;
+      float v = 0.f;
+      if (t < 49 && co < cout) {
+        const float x = w[((size_t)t * 3 + c) * cout + co];
+        v = c6 < 3 ? (x >= 0.f ? x : 0.f) : (x < 0.f ? x : 0.f);
+      }
+      wb[q] = v;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void rn_stem_stencil_kernel(const float* __restrict__ T, const float* __restrict__ ximg,
                                                               const int* __restrict__ row2img, float* __restrict__ out,
                                                               int ntok, int H, int W) {

@@ -22,10 +22,11 @@ def agg(path, key_len=120):
     return out, {k: len(v) for k, v in n.items()}
 
 
-def main(tag):
+def main(tag, suffix=""):
+    """suffix: appended to the output names, e.g. "_bf16x3" (bench.py's fallback looks for r*_pmc_summary_<precision>.json)"""
     here = os.path.dirname(os.path.abspath(__file__))
     src = os.path.join(os.path.dirname(here), "gpurun_out", "prof_" + tag)
-    shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "trace", "t_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats" + suffix + ".csv"))
     summ = {}
     sq, nsq = agg(os.path.join(src, "pmc_sq", "p_counter_collection.csv"))
     fe, nfe = agg(os.path.join(src, "pmc_fetch", "p_counter_collection.csv"))
@@ -53,9 +54,9 @@ def main(tag):
         if k in wr:
             d["write_bytes_per_launch"] = round(wr[k]["WRITE_SIZE"] * 1024 / nwr[k])
         summ[k] = d
-    json.dump(summ, open(os.path.join(here, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
+    json.dump(summ, open(os.path.join(here, tag + "_pmc_summary" + suffix + ".json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1, sort_keys=True)[:3000])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r02")
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03", sys.argv[2] if len(sys.argv) > 2 else "")

@@ -141,3 +141,39 @@ def test_resnet_handle_takes_weights_from_device():
         eng.decoder_forward([cap])
         outs.append([t.clone() for t in eng.explain_tokens([0, 0, 0], [1, 2, 3], want_R_feat=True)[:2]])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("stacks,stem,hw", [(((8, 2), (16, 3), (32, 2)), 16, 64), (((32, 2), (64, 2)), 32, 64)])
+def test_resnet_weights_set_from_device_match_host_set(stacks, stem, hw):
+    """lrp_set_weight_dev for the ResNet encoder (the multi-GPU start-up path: conv kernels, the 7x7 stem's three matrices,
+    BatchNorm vectors packed by device kernels — resnet_encoder.h pack_unit_dev; no device-to-host copy): features and
+    heat-maps bit-identical to the host-set handle, in both arithmetic modes; a second device set replaces the operands.
+    (The second geometry has widths % 32 == 0: the interleaved fp16-pair dual matrices.)"""
+    import torch
+    rs = np.random.RandomState(8)
+    w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
+    H, V = 32, 50
+    side = hw // 4 // (2 ** (len(stacks) - 1))
+    w.update(gridtd_weights(rs, side * side, 4 * stacks[-1][0], H, H, V))
+    X = rs.uniform(-120, 130, size=(2, hw, hw, 3)).astype(np.float32)
+    host, side, D = _engine(stacks, stem, hw, 2, 4, w)
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    dev = LRPEngine(decoder="gridtd", img_hw=(hw, hw), L=side * side, D=D, H=H, E=H, V=V, max_images=2, max_tokens=4,
+                    max_caption_len=6, resnet={"stem": stem, "stacks": stacks})
+    dev.set_weights_from_device({k: torch.as_tensor(v).cuda() for k, v in w.items()})
+    R = rs.standard_normal((4, side * side, D)).astype(np.float32)
+
+    def run(eng, prec):
+        eng.set_precision(prec)
+        eng.encode_images(X)
+        return eng.get_features().clone(), eng.cnn_explain([0, 1, 1, 0], R).clone()
+    for prec in ("bf16x3", "fp32"):
+        fh, oh = run(host, prec)
+        fd, od = run(dev, prec)
+        assert torch.equal(fd, fh) and torch.equal(od, oh), prec
+    w2 = {k: (v * 1.25).astype(np.float32) if k.endswith("_conv_W") else v for k, v in w.items()}
+    dev.set_weights_from_device({k: torch.as_tensor(v).cuda() for k, v in w2.items() if k.endswith("_conv_W")})
+    host.set_weights({k: v for k, v in w2.items() if k.endswith("_conv_W")})
+    fh, oh = run(host, "bf16x3")
+    fd, od = run(dev, "bf16x3")
+    assert torch.equal(fd, fh) and torch.equal(od, oh) and not torch.equal(od, run(host, "fp32")[1])
