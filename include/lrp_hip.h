@@ -111,8 +111,10 @@ int lrp_set_weight(lrp_handle* h, const char* name, const float* data_host,
                    int32_t ndim, const int64_t* shape);
 /* Same, from device memory on rank-local HBM (used after an RCCL broadcast).  ABI v3: packed by device kernels — a
  * device-to-device copy of the array plus the pack / split kernels on `stream`; no host round trip and no stream
- * synchronisation (only ResNet encoder units, whose conv + BatchNorm folding is a host packer, are staged through
- * the host).  Host-set and device-set weights may be mixed; the last setter of a name wins. */
+ * synchronisation, for the conv-list (VGG) encoder, both decoders and (ABI v4) the ResNet encoder's units
+ * ("<unit>_conv_W/_conv_b/_bn_gamma/_bn_beta/_bn_mean/_bn_var") alike.  The caller's buffer is copied before the call
+ * returns control to the stream's next work, so it may be released (stream-ordered) right after.  Host-set and device-set
+ * weights may be mixed; the last setter of a name wins. */
 int lrp_set_weight_dev(lrp_handle* h, const char* name, const float* data_dev,
                        int32_t ndim, const int64_t* shape, void* stream);
 
