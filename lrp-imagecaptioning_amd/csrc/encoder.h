@@ -209,6 +209,15 @@ struct Encoder {
     }
     LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_fwd, hipEventDisableTiming));
     LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_gates, hipEventDisableTiming));
+    // scale records of the fp16-pair forward, per layer AND image (the emitting forward scales every image by its own
+    // maxima; +1 level: the images themselves)
+    LRP_TRY(act_max.alloc((layers.size() + 1) * B * ACT_MAX_SLOTS * sizeof(unsigned), total));
+    LRP_TRY(act_unscale.alloc((layers.size() + 1) * B * sizeof(float), total));
+    LRP_TRY(out_scale.alloc((layers.size() + 1) * B * sizeof(float), total));
+    LRP_TRY(unit_norm.alloc(2 * sizeof(float), total));
+    const float un[2] = {1.f, 0.f};
+    LRP_HIP_CHECK(hipMemcpy(unit_norm.p, un, sizeof(un), hipMemcpyHostToDevice));
+    for (ConvLayer& L : layers) LRP_TRY(L.fnorm.alloc(2 * sizeof(float), total));
     return LRP_OK;
   }
 
@@ -534,17 +543,6 @@ struct Encoder {
       LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));
       gates_pending = false;
     }
-    if (!act_max.p) {
-      int64_t dummy = 0;
-      // per layer AND image (the emitting forward scales every image by its own maxima; +1 layer: the images themselves)
-      LRP_TRY(act_max.alloc((layers.size() + 1) * (size_t)max_images * ACT_MAX_SLOTS * sizeof(unsigned), &dummy));
-      LRP_TRY(act_unscale.alloc((layers.size() + 1) * (size_t)max_images * sizeof(float), &dummy));
-      LRP_TRY(out_scale.alloc((layers.size() + 1) * (size_t)max_images * sizeof(float), &dummy));   // (+1: the images' own pairs)
-      LRP_TRY(unit_norm.alloc(2 * sizeof(float), &dummy));
-      const float un[2] = {1.f, 0.f};
-      LRP_HIP_CHECK(hipMemcpyAsync(unit_norm.p, un, sizeof(un), hipMemcpyHostToDevice, st));
-      LRP_HIP_CHECK(hipStreamSynchronize(st));           // (first encode only; `un` lives on this stack frame)
-    }
     LRP_HIP_CHECK(hipMemsetAsync(act_max.p, 0, act_max.bytes, st));
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, B * img_elems * sizeof(float), hipMemcpyDeviceToDevice, st));
     auto im2col_fp32 = [&]() -> int {
@@ -582,7 +580,6 @@ struct Encoder {
       for (size_t li = 0; li < layers.size(); ++li) {
         ConvLayer& L = layers[li];
         if (!L.norm_dirty) continue;
-        if (!L.fnorm.p) { int64_t dummy = 0; LRP_TRY(L.fnorm.alloc(2 * sizeof(float), &dummy)); }
         LRP_HIP_CHECK(hipMemsetAsync(L.fnorm.p, 0, 2 * sizeof(float), st));
         // (image layer: the a rows of its 64-wide im2col matrix hold w twice, against x+ and x-: the row sum is 2x the bound)
         hipLaunchKernelGGL(conv_norm_kernel, dim3(L.cout + 1), dim3(256), 0, st, li == 0 ? L.w_fwd.as<float>() : L.w_fwd_a.as<float>(), L.cout,

@@ -207,3 +207,26 @@ def test_gradient_walk_is_the_true_gradient():
             y = F.max_pool2d(y, 2, 2)
     (g,) = torch.autograd.grad(y, xt, grad_outputs=torch.as_tensor(head).permute(0, 3, 1, 2))
     np.testing.assert_allclose(C.gradient_analyze(layers, X, head, "gradient"), g.permute(0, 2, 3, 1).numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_trained_like_generator_makes_what_the_stress_tests_rely_on():
+    """synthetic.vgg_weights_trained_like (the weights of tests/test_gpu_stress_parity.py): sparse heavy-tailed kernels,
+    ~80 % dead activations per conv, unit activation scale — checked on a small net with the float64 forward of the oracle."""
+    from lrp_imagecaptioning_amd.synthetic import vgg_weights_trained_like
+    cfg = [("c1", 3, 16, False), ("c2", 16, 16, True), ("c3", 16, 32, False), ("c4", 32, 32, False)]
+    rs = np.random.RandomState(4)
+    X = (rs.uniform(0, 255, size=(1, 32, 32, 3)) - 110).astype(np.float32)
+    w = vgg_weights_trained_like(np.random.RandomState(5), cfg, density=0.1, sigma=1.5, active_frac=0.2, calib_image=X)
+    for name, cin, cout, _ in cfg[1:]:
+        k = w[name + "_W"]
+        assert 0.03 < float((k != 0).mean()) < 0.2
+        nz = np.abs(k[k != 0])
+        assert nz.max() / np.median(nz) > 10                  # heavy tail
+    layers = C.vgg_layers(w, cfg)
+    feat, inputs = C.forward(layers, X, return_inputs=True)
+    for i in range(1, len(layers)):
+        if layers[i - 1][0] == "conv":
+            a = inputs[i].numpy()
+            assert 0.1 < float((a > 0).mean()) < 0.3          # calibrated in float32, evaluated in float64: ~20 % active
+            assert 0.5 < float(np.sqrt((a ** 2).mean())) < 2.0
+    assert np.isfinite(feat).all() and (feat > 0).any()
