@@ -191,6 +191,8 @@ PREC_TEMPLATE_ARG = {"fp32": "0", "bf16x3": "1", "bf16x3_fast": "1", "f16x2": "2
 
 def is_walk_kernel(name, precision):
     """reverse-walk launches: epilogues MUL(2) / MUL_UP2(3) / STORE(5) / fused image layer (6) in the walk's arithmetic"""
+    if "img_partial_sum_kernel" in name:                       # second half of the image layer when it is folded into block1_conv2
+        return precision in ("bf16x3", "bf16x3_fast")
     m = WALK_KERNEL_RE.search(name)
     return bool(m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == PREC_TEMPLATE_ARG[precision])
 

@@ -582,6 +582,45 @@ __global__ __launch_bounds__(256) void img_stencil_kernel(const float* __restric
   }
 }
 
+// Second half of the image layer when it is folded into the epilogue of the layer above it (conv_igemm.h ConvArgs::img_part):
+// every tile of that launch left, for its (th + 2) x (tw + 2) ring-inclusive output positions, the six partial sums
+// (3 x "+", 3 x "-") over the source pixels it owns.  An output pixel adds the partials of the up to four tiles whose ring
+// covers it — in a FIXED order (tile row, then tile column), the same for every token and every batch — and applies
+//   R_img = x+ * sum+  +  x- * sum-      (RR:274-322 at the image; mode 1 / 2: plain gradient / input x gradient).
+__global__ __launch_bounds__(256) void img_partial_sum_kernel(const float* __restrict__ part, const float* __restrict__ ximg,
+                                                              const int* __restrict__ row2img, float* __restrict__ out, int n, int H, int W,
+                                                              int th, int tw, int cols_t, int mode) {
+  const size_t total = (size_t)n * H * W;
+  const int RW = tw + 2, npos = (th + 2) * RW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int HW = H * W;
+    const int t = (int)(i / HW), pix = (int)(i - (size_t)t * HW);
+    const int h = pix / W, w = pix - h * W;
+    const int Y = t * H + h, tyt0 = Y / th, txt0 = w / tw, hm = h % th, wm = w % tw;
+    const int ty_lo = (hm == 0 && h > 0) ? tyt0 - 1 : tyt0, ty_hi = (hm == th - 1 && h + 1 < H) ? tyt0 + 1 : tyt0;
+    const int tx_lo = (wm == 0 && w > 0) ? txt0 - 1 : txt0, tx_hi = (wm == tw - 1 && txt0 + 1 < cols_t) ? txt0 + 1 : txt0;
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int ty = ty_lo; ty <= ty_hi; ++ty)
+      for (int tx = tx_lo; tx <= tx_hi; ++tx) {
+        const int p = (Y - ty * th + 1) * RW + (w - tx * tw + 1);
+        const float* r = part + (((size_t)ty * cols_t + tx) * npos + p) * 6;
+        const float2 a = *reinterpret_cast<const float2*>(r);
+        const float2 b = *reinterpret_cast<const float2*>(r + 2);
+        const float2 c = *reinterpret_cast<const float2*>(r + 4);
+        s[0] += a.x; s[1] += a.y; s[2] += b.x; s[3] += b.y; s[4] += c.x; s[5] += c.y;
+      }
+    const int img = row2img ? row2img[t] : t;
+    const float* x = ximg + ((size_t)img * HW + pix) * 3;
+    float* o = out + i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (mode == 0) o[c] = x[c] >= 0.f ? x[c] * s[c] : x[c] * s[3 + c];
+      else if (mode == 1) o[c] = s[c] + s[3 + c];
+      else o[c] = x[c] * (s[c] + s[3 + c]);
+    }
+  }
+}
+
 // Head of the gradient walks: the cut is AFTER block5_conv3's ReLU, so the head tensor first passes that ReLU's
 // backward: S_top = R * [feat > 0]  (guided backprop: max(R, 0) * [feat > 0], gradient_based.py:228-234)
 __global__ __launch_bounds__(256) void grad_top_kernel(const f32x4* __restrict__ R, const f32x4* __restrict__ feat,

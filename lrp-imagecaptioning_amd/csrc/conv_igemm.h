@@ -205,7 +205,17 @@ struct ConvArgs {
   const float* up2_src;        // P  [NB][H/2][W/2][Cin] fp32
   const float* up2_gate;       // G_up [images][H][W][Cin] fp32
   int gate_none;               // EPI_MUL: out = acc (no gate: the consumer applies it, see up2_src)
+  // Image layer folded into the epilogue of the layer above it (weights-in-registers kernel, PREC_BF16X3, N = 64, EPI_MUL):
+  // S_1 = acc x gate never goes to memory.  The tile turns it into bf16 pairs in LDS, multiplies it with the tap-expanded
+  // 64 -> 54 matrix `img_w` (the image layer's T = S_1 . W, cnn_kernels.h) and applies the 9-tap shift-and-add for the
+  // SOURCE pixels it owns: per tile (th + 2) x (tw + 2) output positions (its pixels and the one-pixel ring around them)
+  // x 6 partial sums go to img_part[tile of the stack][position][6]; img_partial_sum_kernel adds the up to four tiles'
+  // partials of a pixel in a fixed order and applies x+ / x-.  Needs th | H (tiles do not straddle tokens, so the
+  // grouping of a pixel's nine taps into partials is the same for every token: results stay batch-invariant bit for bit).
+  const float* img_w;          // [64][64] split8 bf16 pairs (layer 0's backward matrix)
+  float* img_part;
 };
+constexpr int IMGF_TH = 8;     // tile rows of the fused launch (224 = 28 x 8)
 constexpr int ACT_MAX_SLOTS = 64;
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -816,6 +826,140 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
+  }
+
+  // ---- image layer folded into this layer's epilogue (ConvArgs::img_part)
+  if constexpr (BREG && EPI == EPI_MUL && PREC == PREC_BF16X3 && TM == 2 && TN == 1 && WM == 2 && WN == 2) {
+    if (a.img_part) {
+      static_assert(2 * STAGE >= 64 * 64 + 2 * 128 * 32 && 2 * STAGE >= 128 * 57, "Cs slab + A2, then T, inside the staging LDS");
+      constexpr int TS2 = 57;                             // T row stride (54 used; odd: conflict-free column reads)
+      float* Cs = smem;                                   // [64 rows][64] fp32: one row slab of the C tile at a time
+      float* A2 = smem + 64 * 64;                         // [2 chunks][128 rows][32 floats]: S_1 as split8 pairs, swizzled like an A tile
+      const float inv_tw2 = 1.0f / (float)a.tw;
+      // everything this epilogue needs from global memory is requested up front — the gates of this thread's four
+      // (row, channel group) items and this wave's fragments of the tap matrix — so that the latencies overlap each other
+      // and the LDS passes below instead of sitting between them
+      f32x4 gq[4][2];
+      bool gok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {                       // k = 2 * slab + u
+        const int item = tid + (k & 1) * NT, row = (k >> 1) * 64 + (item >> 3), g = item & 7;
+        int ty, tx;
+        divmod(row, a.tw, inv_tw2, ty, tx);
+        const int Y = Y0 + ty, w = x0 + tx;
+        gok[k] = row < a.th * a.tw && Y < a.nyh && w < a.W;
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        gq[k][0] = gq[k][1] = z4;
+        if (gok[k]) {
+          int n, h;
+          divmod(Y, a.H, inv_H, n, h);
+          const int img = a.row2img ? a.row2img[n] : n;
+          const float* gp = a.aux + ((size_t)img * HW + h * a.W + w) * a.N + g * 8;
+          gq[k][0] = *reinterpret_cast<const f32x4*>(gp); gq[k][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+        }
+      }
+      u32x4 wq[2][2][2][2];                               // [chunk][step][hi|lo][n tile]
+      {
+        const int h2 = lane >> 5;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int hl = 0; hl < 2; ++hl)
+#pragma unroll
+              for (int j = 0; j < 2; ++j)
+                wq[cc][st][hl][j] = *reinterpret_cast<const u32x4*>(a.img_w + (size_t)(j * 32 + (lane & 31)) * 64 + cc * 32 + (4 * st + 2 * h2 + hl) * 4);
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        if (hf) __syncthreads();
+        if (wm == hf) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + wn * 32 + (lane & 31)] = acc[i][0][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                     // 64 rows x 8 channel groups = 512 items over 256 threads
+          const int item = tid + u * NT, lr = item >> 3, g = item & 7, row = hf * 64 + lr;
+          float v[8];
+          {                                               // (gate = 0 for padding rows / pixels outside the image)
+            const f32x4 g0 = gq[2 * hf + u][0], g1 = gq[2 * hf + u][1];
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + lr * 64 + g * 8), c1 = *reinterpret_cast<const f32x4*>(Cs + lr * 64 + g * 8 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = c0[e] * g0[e]; v[4 + e] = c1[e] * g1[e]; }
+          }
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            hi[q] = (__bf16)v[q];
+            lo[q] = (__bf16)(v[q] - (float)hi[q]);
+          }
+          const int d = (g >> 2) * (128 * 32) + row * 32 + (((2 * (g & 3)) ^ ((row >> 1) & 7)) << 2);
+          *reinterpret_cast<u32x4*>(A2 + d) = __builtin_bit_cast(u32x4, hi);
+          *reinterpret_cast<u32x4*>(A2 + (d ^ 4)) = __builtin_bit_cast(u32x4, lo);
+        }
+      }
+      __syncthreads();
+      // T = S_1 . W: wave w owns tile rows 32 w .. 32 w + 31, all 64 columns; K = 64 = 2 chunks x 2 steps
+      f32x16 t2[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t2[j][r] = 0.f;
+      {
+        const int a_row = wave * 32 + (lane & 31), swz2 = (lane >> 1) & 7, h2 = lane >> 5;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+          for (int st = 0; st < 2; ++st) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(A2 + cc * (128 * 32) + a_row * 32 + (((4 * st + 2 * h2) ^ swz2) << 2)));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(A2 + cc * (128 * 32) + a_row * 32 + (((4 * st + 2 * h2 + 1) ^ swz2) << 2)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, wq[cc][st][0][j]), bl = __builtin_bit_cast(bf16x8, wq[cc][st][1][j]);
+              t2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, t2[j], 0, 0, 0);
+              t2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, t2[j], 0, 0, 0);
+              t2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, t2[j], 0, 0, 0);
+            }
+          }
+      }
+      __syncthreads();                                    // every wave is done reading A2: T may overwrite it
+      float* Ts = smem;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int lr = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = j * 32 + (lane & 31);
+          if (col < TS2) Ts[lr * TS2 + col] = t2[j][r];
+        }
+      }
+      __syncthreads();
+      // partial sums of the ring-inclusive positions: output (oy, ox) in [-1, th] x [-1, tw] tile coordinates gets
+      // sum over taps of T[source = (oy - (kh - 1), ox - (kw - 1))][tap] for the sources this tile owns
+      const int RW = a.tw + 2, npos = (a.th + 2) * RW;
+      const int mtp_ = a.tile_map ? a.tile_map[mt] : mt;
+      for (int p = tid; p < npos; p += NT) {
+        const int ry = p / RW, rx = p - ry * RW, oy = ry - 1, ox = rx - 1;
+        float pos[3] = {0.f, 0.f, 0.f}, neg[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int sy = oy - (tap / 3 - 1), sx = ox - (tap % 3 - 1);
+          if (sy >= 0 && sy < a.th && sx >= 0 && sx < a.tw && Y0 + sy < a.nyh && x0 + sx < a.W) {
+            const float* r = Ts + (sy * a.tw + sx) * TS2 + tap * 6;
+            pos[0] += r[0]; pos[1] += r[1]; pos[2] += r[2];
+            neg[0] += r[3]; neg[1] += r[4]; neg[2] += r[5];
+          }
+        }
+        float* o = a.img_part + ((size_t)mtp_ * npos + p) * 6;
+        o[0] = pos[0]; o[1] = pos[1]; o[2] = pos[2]; o[3] = neg[0]; o[4] = neg[1]; o[5] = neg[2];
+      }
+      return;
+    }
   }
 
   // ---- conv-LRP epilogues: stage the C tile through the (now idle) LDS so that the gate loads
@@ -1437,6 +1581,12 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+          if (a.img_part) {                              // image layer folded in: tiles of IMGF_TH rows that never straddle two tokens
+            if (PREC != PREC_BF16X3 || EPI != EPI_MUL || a.N != 64 || !a.img_w || (a.H % IMGF_TH) || a.th < IMGF_TH) return hipErrorInvalidValue;
+            a.th = IMGF_TH;
+            a.hrows = IMGF_TH + 2;                       // (no separator row inside a tile)
+            a.m_tiles = (a.nyh / a.th) * a.cols_t;
+          }
           a.tile_map = conv_tile_order(a, st);
           if (a.up2_src && (PREC != PREC_BF16X3 || a.CinP > 64 || !a.up2_gate || (a.H & 1) || (a.W & 1))) return hipErrorInvalidValue;
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true, TERMS>), dim3(a.m_tiles), dim3(256), 0, st, a);
@@ -1444,7 +1594,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
         }
       }
     }
-    if (a.up2_src) return hipErrorInvalidValue;          // the compact pool interface exists for the weights-in-registers kernel only
+    if (a.up2_src || a.img_part) return hipErrorInvalidValue;   // the compact pool interface / the folded image layer exist for the weights-in-registers kernel only
     if (a.taps == 9 && mode > 0 && (t.BN >= 128 || (mode == 2 && t.BN >= 64)) && wide != 128) {
       const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
       if (u >= 0.9f || (mode == 2 && u > 0.f)) {
