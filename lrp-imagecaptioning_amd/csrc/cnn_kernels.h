@@ -591,19 +591,19 @@ __global__ __launch_bounds__(256) void img_partial_sum_kernel(const float* __res
                                                               const int* __restrict__ row2img, float* __restrict__ out, int n, int H, int W,
                                                               int th, int tw, int cols_t, int mode) {
   const size_t total = (size_t)n * H * W;
-  const int RW = tw + 2, npos = (th + 2) * RW;
+  const int RW = tw + 2, npos = (th + 2) * RW, tpt = (H + th - 1) / th;   // tiles are laid out per token: tpt tile rows each
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int HW = H * W;
     const int t = (int)(i / HW), pix = (int)(i - (size_t)t * HW);
     const int h = pix / W, w = pix - h * W;
-    const int Y = t * H + h, tyt0 = Y / th, txt0 = w / tw, hm = h % th, wm = w % tw;
-    const int ty_lo = (hm == 0 && h > 0) ? tyt0 - 1 : tyt0, ty_hi = (hm == th - 1 && h + 1 < H) ? tyt0 + 1 : tyt0;
+    const int tr0 = h / th, txt0 = w / tw, hm = h - tr0 * th, wm = w - txt0 * tw;        // tile row WITHIN the token
+    const int ty_lo = (hm == 0 && h > 0) ? tr0 - 1 : tr0, ty_hi = (hm == th - 1 && h + 1 < H) ? tr0 + 1 : tr0;
     const int tx_lo = (wm == 0 && w > 0) ? txt0 - 1 : txt0, tx_hi = (wm == tw - 1 && txt0 + 1 < cols_t) ? txt0 + 1 : txt0;
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int ty = ty_lo; ty <= ty_hi; ++ty)
       for (int tx = tx_lo; tx <= tx_hi; ++tx) {
-        const int p = (Y - ty * th + 1) * RW + (w - tx * tw + 1);
-        const float* r = part + (((size_t)ty * cols_t + tx) * npos + p) * 6;
+        const int p = (h - ty * th + 1) * RW + (w - tx * tw + 1);
+        const float* r = part + ((((size_t)t * tpt + ty) * cols_t + tx) * npos + p) * 6;
         const float2 a = *reinterpret_cast<const float2*>(r);
         const float2 b = *reinterpret_cast<const float2*>(r + 2);
         const float2 c = *reinterpret_cast<const float2*>(r + 4);

@@ -101,7 +101,7 @@ constexpr int IMG_PATCH = 16, IMG_TILE = 14;
 // token -> image map, rebuilt only when that map changes.  Tiles are independent, so the order changes no result bit.
 struct TileOrder {
   std::vector<int> sig;                                 // token -> image map the table was built for
-  int H = 0, th = 0, nyh = 0, cols_t = 0;
+  int H = 0, th = 0, nyh = 0, cols_t = 0, tpt = 0;
   bool identity = true;
   int* dev = nullptr;
   int* pinned = nullptr;
@@ -210,12 +210,16 @@ struct ConvArgs {
   // 64 -> 54 matrix `img_w` (the image layer's T = S_1 . W, cnn_kernels.h) and applies the 9-tap shift-and-add for the
   // SOURCE pixels it owns: per tile (th + 2) x (tw + 2) output positions (its pixels and the one-pixel ring around them)
   // x 6 partial sums go to img_part[tile of the stack][position][6]; img_partial_sum_kernel adds the up to four tiles'
-  // partials of a pixel in a fixed order and applies x+ / x-.  Needs th | H (tiles do not straddle tokens, so the
-  // grouping of a pixel's nine taps into partials is the same for every token: results stay batch-invariant bit for bit).
+  // partials of a pixel in a fixed order and applies x+ / x-.  Tiles are laid out per token (tpt below: none straddles two
+  // tokens, so the grouping of a pixel's nine taps into partials is the same for every token and every batch: results stay
+  // batch-invariant bit for bit).
   const float* img_w;          // [64][64] split8 bf16 pairs (layer 0's backward matrix)
   float* img_part;
+  // tpt > 0 (folded launch): tiles are laid out PER TOKEN — tpt tile rows of th stack rows per token, the last one possibly
+  // short — instead of over the whole stack, so that no tile straddles two tokens and the tile boundaries fall at the same
+  // image rows for every token.  Tile row R of the launch covers token R / tpt, image rows (R % tpt) * th ...
+  int tpt;
 };
-constexpr int IMGF_TH = 8;     // tile rows of the fused launch (224 = 28 x 8)
 constexpr int ACT_MAX_SLOTS = 64;
 
 constexpr int LDS_STRIDE = 32;   // floats per staged row (128 B, no padding; swizzled chunks)
@@ -289,8 +293,13 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     const int mtp = a.tile_map ? a.tile_map[mt] : mt;    // launch order -> tile of the stack (TileOrder)
     const int tyt = mtp / a.cols_t;
     x0 = (mtp - tyt * a.cols_t) * a.tw;
-    Y0 = tyt * a.th;
-    img0 = Y0 / a.H;
+    if (a.tpt > 0) {                                     // per-token tiling (ConvArgs::tpt)
+      img0 = tyt / a.tpt;
+      Y0 = img0 * a.H + (tyt - img0 * a.tpt) * a.th;
+    } else {
+      Y0 = tyt * a.th;
+      img0 = Y0 / a.H;
+    }
   }
   // exact small-integer division (operands < 2^22): float estimate + one fix-up step
   auto divmod = [](int x, int d, float inv, int& q, int& r) {
@@ -298,6 +307,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     r = x - q * d;
     if (r < 0) { --q; r += d; } else if (r >= d) { ++q; r -= d; }
   };
+  // first stack row that is NOT this tile's any more: the end of the stack, or of the tile's token when tiles are per token
+  const int yend = HALO ? (a.tpt > 0 && (img0 + 1) * a.H < a.nyh ? (img0 + 1) * a.H : a.nyh) : 0;
   const float inv_tw = HALO ? 1.0f / (float)a.tw : 0.f, inv_H = HALO ? 1.0f / (float)a.H : 0.f;
   const float inv_H1 = HALO ? 1.0f / (float)(a.H + 1) : 0.f;
   // interleaved dual forward: the scale records of the (at most two, for all but tiny images) images this tile's rows belong
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
       divmod(r, a.tw, inv_tw, ty, tx);
       const int Y = Y0 + ty;
       divmod(Y, a.H, inv_H, n_, h_);
-      const bool ok = r < a.th * a.tw && Y < a.nyh && x0 + tx < a.W;
+      const bool ok = r < a.th * a.tw && Y < yend && x0 + tx < a.W;
       const int hy = ok ? ty + 1 + n_ - img0 : 1, hx = ok ? tx + 1 : 1;
       fbase[i] = hy * HALO_PITCH + hx;
       fu[i] = hy * a.tw + hx - 1;
@@ -831,26 +842,26 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   // ---- image layer folded into this layer's epilogue (ConvArgs::img_part)
   if constexpr (BREG && EPI == EPI_MUL && PREC == PREC_BF16X3 && TM == 2 && TN == 1 && WM == 2 && WN == 2) {
     if (a.img_part) {
-      static_assert(2 * STAGE >= 64 * 64 + 2 * 128 * 32 && 2 * STAGE >= 128 * 57, "Cs slab + A2, then T, inside the staging LDS");
+      static_assert(2 * STAGE >= 128 * 64, "the C tile (then S_1 as pairs, in place; then T) inside the staging LDS");
       constexpr int TS2 = 57;                             // T row stride (54 used; odd: conflict-free column reads)
-      float* Cs = smem;                                   // [64 rows][64] fp32: one row slab of the C tile at a time
-      float* A2 = smem + 64 * 64;                         // [2 chunks][128 rows][32 floats]: S_1 as split8 pairs, swizzled like an A tile
+      float* Cs = smem;                                   // [128 rows][64] fp32 — rewritten IN PLACE as S_1's bf16 pairs:
+      // row r keeps its 256 B = [chunk 0 | chunk 1] x 128 B, 16 B slots XOR-swizzled with (r >> 1) & 7 like an A tile.  The eight
+      // lanes that own a row are neighbours in one wave and LDS serves a wave's instructions in order, so all of a row's
+      // reads are done before any of its writes.
       const float inv_tw2 = 1.0f / (float)a.tw;
       // everything this epilogue needs from global memory is requested up front — the gates of this thread's four
       // (row, channel group) items and this wave's fragments of the tap matrix — so that the latencies overlap each other
       // and the LDS passes below instead of sitting between them
       f32x4 gq[4][2];
-      bool gok[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {                       // k = 2 * slab + u
-        const int item = tid + (k & 1) * NT, row = (k >> 1) * 64 + (item >> 3), g = item & 7;
+      for (int k = 0; k < 4; ++k) {
+        const int item = tid + k * NT, row = item >> 3, g = item & 7;
         int ty, tx;
         divmod(row, a.tw, inv_tw2, ty, tx);
         const int Y = Y0 + ty, w = x0 + tx;
-        gok[k] = row < a.th * a.tw && Y < a.nyh && w < a.W;
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        gq[k][0] = gq[k][1] = z4;
-        if (gok[k]) {
+        gq[k][0] = gq[k][1] = z4;                         // (gate = 0 for padding rows / pixels outside the image)
+        if (row < a.th * a.tw && Y < yend && w < a.W) {
           int n, h;
           divmod(Y, a.H, inv_H, n, h);
           const int img = a.row2img ? a.row2img[n] : n;
@@ -872,36 +883,28 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
                 wq[cc][st][hl][j] = *reinterpret_cast<const u32x4*>(a.img_w + (size_t)(j * 32 + (lane & 31)) * 64 + cc * 32 + (4 * st + 2 * h2 + hl) * 4);
       }
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        if (hf) __syncthreads();
-        if (wm == hf) {
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+        for (int r = 0; r < 16; ++r)
+          Cs[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + wn * 32 + (lane & 31)] = acc[i][0][r];
+      __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              Cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 64 + wn * 32 + (lane & 31)] = acc[i][0][r];
+      for (int k = 0; k < 4; ++k) {                       // 128 rows x 8 channel groups = 1024 items over 256 threads
+        const int item = tid + k * NT, row = item >> 3, g = item & 7;
+        float* rp = Cs + row * 64 + (g >> 2) * 32;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(rp + (g & 3) * 8), c1 = *reinterpret_cast<const f32x4*>(rp + (g & 3) * 8 + 4);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = c0[e] * gq[k][0][e]; v[4 + e] = c1[e] * gq[k][1][e]; }
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          hi[q] = (__bf16)v[q];
+          lo[q] = (__bf16)(v[q] - (float)hi[q]);
         }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {                     // 64 rows x 8 channel groups = 512 items over 256 threads
-          const int item = tid + u * NT, lr = item >> 3, g = item & 7, row = hf * 64 + lr;
-          float v[8];
-          {                                               // (gate = 0 for padding rows / pixels outside the image)
-            const f32x4 g0 = gq[2 * hf + u][0], g1 = gq[2 * hf + u][1];
-            const f32x4 c0 = *reinterpret_cast<const f32x4*>(Cs + lr * 64 + g * 8), c1 = *reinterpret_cast<const f32x4*>(Cs + lr * 64 + g * 8 + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = c0[e] * g0[e]; v[4 + e] = c1[e] * g1[e]; }
-          }
-          bf16x8 hi, lo;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            hi[q] = (__bf16)v[q];
-            lo[q] = (__bf16)(v[q] - (float)hi[q]);
-          }
-          const int d = (g >> 2) * (128 * 32) + row * 32 + (((2 * (g & 3)) ^ ((row >> 1) & 7)) << 2);
-          *reinterpret_cast<u32x4*>(A2 + d) = __builtin_bit_cast(u32x4, hi);
-          *reinterpret_cast<u32x4*>(A2 + (d ^ 4)) = __builtin_bit_cast(u32x4, lo);
-        }
+        const int d = ((2 * (g & 3)) ^ ((row >> 1) & 7)) << 2;
+        *reinterpret_cast<u32x4*>(rp + d) = __builtin_bit_cast(u32x4, hi);
+        *reinterpret_cast<u32x4*>(rp + (d ^ 4)) = __builtin_bit_cast(u32x4, lo);
       }
       __syncthreads();
       // T = S_1 . W: wave w owns tile rows 32 w .. 32 w + 31, all 64 columns; K = 64 = 2 chunks x 2 steps
@@ -916,8 +919,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
           for (int st = 0; st < 2; ++st) {
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(A2 + cc * (128 * 32) + a_row * 32 + (((4 * st + 2 * h2) ^ swz2) << 2)));
-            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(A2 + cc * (128 * 32) + a_row * 32 + (((4 * st + 2 * h2 + 1) ^ swz2) << 2)));
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Cs + a_row * 64 + cc * 32 + (((4 * st + 2 * h2) ^ swz2) << 2)));
+            const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(Cs + a_row * 64 + cc * 32 + (((4 * st + 2 * h2 + 1) ^ swz2) << 2)));
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const bf16x8 bh = __builtin_bit_cast(bf16x8, wq[cc][st][0][j]), bl = __builtin_bit_cast(bf16x8, wq[cc][st][1][j]);
@@ -949,7 +952,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int sy = oy - (tap / 3 - 1), sx = ox - (tap % 3 - 1);
-          if (sy >= 0 && sy < a.th && sx >= 0 && sx < a.tw && Y0 + sy < a.nyh && x0 + sx < a.W) {
+          if (sy >= 0 && sy < a.th && sx >= 0 && sx < a.tw && Y0 + sy < yend && x0 + sx < a.W) {
             const float* r = Ts + (sy * a.tw + sx) * TS2 + tap * 6;
             pos[0] += r[0]; pos[1] += r[1]; pos[2] += r[2];
             neg[0] += r[3]; neg[1] += r[4]; neg[2] += r[5];
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
         divmod(lr, a.tw, inv_tw, ty, tx);
         const int Y = Y0 + ty;
         w = x0 + tx;
-        if (lr >= a.th * a.tw || Y >= a.nyh || w >= a.W) return false;
+        if (lr >= a.th * a.tw || Y >= yend || w >= a.W) return false;
         divmod(Y, a.H, inv_H, n, h);
         row = Y * a.W + w;
         return true;
@@ -1455,17 +1458,18 @@ inline const int* conv_tile_order(const ConvArgs& a, hipStream_t st) {
   static const int on = [] { const char* e = getenv("LRP_TILE_ORDER"); return e ? atoi(e) : 1; }();
   if (!on || !a.order || !a.row2img_host || a.NB < 2 || a.th < 1) return nullptr;
   TileOrder& o = *a.order;
-  const int tiles_y = (a.nyh + a.th - 1) / a.th;
-  const bool same = o.H == a.H && o.th == a.th && o.nyh == a.nyh && o.cols_t == a.cols_t && (int)o.sig.size() == a.NB &&
+  const int tiles_y = a.tpt > 0 ? a.NB * a.tpt : (a.nyh + a.th - 1) / a.th;
+  const bool same = o.H == a.H && o.th == a.th && o.nyh == a.nyh && o.cols_t == a.cols_t && o.tpt == a.tpt && (int)o.sig.size() == a.NB &&
                     memcmp(o.sig.data(), a.row2img_host, (size_t)a.NB * sizeof(int)) == 0;
   if (same) return o.identity ? nullptr : o.dev;
   o.sig.assign(a.row2img_host, a.row2img_host + a.NB);
-  o.H = a.H; o.th = a.th; o.nyh = a.nyh; o.cols_t = a.cols_t;
+  o.H = a.H; o.th = a.th; o.nyh = a.nyh; o.cols_t = a.cols_t; o.tpt = a.tpt;
   static const int band = [] { const char* e = getenv("LRP_TILE_BAND"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
   static const int strip = [] { const char* e = getenv("LRP_TILE_STRIP"); return e ? atoi(e) : 2; }();   // column tiles per strip; 0 = whole rows
   std::vector<long long> key((size_t)tiles_y);
   for (int ty = 0; ty < tiles_y; ++ty) {
-    int Ym = ty * a.th + a.th / 2;
+    int Ym = a.tpt > 0 ? (ty / a.tpt) * a.H + (ty % a.tpt) * a.th + a.th / 2 : ty * a.th + a.th / 2;
+    if (a.tpt > 0 && Ym > (ty / a.tpt + 1) * a.H - 1) Ym = (ty / a.tpt + 1) * a.H - 1;
     if (Ym > a.nyh - 1) Ym = a.nyh - 1;
     const int t = Ym / a.H, hpos = Ym - t * a.H;
     key[ty] = ((long long)o.sig[t] << 42) | ((long long)(hpos / (a.th * band)) << 21) | (long long)t;
@@ -1581,11 +1585,11 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
           a.nyh = a.NB * a.H;
           a.cols_t = (a.W + a.tw - 1) / a.tw;
           a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
-          if (a.img_part) {                              // image layer folded in: tiles of IMGF_TH rows that never straddle two tokens
-            if (PREC != PREC_BF16X3 || EPI != EPI_MUL || a.N != 64 || !a.img_w || (a.H % IMGF_TH) || a.th < IMGF_TH) return hipErrorInvalidValue;
-            a.th = IMGF_TH;
-            a.hrows = IMGF_TH + 2;                       // (no separator row inside a tile)
-            a.m_tiles = (a.nyh / a.th) * a.cols_t;
+          if (a.img_part) {                              // image layer folded in: tiles laid out per token (none straddles two tokens)
+            if (PREC != PREC_BF16X3 || EPI != EPI_MUL || a.N != 64 || !a.img_w) return hipErrorInvalidValue;
+            a.tpt = (a.H + a.th - 1) / a.th;
+            a.hrows = a.th + 2;                          // (no separator row inside a tile's own rows)
+            a.m_tiles = a.NB * a.tpt * a.cols_t;
           }
           a.tile_map = conv_tile_order(a, st);
           if (a.up2_src && (PREC != PREC_BF16X3 || a.CinP > 64 || !a.up2_gate || (a.H & 1) || (a.W & 1))) return hipErrorInvalidValue;

@@ -932,10 +932,12 @@ struct Encoder {
     // walk 26.3 -> 25.7-25.9 ms; heat-map parity unchanged].  LRP_UP2_COMPACT=0 disables.
     static const bool up2_on = [] { const char* e = getenv("LRP_UP2_COMPACT"); return !e || atoi(e) != 0; }();
     bool compact_in = false;                             // S (the current layer's input) is in the compact form
-    int fold_tw = 0;
+    int fold_tw = 0, fold_th = 0;
     // Image layer folded into the epilogue of the layer above it (ConvArgs::img_part): S_1 — 4.1 GB written, 4.5 GB read at
     // the bench configuration — never goes to memory; per tile 160 positions x 6 partial sums do, and a streaming pass
-    // adds them up in a fixed order [MI355X: block1_conv2 x.xx -> x.xx ms, image layer 1.29 -> x.xx ms].
+    // adds them up in a fixed order [MI355X, same box: block1_conv2 4.25 -> 4.57 ms (it now also runs the tap GEMM and the
+    // in-tile stencil), image layer 1.29 -> 0.18 ms, walk 26.1-26.3 -> 25.3 ms; heat-maps unchanged to fp32 round-off,
+    // batch invariance bit-exact].
     // LRP_IMG_FOLD=0 disables.
     static const bool fold_on = [] { const char* e = getenv("LRP_IMG_FOLD"); return !e || atoi(e) != 0; }();
     for (int li = (int)layers.size() - 1; li >= 0; --li) {
@@ -982,13 +984,10 @@ struct Encoder {
         epi = P.pool_after ? EPI_MUL_UP2 : EPI_MUL;
         // the image layer rides on this launch's epilogue?
         if (li == 1 && fold_on && split && !f16 && walk == 0 && !layer_hook && img_fused() && !P.pool_after && L.cin == 64 &&
-            !(L.H % IMGF_TH) && P.w_bwd_s.p && conv_takes_breg(L.cin, L.H, L.W, L.w_bwd_frag.p != nullptr)) {
-          int tw_ = 0, th_ = 0, hr_ = 0;
-          (void)conv_halo_geom(128, L.H, L.W, tw_, th_, hr_);
-          if (th_ >= IMGF_TH) {
-            ca.img_w = P.w_bwd_s.as<float>(); ca.img_part = Snext; ca.out = nullptr;
-            fold_tw = tw_;
-          }
+            P.w_bwd_s.p && conv_takes_breg(L.cin, L.H, L.W, L.w_bwd_frag.p != nullptr)) {
+          int hr_ = 0;
+          (void)conv_halo_geom(128, L.H, L.W, fold_tw, fold_th, hr_);
+          ca.img_w = P.w_bwd_s.as<float>(); ca.img_part = Snext; ca.out = nullptr;
         }
         if (compact_in) {                                 // this layer reads the compact form its producer left
           ca.up2_src = S; ca.up2_gate = L.G.as<float>();     // (ca.in = S stays a valid pointer; it is not read)
@@ -1036,7 +1035,7 @@ struct Encoder {
           (void)hipEventRecord(p2.e0, st);
         }
         hipLaunchKernelGGL(img_partial_sum_kernel, dim3(stream_grid((size_t)n * L0.H * L0.W)), dim3(256), 0, st, ca.img_part, images.as<float>(),
-                           row2img_dev, R_img_dev, n, L0.H, L0.W, IMGF_TH, fold_tw, (L0.W + fold_tw - 1) / fold_tw, 0);
+                           row2img_dev, R_img_dev, n, L0.H, L0.W, fold_th, fold_tw, (L0.W + fold_tw - 1) / fold_tw, 0);
         LRP_HIP_CHECK(hipGetLastError());
         if (profile) {
           (void)hipEventRecord(p2.e1, st);
