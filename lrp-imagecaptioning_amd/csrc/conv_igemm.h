@@ -1422,6 +1422,17 @@ inline int conv_tile_override() {
   return v;
 }
 
+// small grids take 64 x 64 tiles (conv_launch_epi): LRP_CONV_SMALL=0 disables, LRP_CONV_SMALL_BLOCKS = the 128-row grid size
+// up to which they are used (default 256 = one workgroup per CU)
+inline bool conv_small_tile_on() {
+  static const int v = [] { const char* e = getenv("LRP_CONV_SMALL"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
+inline long conv_small_tile_blocks() {
+  static const long v = [] { const char* e = getenv("LRP_CONV_SMALL_BLOCKS"); return e ? atol(e) : 256L; }();
+  return v;
+}
+
 // halo-resident variant: env LRP_CONV_HALO = 0 never, 1 (default) when a tile shape fills >= 90 % of the M tile,
 // 2 always (tests: ragged tile shapes).  Read per launch so a test can flip it.
 inline int conv_halo_mode() {
@@ -1569,6 +1580,13 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  // Small grids (one image, a handful of words: explain_image.py's own call): with 128-row tiles the 14 x 14 / 28 x 28
+  // layers are 16-250 workgroups, each walking K = 2304-4608 alone — the launch takes as long as ONE tile's K loop
+  // [MI355X, B = 1, T = 10: 115-119 us per block4 / block5 launch, forward and backward].  64 x 64 tiles (4 waves of
+  // 32 x 32) put 4x the workgroups on the chip and a k-step costs a quarter of the MFMAs.  Every output element still sees
+  // the same chain of MFMAs in the same k order, so the results are bit-identical to the large tiles (batch invariance).
+  const bool small_tile = conv_small_tile_on() && t.BM == 128 && t.BN >= 64 && (long)a.m_tiles * a.n_tiles <= conv_small_tile_blocks() &&
+                          !a.up2_src && !a.img_part;
 
   if constexpr (PREC != PREC_FP32 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL)) {
     const int mode = conv_halo_mode();
@@ -1599,6 +1617,12 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
       }
     }
     if (a.up2_src || a.img_part) return hipErrorInvalidValue;   // the compact pool interface / the folded image layer exist for the weights-in-registers kernel only
+    if (small_tile) {
+      a.m_tiles = (a.M + 63) / 64;
+      a.n_tiles = (a.N + 63) / 64;
+      hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 1, 1, EPI, PREC, false, false, TERMS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+      return hipGetLastError();
+    }
     if (a.taps == 9 && mode > 0 && (t.BN >= 128 || (mode == 2 && t.BN >= 64)) && wide != 128) {
       const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
       if (u >= 0.9f || (mode == 2 && u > 0.f)) {
@@ -1616,6 +1640,12 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
         return hipGetLastError();
       }
     }
+  }
+  if (small_tile) {
+    a.m_tiles = (a.M + 63) / 64;
+    a.n_tiles = (a.N + 63) / 64;
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 1, 1, EPI, PREC, false, false, TERMS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    return hipGetLastError();
   }
   const dim3 grid(a.m_tiles * a.n_tiles);
   if constexpr (PREC != PREC_FP32) {
