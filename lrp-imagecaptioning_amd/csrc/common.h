@@ -50,19 +50,28 @@ inline int fail(int code, const char* fmt, ...) {
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool owned = true;                                   // false: a window of another DevBuf (view_of), never freed here
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes), owned(o.owned) { o.p = nullptr; o.bytes = 0; o.owned = true; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+    if (this != &o) { release(); p = o.p; bytes = o.bytes; owned = o.owned; o.p = nullptr; o.bytes = 0; o.owned = true; }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     bytes = 0;
+    owned = true;
+  }
+  // n bytes at `offset` of `arena` (which must outlive this view)
+  void view_of(const DevBuf& arena, size_t offset, size_t n) {
+    release();
+    p = static_cast<char*>(arena.p) + offset;
+    bytes = n;
+    owned = false;
   }
   int alloc(size_t n, int64_t* total) {
     release();

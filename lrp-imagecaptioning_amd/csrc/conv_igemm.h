@@ -255,8 +255,13 @@ constexpr int conv_halo_rows(int BM) { return BM == 256 ? 352 : 192; }   // x 12
 //   pass A  (h|m) x (h|m), TERMS 15: hh + hm + mh + mm      pass B  (h|l) x (h|l), TERMS 3: hl + lh
 // = every partial product down to 2^-16 of the leading one, i.e. an fp32-grade product in 6 bf16 MFMAs of 32 cycles
 // per 16 k (192) instead of 8 fp32 MFMAs of 64 (512).
-template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false, bool BREG = false, int TERMS = 7>
-__global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
+// NS (plain staging only: !HALO, !BREG): LDS stages of the k pipeline.  2 = chunk kc+2 is launched at the barrier of iteration kc
+// and must have landed one iteration later — fine when an iteration holds 24-48 MFMAs per wave, but the 64 x 64 tiles of the
+// small-grid launches (6 MFMAs per wave and iteration) then run at one L2 / HBM round trip per k-step [MI355X, one image:
+// 0.65 us per k-step, 95 us for a K = 4608 launch].  With NS stages NS-1 chunks are in flight and the barrier waits with a
+// COUNTED s_waitcnt vmcnt((NS-2) x DMA instructions per chunk) for the oldest only.
+template <int WM, int WN, int TM, int TN, int EPI, int PREC, bool HALO = false, bool BREG = false, int TERMS = 7, int NS = 2>
+__global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_waves(WM * WN, TM, TN, HALO)) void conv_igemm_kernel(ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub (the buffer-resource builtins are device-only)
   constexpr int NW = WM * WN, NT = 64 * NW;           // waves / threads per block (4 or 8 waves)
   constexpr bool SPLIT = PREC != PREC_FP32;            // operands in split8 form (bf16 or fp16 pairs): 16 k per MFMA
@@ -268,7 +273,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   static_assert(!BREG || (HALO && SPLIT && BM * BN <= 2 * STAGE), "BREG needs the resident image");
   static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces must divide over the waves");
   static_assert(!HALO || EPI != EPI_STORE, "the image layer is a 1-tap GEMM");
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  static_assert(NS == 2 || (NS > 2 && !HALO && !BREG), "deeper staging exists for the plain (non-resident) A path only");
+  constexpr int DPC = AP + BP;                         // DMA instructions per wave and chunk (plain staging)
+  static_assert((NS - 2) * DPC <= 63, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(16))) float smem[NS * STAGE];
 
   // ---- XCD-aware block remap: the n_tiles blocks that share an A tile get
   // consecutive logical ids and land on one XCD (one L2) [bijective form].
@@ -554,13 +562,25 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     }
     fire_chunk(prep_chunk(true), 0);
     fire_chunk(prep_chunk(nk > 1), 1);
+#pragma unroll
+    for (int s_ = 2; s_ < NS; ++s_) fire_chunk(prep_chunk(nk > s_), s_);
   }
   // hipcc gives __syncthreads() an lgkmcnt(0) only; the LDS-DMA completes on vmcnt, so the wait is explicit
   auto dma_landed_barrier = [] {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  dma_landed_barrier();
+  // NS > 2: the oldest chunk in flight has landed (the NS - 2 younger ones may still be on their way)
+  auto dma_oldest_landed_barrier = [] {
+    if constexpr (NS > 2) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * ((WM * TM * 32 + WN * TN * 32) / 8 / (WM * WN))) : "memory");   // (NS - 2) x DPC
+      __syncthreads();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  };
+  dma_oldest_landed_barrier();
 
   const int a_off = HALO ? 0 : (wm * TM * 32 + (lane & 31)) * LDS_STRIDE;
   const int b_off = ABUF + (wn * TN * 32 + (lane & 31)) * LDS_STRIDE;
@@ -771,9 +791,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
   set_tap(0);
   read_frag(f0, smem + a_off, smem + b_off, 0);
   }
+  int buf = 0;                                         // = kc % NS
   for (int kc = 0; kc < (BREG ? 0 : nk); ++kc) {
-    const int buf = kc & 1;
     const bool more = (kc + 1) < nk;
+    const int nbuf = buf + 1 == NS ? 0 : buf + 1;      // stage of chunk kc + 1
     const int abuf = HALO ? (ccc & 1) : buf;
     const float* Ab = smem + abuf * STAGE + a_off;
     const float* Bb = smem + buf * STAGE + b_off;
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     }
     // offsets of chunk kc+2 (-> `buf`) and, HALO, of this tap slot's piece of the next channel chunk's resident
     // image (slot = one piece per wave; that A buffer was last read in the chunk before this one)
-    const ChunkPrep cp = prep_chunk(kc + 2 < nk);
+    const ChunkPrep cp = prep_chunk(kc + NS < nk);
     HaloPiece hp{};
     int hpp = 0;
     if constexpr (HALO) {
@@ -799,7 +820,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
       if (hpp >= halo_np) hpp = -1;
       hp = prep_halo_piece(hpp < 0 ? 0 : hpp, ccc + 1, more && ccc + 1 < cpt);
     }
-    dma_landed_barrier();                              // reads of `buf` done everywhere; DMA of chunk kc+1 landed
+    dma_oldest_landed_barrier();                       // reads of `buf` done everywhere; DMA of chunk kc+1 landed
     fire_chunk(cp, buf);
     if constexpr (HALO) {
       if (hpp >= 0 && more && ccc + 1 < cpt) fire_halo_piece(hp, hpp, (ccc & 1) ^ 1);
@@ -813,9 +834,9 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
     // (on the last iteration this reads a stale buffer into registers nobody uses)
     if constexpr (HALO) {
       set_tap(ctap);
-      read_frag(f0, smem + (ccc & 1) * STAGE, smem + (buf ^ 1) * STAGE + b_off, 0);
+      read_frag(f0, smem + (ccc & 1) * STAGE, smem + nbuf * STAGE + b_off, 0);
     } else {
-      read_frag(f0, smem + (buf ^ 1) * STAGE + a_off, smem + (buf ^ 1) * STAGE + b_off, 0);
+      read_frag(f0, smem + nbuf * STAGE + a_off, smem + nbuf * STAGE + b_off, 0);
     }
     mfma_frag(f1);                                     // last step
     if constexpr (BLOCKED) {
@@ -830,6 +851,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : conv_min_waves(WM * WN, TM
           }
       }
     }
+    buf = nbuf;
   }
   dma_landed_barrier();                                // LDS is reused by the epilogue (and the tail DMAs of zeros are in)
   if constexpr (BLOCKED) {
@@ -1424,6 +1446,7 @@ inline int conv_tile_override() {
 
 // small grids take 64 x 64 tiles (conv_launch_epi): LRP_CONV_SMALL=0 disables, LRP_CONV_SMALL_BLOCKS = the 128-row grid size
 // up to which they are used (default 256 = one workgroup per CU)
+constexpr int CONV_SMALL_NS = 4;                       // LDS stages of the 64 x 64 tile's k pipeline (4 x 16 KB: two workgroups per CU... see NS)
 inline bool conv_small_tile_on() {
   static const int v = [] { const char* e = getenv("LRP_CONV_SMALL"); return e ? atoi(e) : 1; }();
   return v != 0;
@@ -1620,7 +1643,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     if (small_tile) {
       a.m_tiles = (a.M + 63) / 64;
       a.n_tiles = (a.N + 63) / 64;
-      hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 1, 1, EPI, PREC, false, false, TERMS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 1, 1, EPI, PREC, false, false, TERMS, CONV_SMALL_NS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
       return hipGetLastError();
     }
     if (a.taps == 9 && mode > 0 && (t.BN >= 128 || (mode == 2 && t.BN >= 64)) && wide != 128) {
@@ -1644,7 +1667,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if (small_tile) {
     a.m_tiles = (a.M + 63) / 64;
     a.n_tiles = (a.N + 63) / 64;
-    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 1, 1, EPI, PREC, false, false, TERMS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 1, 1, EPI, PREC, false, false, TERMS, CONV_SMALL_NS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
     return hipGetLastError();
   }
   const dim3 grid(a.m_tiles * a.n_tiles);

@@ -40,6 +40,7 @@ struct Decoder {
   // per-step scratch
   DevBuf xh, zgate, hproj, sproj, u, att_pre;
   // cached state (what the reference leaves on `self`)
+  DevBuf state_arena;              // declared before its views (destroyed after them)
   std::map<std::string, StateBuf> state;
   DevBuf cap_dev;
   std::vector<int> cap_host, len_host;
@@ -74,10 +75,13 @@ struct Decoder {
     if (2 * E + H > SCAN_MAXR * 256 || H + 2 * E + H > SCAN_MAXR * 256)
       return fail(LRP_ERR_UNSUPPORTED, "2E+H too large for the scan kernel");
     const size_t B = B_max, S = Tm + 1;
+    // every array prepare_static has to zero lives in ONE arena (state_arena): one memset per forward instead of one per
+    // array [MI355X, single image: 14 fills of ~4.8 us each on the critical path].  Two passes: sizes, then the views.
+    struct Want { std::string nm; size_t bytes, eb; };
+    std::vector<Want> wants;
     auto st = [&](const char* nm, size_t elems, size_t eb) -> int {
-      StateBuf& s = state[nm];
-      s.elem_bytes = eb;
-      return s.buf.alloc(elems * eb, total);
+      wants.push_back({nm, elems * eb, eb});
+      return LRP_OK;
     };
     if (kind == LRP_DEC_ADAPTIVE) {
       for (const char* nm : {"ht", "ct", "gt", "it_act", "ft_act", "st", "ot_act"}) LRP_TRY(st(nm, B * S * H, 4));
@@ -103,7 +107,7 @@ struct Decoder {
       LRP_TRY(zg2d.alloc(B * 4 * H * 8 * KS_GATE, total));
       LRP_TRY(hprojd.alloc(B * H * 8 * KS_PROJ, total));
       LRP_TRY(sprojd.alloc(B * H * 8 * KS_PROJ, total));
-      LRP_TRY(h2u.alloc(B * Tm * H * 8, total));
+      LRP_TRY(st("#h2u", B * Tm * H, 8));
       LRP_TRY(rho.alloc((size_t)NT_max * Tm * H * 8, total));
     }
     LRP_TRY(vfeat.alloc(B * L * H * 4, total));
@@ -117,7 +121,23 @@ struct Decoder {
     LRP_TRY(hproj.alloc(B * H * 4 * KS_PROJ, total));
     LRP_TRY(sproj.alloc(B * H * 4 * KS_PROJ, total));
     LRP_TRY(att_pre.alloc(B * (L + 1) * 4, total));
-    LRP_TRY(u.alloc(B * Tm * H * 8, total));
+    LRP_TRY(st("#u", B * Tm * H, 8));
+    {
+      size_t off = 0;
+      for (const Want& w : wants) off += (w.bytes + 255) / 256 * 256;
+      LRP_TRY(state_arena.alloc(off, total));
+      off = 0;
+      for (const Want& w : wants) {
+        if (w.nm == "#u") u.view_of(state_arena, off, w.bytes);
+        else if (w.nm == "#h2u") h2u.view_of(state_arena, off, w.bytes);
+        else {
+          StateBuf& s = state[w.nm];
+          s.elem_bytes = w.eb;
+          s.buf.view_of(state_arena, off, w.bytes);
+        }
+        off += (w.bytes + 255) / 256 * 256;
+      }
+    }
     LRP_TRY(cap_dev.alloc(B * Tm * sizeof(int), total));
     LRP_TRY(rctx.alloc((size_t)NT_max * H * 8, total));
     if ((H & 7) == 0) LRP_TRY(tailA.alloc((size_t)NT_max * L * H * 4, total));
@@ -494,9 +514,7 @@ struct Decoder {
 
   // zeroed state + the per-image static part (E:375-388): relu(F W_if + b), its projection, mean feature, global feature
   int prepare_static(const float* feat_dev, int B, hipStream_t st) {
-    for (auto& kv : state) LRP_HIP_CHECK(hipMemsetAsync(kv.second.buf.p, 0, kv.second.buf.bytes, st));
-    LRP_HIP_CHECK(hipMemsetAsync(u.p, 0, u.bytes, st));
-    if (kind == LRP_DEC_GRIDTD) LRP_HIP_CHECK(hipMemsetAsync(h2u.p, 0, h2u.bytes, st));
+    LRP_HIP_CHECK(hipMemsetAsync(state_arena.p, 0, state_arena.bytes, st));   // every state array, u and h2u (views of the arena)
     {
       ConvArgs ca{};
       ca.in = feat_dev; ca.NB = B * L; ca.H = 1; ca.W = 1; ca.Cin = D; ca.CinP = conv_cinp(D); ca.taps = 1;
@@ -514,10 +532,20 @@ struct Decoder {
                          if_pre.as<float>(), ipre.as<double>(), ne);
       LRP_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(mean_rows_kernel, dim3(B), dim3(256), 0, st, feat_dev, avg.as<float>(), L, D);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(B, (D + 63) / 64), dim3(64), 0, st, feat_dev, avg.as<float>(), L, D);
     LRP_HIP_CHECK(hipGetLastError());
-    LRP_HIP_CHECK((skinny<float, float, float>(avg.as<float>(), D, Wglob.as<float>(), E, bglob.as<float>(),
-                                               glob_pre.as<float>(), E, B, D, E, 0, st)));
+    if (mfma_forward()) {
+      // on the fp32 matrix cores like the products of a step (K split over the chip, slices reduced in index order): the
+      // VALU GEMV walks K = D alone in 8 workgroups [MI355X, one image: 70 us]
+      LRP_TRY(need_sg_ws());
+      SgemmArgs a{};
+      a.A = avg.as<float>(); a.lda = D; a.B = Wglob.as<float>(); a.ldb = E; a.C = glob_pre.as<float>(); a.ldc = E;
+      a.M = B; a.N = E; a.K = D; a.bias = bglob.as<float>();
+      LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
+    } else {
+      LRP_HIP_CHECK((skinny<float, float, float>(avg.as<float>(), D, Wglob.as<float>(), E, bglob.as<float>(),
+                                                 glob_pre.as<float>(), E, B, D, E, 0, st)));
+    }
     return LRP_OK;
   }
 
@@ -535,31 +563,37 @@ struct Decoder {
       // workgroups, slices reduced in index order) — LRP_DEC_MFMA_FWD=0: the VALU skinny GEMM with consumer-side slabs
       const bool mf = mfma_forward();
       int ksg = KS_GATE, ksp = KS_PROJ;
+      size_t zsl = zslab, psl = pslab;
+      const float *zsrc = zgate.as<float>(), *zbias = nullptr, *hsrc = hproj.as<float>(), *ssrc = sproj.as<float>();
+      // MFMA path: the K-split slices stay in the workspace and the CONSUMER kernel adds them up (index order, then the bias
+      // — the arithmetic of sgemm_reduce_kernel, so the results do not change): three launches fewer per step.  Regions of
+      // the workspace: gates [0, 3/4), h projection [3/4, 7/8), sentinel projection [7/8, 1).
+      constexpr size_t WS_G = SG_WS_FLOATS / 4 * 3, WS_P = SG_WS_FLOATS / 8;
       if (mf) {
-        if (!sg_ws.p) { int64_t dummy = 0; LRP_TRY(sg_ws.alloc(SG_WS_FLOATS * sizeof(float), &dummy)); }
-        auto mm = [&](const float* A, long lda, const float* Bm, int N, int K, const float* bias, float* Cc) -> int {
-          SgemmArgs a{};
-          a.A = A; a.lda = lda; a.B = Bm; a.ldb = N; a.C = Cc; a.ldc = N; a.M = B; a.N = N; a.K = K; a.bias = bias;
-          LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
-          return LRP_OK;
-        };
-        LRP_TRY(mm(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, Kd, bcat.as<float>(), zgate.as<float>()));
-        ksg = ksp = 1;
+        LRP_TRY(need_sg_ws());
+        SgemmArgs a{};
+        a.A = xh.as<float>(); a.lda = Kd; a.B = Wcat.as<float>(); a.ldb = 5 * H; a.M = B; a.N = 5 * H; a.K = Kd;
+        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), WS_G, st, &ksg));
+        zsrc = sg_ws.as<float>(); zsl = (size_t)B * 5 * H; zbias = bcat.as<float>();
       } else {
         LRP_HIP_CHECK((skinny<float, float, float>(xh.as<float>(), Kd, Wcat.as<float>(), 5 * H, bcat.as<float>(),
                                                    zgate.as<float>(), 5 * H, B, Kd, 5 * H, 0, st, KS_GATE, zslab)));
       }
-      hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B), dim3(256), 0, st, zgate.as<float>(), ksg, zslab, ht,
+      hipLaunchKernelGGL(dec_pointwise_kernel, dim3(B, (H + 63) / 64), dim3(64), 0, st, zsrc, ksg, zsl, zbias, ht,
                          S_<float>("ct"), S_<float>("gt"), S_<float>("it_act"), S_<float>("ft_act"), stt,
                          S_<float>("ot_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
       if (mf) {
         SgemmArgs a{};
-        a.lda = (long)S * H; a.ldb = H; a.ldc = H; a.M = B; a.N = H; a.K = H;
-        a.A = ht + (size_t)(i + 1) * H; a.B = Wg.as<float>(); a.C = hproj.as<float>();
-        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
-        a.A = stt + (size_t)(i + 1) * H; a.B = Ws.as<float>(); a.C = sproj.as<float>();
-        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>(), SG_WS_FLOATS, st));
+        a.lda = (long)S * H; a.ldb = H; a.M = B; a.N = H; a.K = H;
+        int ks_h = 1, ks_s = 1;
+        a.A = ht + (size_t)(i + 1) * H; a.B = Wg.as<float>();
+        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>() + WS_G, WS_P, st, &ks_h));
+        a.A = stt + (size_t)(i + 1) * H; a.B = Ws.as<float>();
+        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>() + WS_G + WS_P, WS_P, st, &ks_s));
+        if (ks_h != ks_s) return fail(LRP_ERR_HIP, "internal: K split of the two projections differs (%d, %d)", ks_h, ks_s);
+        ksp = ks_h; psl = (size_t)B * H;
+        hsrc = sg_ws.as<float>() + WS_G; ssrc = sg_ws.as<float>() + WS_G + WS_P;
       } else {
         LRP_HIP_CHECK((skinny<float, float, float>(ht + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
                                                    hproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
@@ -567,10 +601,10 @@ struct Decoder {
                                                    sproj.as<float>(), H, B, H, H, 0, st, KS_PROJ, pslab)));
       }
       hipLaunchKernelGGL(dec_att_scores_kernel, dim3(B, (L + 1 + ATT_ROWS - 1) / ATT_ROWS), dim3(256),
-                         (size_t)2 * H * sizeof(float), st, hproj.as<float>(), sproj.as<float>(), ksp, pslab,
+                         (size_t)2 * H * sizeof(float), st, hsrc, ssrc, ksp, psl,
                          stat.as<float>(), vvec.as<float>(), att_pre.as<float>(), L, H);
       LRP_HIP_CHECK(hipGetLastError());
-      hipLaunchKernelGGL(dec_att_finish_kernel, dim3(B), dim3(256), (size_t)(L + 8) * sizeof(float), st,
+      hipLaunchKernelGGL(dec_att_finish_kernel, dim3(B, (H + 63) / 64), dim3(64), (size_t)(L + 8) * sizeof(float), st,
                          att_pre.as<float>(), if_pre.as<float>(), ht, stt, S_<float>("attention"), S_<float>("beta"),
                          S_<double>("context"), S_<double>("c_hat"), u.as<double>(), i, Tm, L, H);
       LRP_HIP_CHECK(hipGetLastError());
@@ -917,6 +951,10 @@ struct Decoder {
   }
   DevBuf sg_ws;                                        // K-split partials of the forward's matrix-core products
   static constexpr size_t SG_WS_FLOATS = (size_t)4 << 20;
+  int need_sg_ws() {
+    if (!sg_ws.p) { int64_t dummy = 0; LRP_TRY(sg_ws.alloc(SG_WS_FLOATS * sizeof(float), &dummy)); }
+    return LRP_OK;
+  }
   static bool mfma_forward() {
     static const bool v = [] { const char* e = getenv("LRP_DEC_MFMA_FWD"); return !e || atoi(e) != 0; }();
     return v;

@@ -121,13 +121,24 @@ __global__ __launch_bounds__(256) void dec_ipre_kernel(const float* __restrict__
 }
 
 // avg[b][d] = mean_l F[b][l][d]   (np.mean(axis=0) in float32: sequential row adds, then / L; E:382)
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ F, float* __restrict__ avg, int L, int D) {
-  const int b = blockIdx.x;
-  for (int d = threadIdx.x; d < D; d += 256) {
-    float s = 0.f;
-    for (int l = 0; l < L; ++l) s += F[((size_t)b * L + l) * D + d];
-    avg[(size_t)b * D + d] = s / (float)L;
+// grid (B, ceil(D / 64)), 64 threads: one channel per thread, rows added in order; the loads of 14 rows are issued together
+// (one image, one 256-thread block walking 196 dependent rows: 55 us [MI355X])
+__global__ __launch_bounds__(64) void mean_rows_kernel(const float* __restrict__ F, float* __restrict__ avg, int L, int D) {
+  const int b = blockIdx.x, d = blockIdx.y * 64 + threadIdx.x;
+  if (d >= D) return;
+  const float* f = F + (size_t)b * L * D + d;
+  float s = 0.f;
+  constexpr int U = 14;
+  int l0 = 0;
+  for (; l0 + U <= L; l0 += U) {                        // (whole batches unconditionally: a guard per load makes hipcc wait per load)
+    float v[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) v[q] = f[(size_t)(l0 + q) * D];
+#pragma unroll
+    for (int q = 0; q < U; ++q) s += v[q];
   }
+  for (; l0 < L; ++l0) s += f[(size_t)l0 * D];
+  avg[(size_t)b * D + d] = s / (float)L;
 }
 
 // Step prologue: xh[b] = [ embedding(tok) | relu(glob_pre_b) | h_{i} ]  and xt[b][i] = first 2E   (E:386, E:402-409)
@@ -152,21 +163,37 @@ __global__ __launch_bounds__(256) void dec_prep_x_kernel(const float* __restrict
 // LSTM pointwise (E:129-138) + visual sentinel s = tanh(c) * sigmoid(x.Wx + h_prev.Wh) (E:415).
 // z[b] = [ i | f | g | o | sentinel-gate ] pre-activations (5H).  Writes state row step+1.
 __global__ __launch_bounds__(256) void dec_pointwise_kernel(const float* __restrict__ z, int ks, size_t slab,
-                                                            float* __restrict__ ht,
+                                                            const float* __restrict__ bias, float* __restrict__ ht,
                                                             float* __restrict__ ct, float* __restrict__ gt,
                                                             float* __restrict__ it, float* __restrict__ ft,
                                                             float* __restrict__ st, float* __restrict__ ot, int step,
                                                             int Tm, int H) {
+  // grid (B, ceil(H / blockDim.x)): one hidden unit per thread; the slabs of the five pre-activations are added in index
+  // order, four slabs (20 loads) requested at a time
   const int b = blockIdx.x, S = Tm + 1;
   const float* zb = z + (size_t)b * 5 * H;
   const size_t prev = ((size_t)b * S + step) * H, cur = prev + H;
-  for (int j = threadIdx.x; j < H; j += 256) {
-    float zz[5];
+  const int j = blockIdx.y * blockDim.x + threadIdx.x;
+  if (j < H) {
+    float zz[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int q = 0;
+    for (; q + 4 <= ks; q += 4) {
+      float t[4][5];
 #pragma unroll
-    for (int g = 0; g < 5; ++g) {
-      float v = zb[g * H + j];
-      for (int q = 1; q < ks; ++q) v += zb[(size_t)q * slab + g * H + j];          // split-K slabs, fixed order
-      zz[g] = v;
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int g = 0; g < 5; ++g) t[u][g] = zb[(size_t)(q + u) * slab + g * H + j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int g = 0; g < 5; ++g) zz[g] += t[u][g];
+    }
+    for (; q < ks; ++q)
+#pragma unroll
+      for (int g = 0; g < 5; ++g) zz[g] += zb[(size_t)q * slab + g * H + j];          // split-K slabs, fixed order
+    if (bias) {                                          // (slabs straight from sgemm: the bias joins after the slices, as in sgemm_reduce_kernel)
+#pragma unroll
+      for (int g = 0; g < 5; ++g) zz[g] += bias[g * H + j];
     }
     const float i_ = sigmoidf_(zz[0]), f_ = sigmoidf_(zz[1]), g_ = zz[2], o_ = sigmoidf_(zz[3]);
     const float c = f_ * ct[prev + j] + i_ * tanhf(g_);
@@ -244,13 +271,17 @@ __global__ __launch_bounds__(256) void dec_att_finish_kernel(const float* __rest
                                                              float* __restrict__ att, float* __restrict__ beta,
                                                              double* __restrict__ ctx, double* __restrict__ chat,
                                                              double* __restrict__ u, int step, int Tm, int L, int H) {
+  // grid (B, ceil(H / 64)), 64 threads: every block redoes the (cheap) soft-max over its image's L + 1 scores and owns 64
+  // channels of the context sum; block y = 0 also stores attention / beta.  [MI355X, one image: one 256-thread block per image
+  // walked L rows for two channels per thread: 20 us per step]
   extern __shared__ float fsm[];
   float* pre = fsm;
-  const int b = blockIdx.x, S = Tm + 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int l = tid; l <= L; l += 256) pre[l] = pre_g[(size_t)b * (L + 1) + l];
+  const int b = blockIdx.x, S = Tm + 1, tid = threadIdx.x, lane = tid & 63;
+  const bool first = blockIdx.y == 0;
+  for (int l = tid; l <= L; l += 64) pre[l] = pre_g[(size_t)b * (L + 1) + l];
   __syncthreads();
   const size_t row = (size_t)b * S + step + 1;
-  if (wave == 0) {
+  {
     float mx = -INFINITY;
     for (int l = lane; l < L; l += 64) mx = fmaxf(mx, pre[l]);
     mx = wave_max(mx);
@@ -267,15 +298,26 @@ __global__ __launch_bounds__(256) void dec_att_finish_kernel(const float* __rest
     for (int l = lane; l < L; l += 64) {
       const float al = expf(pre[l] - mx) / sm;
       pre[l] = al;
-      att[row * L + l] = al;
+      if (first) att[row * L + l] = al;
     }
-    if (lane == 0) { pre[L] = bt; beta[row] = bt; }
+    if (lane == 0) { pre[L] = bt; if (first) beta[row] = bt; }
   }
   __syncthreads();
   const float bt = pre[L];
-  for (int j = tid; j < H; j += 256) {
+  const int j = blockIdx.y * 64 + tid;
+  if (j < H) {
     double c = 0.0;
-    for (int l = 0; l < L; ++l) c += (double)pre[l] * (double)fmaxf(if_pre[((size_t)b * L + l) * H + j], 0.f);
+    const float* ip = if_pre + (size_t)b * L * H + j;
+    constexpr int U = 14;
+    int l0 = 0;
+    for (; l0 + U <= L; l0 += U) {
+      float v[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) v[q] = ip[(size_t)(l0 + q) * H];
+#pragma unroll
+      for (int q = 0; q < U; ++q) c += (double)pre[l0 + q] * (double)fmaxf(v[q], 0.f);
+    }
+    for (; l0 < L; ++l0) c += (double)pre[l0] * (double)fmaxf(ip[(size_t)l0 * H], 0.f);
     const float s = st[row * H + j];
     const double ch = (double)(bt * s) + (double)(1.f - bt) * c;
     ctx[row * H + j] = c;

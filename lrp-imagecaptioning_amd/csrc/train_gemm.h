@@ -213,8 +213,15 @@ inline void sgemm_launch_tile(int tm, int tn, dim3 grid, hipStream_t st, const S
 // ws / ws_floats: workspace for the K split (may be null: no split).  Tile 64 or 128 per side by the extent; the K
 // split fills the chip when the tiles alone do not (weight gradients: few tiles, K = millions of pixels; the
 // per-step products of the scan: 32 rows, a handful of tiles).
-inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st) {
+// ks_out != nullptr ("consumer-side reduction"): no reduce launch — the product is left as *ks_out slabs of M x N floats
+// (row stride N) at ws, bias NOT added; the consumer sums the slabs in index order and adds the bias, which is exactly what
+// sgemm_reduce_kernel would have done, one launch earlier.  (Needs ws; taps must be 1.)
+inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st, int* ks_out = nullptr) {
   if (a.M < 1 || a.N < 1 || a.K < 1) return hipErrorInvalidValue;
+  if (ks_out) {
+    if (!ws || (size_t)a.M * a.N > ws_floats || (a.gather && a.taps > 1) || a.accumulate) return hipErrorInvalidValue;
+    a.C = ws; a.ldc = a.N; a.bias = nullptr;           // (a single slice writes straight to slab 0)
+  }
   a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
   a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
   static const int big = [] { const char* e = getenv("LRP_SGEMM_BIG"); return e ? atoi(e) : 1; }();
@@ -253,6 +260,7 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   else return hipErrorInvalidValue;
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (ks_out) { *ks_out = ks; return e; }
   if (ks > 1 || taps > 1) {
     const size_t mn = (size_t)a.M * a.N * taps;
     const unsigned blocks = (unsigned)((mn + 255) / 256 < 4096 ? (mn + 255) / 256 : 4096);
