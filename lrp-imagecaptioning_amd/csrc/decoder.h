@@ -586,13 +586,11 @@ struct Decoder {
       if (mf) {
         SgemmArgs a{};
         a.lda = (long)S * H; a.ldb = H; a.M = B; a.N = H; a.K = H;
-        int ks_h = 1, ks_s = 1;
+        // h . Wg and s . Ws: same shape, ONE launch (the upper half of the grid's z takes the second pair)
         a.A = ht + (size_t)(i + 1) * H; a.B = Wg.as<float>();
-        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>() + WS_G, WS_P, st, &ks_h));
-        a.A = stt + (size_t)(i + 1) * H; a.B = Ws.as<float>();
-        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>() + WS_G + WS_P, WS_P, st, &ks_s));
-        if (ks_h != ks_s) return fail(LRP_ERR_HIP, "internal: K split of the two projections differs (%d, %d)", ks_h, ks_s);
-        ksp = ks_h; psl = (size_t)B * H;
+        a.A2 = stt + (size_t)(i + 1) * H; a.B2 = Ws.as<float>(); a.ws2 = sg_ws.as<float>() + WS_G + WS_P;
+        LRP_HIP_CHECK(sgemm(a, sg_ws.as<float>() + WS_G, WS_P, st, &ksp));
+        psl = (size_t)B * H;
         hsrc = sg_ws.as<float>() + WS_G; ssrc = sg_ws.as<float>() + WS_G + WS_P;
       } else {
         LRP_HIP_CHECK((skinny<float, float, float>(ht + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
@@ -758,7 +756,7 @@ struct Decoder {
         hipLaunchKernelGGL(gbx_post_kernel, dim3(n), dim3(256), 0, st, x, s);
         LRP_HIP_CHECK(hipGetLastError());
       }
-      hipLaunchKernelGGL(gbx_tail_kernel, dim3(n), dim3(256), (size_t)E * sizeof(double), st, x);
+      hipLaunchKernelGGL(gbx_tail_kernel, dim3(n, (D + 63) / 64), dim3(64), (size_t)E * sizeof(double), st, x);
       LRP_HIP_CHECK(hipGetLastError());
     } else {
       const size_t lds = (size_t)(7 * H + std::max(H, E) + E + 8) * sizeof(double);
@@ -1033,7 +1031,7 @@ struct Decoder {
         hipLaunchKernelGGL(bx_post_kernel, dim3(n), dim3(256), 0, st, x, s);
         LRP_HIP_CHECK(hipGetLastError());
       }
-      hipLaunchKernelGGL(bx_tail_kernel, dim3(n), dim3(256), (size_t)E * sizeof(double), st, x);
+      hipLaunchKernelGGL(bx_tail_kernel, dim3(n, (D + 63) / 64), dim3(64), (size_t)E * sizeof(double), st, x);
       LRP_HIP_CHECK(hipGetLastError());
     } else {
       const size_t lds = (size_t)(2 * H + std::max(H, E) + E + 8) * sizeof(double);

@@ -66,13 +66,27 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__
     }
     __syncthreads();
     if (n < N) {
-#pragma unroll 4
-      for (int kk = 0; kk < 16; ++kk) {
-        const int k = kg * 16 + kk, gk = k0 + k;
-        if (gk < Kend) {
-          const TA w = (TA)W[(size_t)gk * ldw + n];
+      if (k0 + 64 <= Kend) {
+        // whole slab: the 16 weight loads of this wave's k rows are requested together (guarding each load made hipcc
+        // branch around it and wait for it alone: a chain of 16 dependent L2 round trips per slab)
+        float wv[16];
 #pragma unroll
-          for (int r = 0; r < 32; ++r) acc[r] += xs[k][r] * w;
+        for (int kk = 0; kk < 16; ++kk) wv[kk] = W[(size_t)(k0 + kg * 16 + kk) * ldw + n];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+          const TA w = (TA)wv[kk];
+#pragma unroll
+          for (int r = 0; r < 32; ++r) acc[r] += xs[kg * 16 + kk][r] * w;
+        }
+      } else {
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+          const int k = kg * 16 + kk, gk = k0 + k;
+          if (gk < Kend) {
+            const TA w = (TA)W[(size_t)gk * ldw + n];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) acc[r] += xs[k][r] * w;
+          }
         }
       }
     }

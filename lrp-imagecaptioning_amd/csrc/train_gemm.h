@@ -29,6 +29,9 @@ struct SgemmArgs {
   int taps; long tapC;          // gather with taps = 9: blockIdx.z / ksplit = tap (dy, dx from it), C advances by tapC per tap
   int vecA, vecB;          // 16 B loads allowed (alignment checked on the host)
   const float* bias;       // optional: + bias[n] on the final result (not with accumulate)
+  // second product of the same shape in the same launch (consumer-side reduction only, sgemm(..., ks_out)): the upper half
+  // of blockIdx.z multiplies A2 . B2 into ws2 (two launch-bound products of a decoder step become one launch)
+  const float* A2; const float* B2; float* ws2;
 };
 
 constexpr int SG_BK = 16;
@@ -103,7 +106,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
   __shared__ float Bs[2][SG_BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int tap = a.taps > 1 ? (int)blockIdx.z / a.ksplit : 0, slice = a.taps > 1 ? (int)blockIdx.z % a.ksplit : (int)blockIdx.z;
+  int bz = (int)blockIdx.z;
+  if (a.A2 && bz >= a.ksplit) {                        // the second product of a paired launch
+    bz -= a.ksplit;
+    a.A = a.A2; a.B = a.B2; a.ws = a.ws2; a.C = a.ws2;
+  }
+  const int tap = a.taps > 1 ? bz / a.ksplit : 0, slice = a.taps > 1 ? bz % a.ksplit : bz;
   if (a.taps > 1) { a.dy = tap / 3 - 1; a.dx = tap % 3 - 1; }
   const long kb = (long)slice * a.kchunk;
   const long ke = kb + a.kchunk < a.K ? kb + a.kchunk : a.K;
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
     __syncthreads();
   }
   const bool partial = a.ksplit > 1 || a.taps > 1;     // through the workspace; sgemm_reduce_kernel finishes
-  float* C = partial ? a.ws + (size_t)blockIdx.z * a.M * a.N : a.C;
+  float* C = partial ? a.ws + (size_t)bz * a.M * a.N : a.C;
   const long ldc = partial ? a.N : a.ldc;
   const bool accum = partial ? false : a.accumulate != 0;
 #pragma unroll
@@ -221,6 +229,10 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   if (ks_out) {
     if (!ws || (size_t)a.M * a.N > ws_floats || (a.gather && a.taps > 1) || a.accumulate) return hipErrorInvalidValue;
     a.C = ws; a.ldc = a.N; a.bias = nullptr;           // (a single slice writes straight to slab 0)
+    if (a.A2 && (!a.B2 || !a.ws2 || !sg_aligned(a.A2, a.lda) != !sg_aligned(a.A, a.lda) || !sg_aligned(a.B2, a.ldb) != !sg_aligned(a.B, a.ldb)))
+      return hipErrorInvalidValue;                     // (the pair shares one set of launch parameters)
+  } else if (a.A2) {
+    return hipErrorInvalidValue;
   }
   a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
   a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
@@ -253,7 +265,7 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   // (the tap-folded launch always goes through the partials, also with a single K slice)
   if (taps > 1 && (!ws || (size_t)ks * a.M * a.N * taps > ws_floats)) return hipErrorInvalidValue;
   a.ksplit = ks; a.kchunk = chunk; a.ws = ws;
-  dim3 grid(gx, gy, ks * taps);
+  dim3 grid(gx, gy, ks * taps * (a.A2 ? 2 : 1));
   if (a.transA && !a.transB) sgemm_launch_tile<true, false>(tm, tn, grid, st, a);
   else if (!a.transA && !a.transB) sgemm_launch_tile<false, false>(tm, tn, grid, st, a);
   else if (!a.transA && a.transB) sgemm_launch_tile<false, true>(tm, tn, grid, st, a);
