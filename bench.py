@@ -420,17 +420,30 @@ def main():
     # Gaussian kernels average the per-weight rounding out; sparse heavy-tailed ones do not: tests/test_gpu_stress_parity.py)
     fast_block = None
     if extras and not args.no_fp32_mode and args.precision == "bf16x3":
+        from lrp_imagecaptioning_amd.calibration import calibrate_fast_mode
         pipe.reset()
+        # which layers may take the two-MFMA form is MEASURED on these weights first (calibration.py: per-layer heat-map
+        # error against the exact-fp32 mode on two images of the batch, 10x margin under the 1e-4 bar), then timed
+        cal = calibrate_fast_mode(eng, X[:2], tolerance=1e-4, margin=10.0, apply=False)
         pipe.set_precision("f16x2")
+        pipe.set_fast_layers(cal["mask"])
         kb = max(2, min(args.steps, 10))
         dtb = timed_run(2, kb)
         if not args.no_parity:
             got["f16x2"] = sampled("f16x2")
         fast_block = {"value": round(B * T * kb / dtb, 2), "unit": "heatmaps/s", "steps": kb, "warmup": 2,
                       "ms_per_step": round(dtb / kb * 1e3, 3), "dtype": "f16x2",
-                      "note": "opt-in lrp_set_precision(LRP_PREC_F16X2): ONE fp16 per weight (11 bits) in 9 of the 13 reverse "
-                              "launches; parity below is for these synthetic He-normal weights only"}
+                      "two_term_layers": cal["layers"],
+                      "calibration": {"reference": "exact-fp32 mode, same images and relevances (CNN half)",
+                                      "budget": cal["budget"], "error_of_the_mix": cal["error"], "three_mfma_floor": cal["floor"],
+                                      "per_layer_error": {k: float("%.3g" % v) for k, v in cal["per_layer"].items()},
+                                      "images": cal["n_images"], "relevance_maps": cal["n_relevances"]},
+                      "note": "opt-in lrp_set_precision(LRP_PREC_F16X2) + lrp_set_fast_layers(calibrated mask): ONE fp16 per "
+                              "weight (11 bits) in the layers listed, fp16 pairs x fp16 pairs (three MFMAs) elsewhere; the "
+                              "mask and the parity below are for THESE synthetic He-normal weights — on sparse heavy-tailed "
+                              "kernels the same calibration qualifies no layer (tests/test_gpu_calibration.py)"}
         pipe.reset()
+        pipe.set_fast_layers(None)
         pipe.set_precision(args.precision)
 
     # ---- the reference's actual call: ONE image, explain every word of its caption (explain_image.py:152-161 ->

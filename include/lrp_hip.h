@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 4
+#define LRP_ABI_VERSION 5
 
 enum {
   LRP_OK = 0,
@@ -235,6 +235,17 @@ int lrp_cnn_walk(lrp_handle* h, int32_t n, const int32_t* img_idx_host, const fl
  * arithmetic): lrp_encode_images must run again before the next explain call (LRP_ERR_STATE otherwise). */
 enum { LRP_PREC_FP32 = 0, LRP_PREC_BF16X3 = 1, LRP_PREC_BF16X3_FAST = 2, LRP_PREC_F16X2 = 3 };
 int lrp_set_precision(lrp_handle* h, int32_t mode);
+/* ABI v5.  Which conv layers take the two-MFMA form in LRP_PREC_F16X2 mode: bit li of `mask` = the reverse launch through
+ * conv li (and the forward denominators Z+ of that layer, which always follow it) reads ONE fp16 per weight; every other
+ * layer takes the three-MFMA product on fp16 pairs (22 mantissa bits on both operands — at least as exact as
+ * LRP_PREC_BF16X3).  mask = -1 restores the built-in rule (all layers up to the last pool with >= 576 products per sum);
+ * mask = 0 is "fp16 pairs, three MFMAs everywhere".  This is the hook for a per-MODEL decision: calibration.py measures,
+ * on the caller's own weights and images, the heat-map error each layer's two-term form causes against the exact-fp32
+ * mode and enables it only where the measured error leaves the requested margin below the 1e-4 bar (the rule's error
+ * depends on the weight statistics: see LRP_PREC_F16X2 above).  Layer 0 (the image layer) has no two-term form
+ * (LRP_ERR_INVALID), nor have bits beyond the configured convs.  A change drops the encode caches when the handle is in
+ * LRP_PREC_F16X2 mode (LRP_ERR_STATE from explain calls until lrp_encode_images ran again). */
+int lrp_set_fast_layers(lrp_handle* h, int64_t mask);
 
 /* Dominant-kernel timing for bench.py's roofline block: when enabled, HIP
  * events bracket every conv-LRP launch on the caller's stream; query returns

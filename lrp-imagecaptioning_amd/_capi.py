@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrp_hip.so")
 
-LRP_ABI_VERSION = 4
+LRP_ABI_VERSION = 5
 LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANGE, LRP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
 LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
@@ -47,6 +47,7 @@ SYMBOLS = {
     "lrp_cnn_explain": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), _P, _P, _P]),
     "lrp_explain_tokens": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, _P, _P, _P, _P, _P]),
     "lrp_set_precision": (C.c_int, [_P, C.c_int32]),
+    "lrp_set_fast_layers": (C.c_int, [_P, C.c_int64]),
     "lrp_profile_enable": (C.c_int, [_P, C.c_int32]),
     "lrp_profile_query": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lrp_profile_records": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),

@@ -1448,9 +1448,9 @@ inline int conv_tile_override() {
 // up to which they are used (default 128: 4x as many 64 x 64 workgroups = the 512 that are resident at once; beyond that a
 // second round of small tiles costs more than the large tiles' idle CUs [MI355X, one image, 252 large tiles: 115 -> 145 us])
 constexpr int CONV_SMALL_NS = 4;                       // LDS stages of the 64 x 64 tile's k pipeline (4 x 16 KB: two workgroups per CU... see NS)
-inline bool conv_small_tile_on() {
-  static const int v = [] { const char* e = getenv("LRP_CONV_SMALL"); return e ? atoi(e) : 1; }();
-  return v != 0;
+inline bool conv_small_tile_on() {                      // (read per launch so that a test can flip it)
+  const char* e = getenv("LRP_CONV_SMALL");
+  return !e || atoi(e) != 0;
 }
 inline long conv_small_tile_blocks() {
   static const long v = [] { const char* e = getenv("LRP_CONV_SMALL_BLOCKS"); return e ? atol(e) : 128L; }();

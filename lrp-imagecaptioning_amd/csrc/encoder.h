@@ -77,6 +77,20 @@ struct Encoder {
   const int* row2img_host = nullptr;   // host copy of the NEXT explain call's token -> image map (one-shot; lets the launcher
                                        // order the tiles so that an image's gates are fetched once, conv_igemm.h TileOrder)
   bool walk_f16 = false;   // LRP_PREC_F16X2 (opt-in): the LRP reverse walk on fp16 pairs, 2 MFMAs per product below the top block.
+  // Which layers take the two-MFMA form in that mode (reverse launch through layer li AND its forward denominators Z+_li: the
+  // two always go together).  -1 = the built-in rule (every layer up to the last pool whose sums have >= 576 products);
+  // otherwise bit li (lrp_set_fast_layers: a per-model choice, e.g. from calibration.py's measured per-layer error).
+  int64_t t2_mask_user = -1;
+  bool two_term(int li) const {
+    static const int t2env = [] { const char* e = getenv("LRP_F16_T2MASK"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
+    if (li <= 0 || li >= (int)layers.size()) return false;
+    if (t2env >= 0) return ((t2env >> li) & 1) != 0;                  // (experiments)
+    if (t2_mask_user >= 0) return ((t2_mask_user >> li) & 1) != 0;
+    int last_pool = -1;
+    for (size_t q = 0; q < layers.size(); ++q)
+      if (layers[q].pool_after) last_pool = (int)q;
+    return li <= last_pool && 9 * layers[li].cout >= 576 && 9 * layers[li].cin >= 576;   // (narrow test nets: too few products to average over)
+  }
                            // Its parity depends on the weight statistics (one fp16 per weight: worst case 2^-12 per product, above the
                            // 1e-4 bar; tests/test_gpu_stress_parity.py), so the default is the three-MFMA split-bf16 walk.
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
@@ -646,12 +660,7 @@ struct Encoder {
           // transposed conv now belong to one (slightly perturbed) network and the rounding largely cancels in R / Z+;
           // two-term Z+ in EVERY layer: 1.0e-4, the top block again.]  LRP_FWD_Z2=0: three-term everywhere.
           int fterms = 7;
-          if (cd.dual_il && walk_f16 && fwd_z2() && 9 * L.cin >= 576) {
-            int last_pool = -1;
-            for (size_t q = 0; q < layers.size(); ++q)
-              if (layers[q].pool_after) last_pool = (int)q;
-            if ((int)li <= last_pool) fterms = 23;
-          }
+          if (cd.dual_il && walk_f16 && fwd_z2() && two_term((int)li)) fterms = 23;
           LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2, fterms));
           if (top) break;
           in_pairs = emit_conv || emit_pool;
@@ -1010,16 +1019,9 @@ struct Encoder {
       // all layers three-term 2.8e-6 | two-term up to block4 3.1e-6 | two-term in block5 as well 9.7e-5 — the
       // relevance entering the top block is so concentrated that a sum has one or two dominant products and the
       // weight rounding, the same for every token, no longer averages out; profiles/r02_f16_terms_sweep.txt]
-      // LRP_F16_T2MASK (bit li = layer li takes the two-term form) overrides the rule for experiments.
-      int terms = 7;
-      if (f16 && li > 0) {
-        int last_pool = -1;
-        for (size_t q = 0; q < layers.size(); ++q)
-          if (layers[q].pool_after) last_pool = (int)q;
-        if ((int)li <= last_pool && 9 * L.cout >= 576) terms = 5;      // (narrow test nets: too few products to average over)
-        static const int t2mask = [] { const char* e = getenv("LRP_F16_T2MASK"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
-        if (t2mask >= 0) terms = ((t2mask >> li) & 1) ? 5 : 7;
-      }
+      // Encoder::two_term is that rule; lrp_set_fast_layers replaces it by a per-model mask, LRP_F16_T2MASK (experiments)
+      // overrides both.
+      const int terms = f16 && two_term(li) ? 5 : 7;
       LRP_HIP_CHECK(conv_launch(epi, ca, st, run_prec, terms));
       if (profile) {
         (void)hipEventRecord(pr.e1, st);

@@ -386,6 +386,21 @@ int lrp_set_precision(lrp_handle* h, int32_t mode) {
   });
 }
 
+int lrp_set_fast_layers(lrp_handle* h, int64_t mask) {
+  return with_handle(h, [&]() -> int {
+    if (!h) return fail(LRP_ERR_INVALID, "null handle");
+    const int nl = (int)h->enc.layers.size();
+    if (mask < -1 || (mask >= 0 && nl < 63 && (mask >> nl) != 0)) return fail(LRP_ERR_INVALID, "mask 0x%llx names layers beyond the %d convs", (unsigned long long)mask, nl);
+    if (mask >= 0 && (mask & 1)) return fail(LRP_ERR_INVALID, "layer 0 (the image layer) has no two-term form");
+    if (h->enc.t2_mask_user != mask && h->enc.walk_f16) {   // the denominators follow the walk: the caches belong to the old choice
+      LRP_TRY(h->trainer.drop_early_forward(nullptr));
+      h->enc.encoded = 0;
+    }
+    h->enc.t2_mask_user = mask;
+    return LRP_OK;
+  });
+}
+
 int lrp_profile_enable(lrp_handle* h, int32_t on) {
   return with_handle(h, [&]() -> int {
     if (!h) return fail(LRP_ERR_INVALID, "null handle");

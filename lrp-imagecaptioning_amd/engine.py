@@ -400,6 +400,20 @@ class LRPEngine(object):
             self.captions = None
         self.precision = mode
 
+    def set_fast_layers(self, mask):
+        """Which conv layers take the two-MFMA form in 'f16x2' mode (lrp_set_fast_layers): bit li of `mask`, an iterable of
+        layer indices, or None / -1 for the built-in rule.  0 = fp16 pairs with three MFMAs in every layer.  A change drops
+        the encode caches while the engine is in 'f16x2' mode.  See calibration.calibrate_fast_mode for a measured choice."""
+        if mask is None:
+            mask = -1
+        elif not isinstance(mask, int):
+            mask = sum(1 << int(li) for li in set(mask))
+        _capi.check(self._lib.lrp_set_fast_layers(self._h, int(mask)))
+        if self.precision == "f16x2" and mask != getattr(self, "fast_layers", -1):
+            self.n_images = 0
+            self.captions = None
+        self.fast_layers = mask
+
     # ------------------------------------------------------------------ profiling hooks (bench.py)
     def profile_enable(self, on=True):
         _capi.check(self._lib.lrp_profile_enable(self._h, int(bool(on))))

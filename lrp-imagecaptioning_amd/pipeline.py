@@ -45,6 +45,10 @@ class LRPPipeline(object):
         for e in self.engines:
             e.set_precision(mode)
 
+    def set_fast_layers(self, mask):
+        for e in self.engines:
+            e.set_fast_layers(mask)
+
     def explain_batch(self, images, captions, img_idx, tpos, out=None):
         """One step (encode -> decoder replay -> per-token heat-maps) on the next handle's stream; returns
         (out, slot).  The result is complete on `streams[slot]` only: before reading it on another stream call

@@ -158,3 +158,38 @@ def test_split_bf16_lrp_backward(case, mode, halo_mode):
     err = rel_l1(out, c * gate)
     report("conv_split_bwd", case=list(case), mode=mode, halo=halo_mode, rel_l1=err)
     assert err < 2e-5, err
+
+
+# ---- small grids take 64 x 64 tiles with a 4-stage k pipeline (LRP_CONV_SMALL, conv_igemm.h): every output element sees the
+# same chain of MFMAs in the same k order as with the large tiles, so the two must agree BIT FOR BIT — that is what keeps a
+# single image's heat-maps identical to the same image explained inside a batch of 32
+SMALL_CASES = [  # NB, H, W, Cin, Cout
+    (1, 14, 14, 512, 512),    # block5 of one image: 2 x 4 large tiles, K = 4608
+    (10, 14, 14, 256, 128),   # ten words: 16 x 1 large tiles
+    (1, 28, 28, 72, 64),      # N = 64 tile family, Cin not a multiple of 32
+    (2, 7, 5, 40, 192),       # ragged M, N = 192
+]
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_small_tiles_are_bit_identical_to_large_tiles(case, split, mode, monkeypatch):
+    from lrp_imagecaptioning_amd.engine import op_conv
+    NB, H, W, Cin, Cout = case
+    rs = np.random.RandomState(sum(case) + mode)
+    if mode == 1:
+        x = rs.standard_normal((NB, H, W, Cin)).astype(np.float32)
+        w = (rs.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+        args = (torch.as_tensor(x).cuda(), w, rs.standard_normal(Cout).astype(np.float32), None, 1, 9)
+    else:
+        s = rs.standard_normal((NB, H, W, Cout)).astype(np.float32)
+        w = np.abs(rs.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+        up = 2 if mode == 3 else 1
+        gate = rs.uniform(0, 1, size=(NB, up * H, up * W, Cin)).astype(np.float32)
+        args = (torch.as_tensor(s).cuda(), w, None, torch.as_tensor(gate).cuda(), mode, 9)
+    outs = {}
+    for small in ("1", "0"):
+        monkeypatch.setenv("LRP_CONV_SMALL", small)
+        outs[small] = op_conv(*args, split_bf16=split).clone()
+    assert torch.equal(outs["1"], outs["0"]), float((outs["1"] - outs["0"]).abs().max())
