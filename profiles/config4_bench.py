@@ -50,6 +50,7 @@ def main():
         n2 = 6
         ms2 = timed(lambda: [[pipe.explain_batch(X, caps, idx, tt, out=outs[pipe.next_slot]) for _ in range(n2)], pipe.synchronize()]) / n2
         print("config4 with %d handles in flight: %.2f ms/step = %.1f heat-maps/s" % (handles, ms2, B * T / ms2 * 1e3))
+    eng.decoder_explain(idx, tt, want_attention=False, want_r_words=False)     # (first call of this entry: its output tensor is allocated)
     print("config4 (grid-TD + ResNet-101, B=%d, T=%d): %.2f ms/step = %.1f heat-maps/s; encode %.2f, decoder fwd %.2f, "
           "decoder explain %.2f ms; workspace %.1f GB" % (
               B, T, ms, B * T / ms * 1e3, timed(lambda: eng.encode_images(X)), timed(lambda: eng.decoder_forward(caps)),
