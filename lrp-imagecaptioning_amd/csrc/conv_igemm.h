@@ -219,6 +219,7 @@ struct ConvArgs {
   // short — instead of over the whole stack, so that no tile straddles two tokens and the tile boundaries fall at the same
   // image rows for every token.  Tile row R of the launch covers token R / tpt, image rows (R % tpt) * th ...
   int tpt;
+  int epi_generic;             // MUL / MUL_UP2 epilogues: 1 = always the general pass loop (A/B switch LRP_EPI_FAST=0; filled by the launcher)
 };
 constexpr int ACT_MAX_SLOTS = 64;
 
@@ -1086,14 +1087,16 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
     for (int hf = 0; hf < NH; ++hf) {
       if (hf) __syncthreads();                          // previous slab fully consumed
       if ((wm * TM * 32) / RH == hf) {
+        // a wave's TM x 32 rows lie inside ONE slab (static_assert above), so their position in the slab does not depend on hf:
+        // one base address + compile-time offsets (written with `- hf * RH` hipcc kept sixteen addresses per wave alive across
+        // the main loop of the 8-wave tile, spilled them, and reloaded each behind its own s_waitcnt vmcnt(0))
+        float* cw = Cs + (((wm * TM * 32) % RH) + 4 * (lane >> 5)) * BN + wn * TN * 32 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int lr = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) - hf * RH;
+          for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) Cs[lr * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
-          }
+            for (int j = 0; j < TN; ++j) cw[(i * 32 + (r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
       }
       __syncthreads();
       if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) {
@@ -1272,6 +1275,78 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
         // pass, the possible aliasing of `out` and `aux` made hipcc serialise a full memory round trip per pass, which
         // the short K = 576 layers could not hide).
         if (col < a.N) {
+          // ---- the walk's common case (plain gate, no residual join, no second head, no gradient-walk switches): the same
+          // arithmetic with nothing to decide inside the passes.  In the general form below every runtime switch sits next to
+          // a load, hipcc branches around those loads, cannot count them any more and drains the queue (s_waitcnt vmcnt(0) /
+          // (1)) in every pass — the gate rows requested "one pass ahead" were in fact waited for immediately, and an 8-wave
+          // tile's epilogue ran as 16 dependent L2 round trips with the matrix pipe idle.  Here the gate loads of RING passes
+          // are in flight, unconditionally (padding rows read row 0 of image 0), and each pass waits with a counted vmcnt.
+          // Rows are located twice (at issue and at use: a few VALU ops) instead of keeping six arrays of NP entries alive.
+          if constexpr (PREC != PREC_F16X2) {
+            const bool tail_ = EPI == EPI_MUL && a.join != nullptr, head2_ = EPI == EPI_MUL && a.out2s != nullptr;
+            if (!(EPI == EPI_MUL && a.gate_none) && !tail_ && !head2_ && !a.gate_binary && !a.relu_out && !a.epi_generic) {
+              constexpr int NPf = RH / RPP;
+              constexpr int UPf = EPI == EPI_MUL_UP2 ? 4 : 1;
+              constexpr int RING = (UPf == 1 ? 4 : 2) < NPf ? (UPf == 1 ? 4 : 2) : NPf;
+              const int W2f = 2 * a.W, H2f = 2 * a.H;
+              int imgf[NPf];
+#pragma unroll
+              for (int ps = 0; ps < NPf; ++ps) {
+                int row, n_, h_, w_;
+                if (!locate(hf * RH + rin + ps * RPP, row, n_, h_, w_)) n_ = 0;
+                imgf[ps] = a.row2img ? a.row2img[n_] : n_;
+              }
+              f32x4 gq[RING][UPf][CW / 4];
+              auto issue = [&](int ps) {
+                int row, n_, h_, w_;
+                if (!locate(hf * RH + rin + ps * RPP, row, n_, h_, w_)) { h_ = 0; w_ = 0; }
+#pragma unroll
+                for (int q = 0; q < UPf; ++q) {
+                  const float* gp = EPI == EPI_MUL ? a.aux + ((size_t)imgf[ps] * HW + h_ * a.W + w_) * a.N + col
+                                                   : a.aux + (((size_t)imgf[ps] * H2f + 2 * h_ + (q >> 1)) * W2f + 2 * w_ + (q & 1)) * a.N + col;
+#pragma unroll
+                  for (int q4 = 0; q4 < CW / 4; ++q4) gq[ps % RING][q][q4] = *reinterpret_cast<const f32x4*>(gp + 4 * q4);
+                }
+              };
+#pragma unroll
+              for (int ps = 0; ps < RING - 1; ++ps) issue(ps);
+              const bool plain = SPLIT_OUT && a.out_plain;
+#pragma unroll
+              for (int ps = 0; ps < NPf; ++ps) {
+                if (ps + RING - 1 < NPf) issue(ps + RING - 1);
+                int row, n_, h_, w_;
+                if (locate(hf * RH + rin + ps * RPP, row, n_, h_, w_)) {
+                  const int ll = rin + ps * RPP;
+                  float v[CW];
+#pragma unroll
+                  for (int q4 = 0; q4 < CW / 4; ++q4)
+                    *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * CW + 4 * q4);
+#pragma unroll
+                  for (int q = 0; q < UPf; ++q) {
+                    float r[CW];
+#pragma unroll
+                    for (int q4 = 0; q4 < CW / 4; ++q4)
+#pragma unroll
+                      for (int e = 0; e < 4; ++e) r[4 * q4 + e] = v[4 * q4 + e] * gq[ps % RING][q][q4][e];
+                    float* dst = EPI == EPI_MUL
+                                     ? a.out + (size_t)row * a.N + col
+                                     : a.out + (((size_t)n_ * H2f + 2 * h_ + (q >> 1)) * W2f + 2 * w_ + (q & 1)) * a.N + col;
+                    if constexpr (SPLIT_OUT) {
+                      if (plain) {
+                        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+                        *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(r + 4);
+                      } else {
+                        split8_store(r, dst);
+                      }
+                    } else {
+                      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
+                    }
+                  }
+                }
+              }
+              continue;                                   // next slab
+            }
+          }
           constexpr int NP = RH / RPP;
           constexpr int UPN = EPI == EPI_MUL_UP2 ? 4 : 1;
           const int W2 = 2 * a.W, H2 = 2 * a.H;
@@ -1421,6 +1496,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
 #endif
 }
 
+#ifndef LRP_CONV_KERNEL_ONLY   // (a translation unit that wants ONE instantiation for ISA inspection defines this and skips the launchers)
 // tile configurations: (WM,WN,TM,TN) -> BM x BN
 //   big   : 2,2,2,2 -> 128 x 128   (N >= 128)                 64 KB LDS, 2 blocks/CU   [fp32]
 //   n64   : 2,2,2,1 -> 128 x  64   (N == 64 layers)           48 KB LDS, 3 blocks/CU
@@ -1604,6 +1680,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  { const char* e = getenv("LRP_EPI_FAST"); a.epi_generic = (e && atoi(e) == 0) ? 1 : 0; }
   // Small grids (one image, a handful of words: explain_image.py's own call): with 128-row tiles the 14 x 14 / 28 x 28
   // layers are 16-250 workgroups, each walking K = 2304-4608 alone — the launch takes as long as ONE tile's K loop
   // [MI355X, B = 1, T = 10: 115-119 us per block4 / block5 launch, forward and backward].  64 x 64 tiles (4 waves of
@@ -1820,5 +1897,7 @@ inline void pack_split8(const float* src, size_t n_floats, float* dst_as_float) 
       d[g * 16 + 8 + q] = f32_to_bf16_rne(x - bf16_to_f32(hi));
     }
 }
+
+#endif  // LRP_CONV_KERNEL_ONLY
 
 }  // namespace lrp
