@@ -348,9 +348,12 @@ __global__ __launch_bounds__(256) void dual_interleave_rows_kernel(const float* 
 // 2x2/2 max-pool + first-arg-max gate (pool_gate_kernel) + the pooled activations as the next conv's operand (fp16 pairs
 // scaled by scale[image]) in ONE pass over (a_l, Z+_l): replaces maxpool2_kernel + pool_gate_kernel + split_h_scaled_kernel.
 // 8 channels per thread; a may alias g; xnext (fp32 pooled activations: the fine-tune step's kept input) may be null.
+// gc / gpos (may be null): the same gate in COMPACT form — per window and channel its one non-zero value and that value's
+// position p = 2 dy + dx — for the consumer of the compact pool interface (conv_igemm.h ConvArgs::up2_gc).
 __global__ __launch_bounds__(256) void pool_gate_split_kernel(const float* a, const float* __restrict__ z, float* g,
                                                               float* __restrict__ pairs, float* __restrict__ xnext,
-                                                              const float* __restrict__ scale, int NB, int H, int W, int C) {
+                                                              const float* __restrict__ scale, int NB, int H, int W, int C,
+                                                              float* __restrict__ gc, unsigned char* __restrict__ gpos) {
   const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
   const size_t total = (size_t)NB * Ho * Wo * C8;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -396,6 +399,24 @@ __global__ __launch_bounds__(256) void pool_gate_split_kernel(const float* a, co
       for (int c = 0; c < 8; ++c) o[c] = (arg[c] == p) ? av[p][c] / safe_den(zv[p][c]) : 0.f;
       *reinterpret_cast<f32x4*>(g + off[p]) = *reinterpret_cast<const f32x4*>(o);
       *reinterpret_cast<f32x4*>(g + off[p] + 4) = *reinterpret_cast<const f32x4*>(o + 4);
+    }
+    if (gc) {
+      float o[8];
+      unsigned pw[2] = {0u, 0u};
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        float av_ = av[0][c], zv_ = zv[0][c];
+#pragma unroll
+        for (int p = 1; p < 4; ++p)
+          if (arg[c] == p) { av_ = av[p][c]; zv_ = zv[p][c]; }
+        o[c] = av_ / safe_den(zv_);                       // (the very division of the full-resolution gate above)
+        pw[c >> 2] |= (unsigned)arg[c] << (8 * (c & 3));
+      }
+      *reinterpret_cast<f32x4*>(gc + po) = *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(gc + po + 4) = *reinterpret_cast<const f32x4*>(o + 4);
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      u32x2_ pv; pv[0] = pw[0]; pv[1] = pw[1];
+      *reinterpret_cast<u32x2_*>(gpos + po) = pv;
     }
   }
 }

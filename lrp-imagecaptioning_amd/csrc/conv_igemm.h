@@ -205,6 +205,12 @@ struct ConvArgs {
   const float* up2_src;        // P  [NB][H/2][W/2][Cin] fp32
   const float* up2_gate;       // G_up [images][H][W][Cin] fp32
   int gate_none;               // EPI_MUL: out = acc (no gate: the consumer applies it, see up2_src)
+  // The pool gate in compact form as well (per-token tiles, ConvArgs::tpt > 0): gc [images][H/2][W/2][Cin] = the window's one
+  // non-zero gate value, gpos (same shape, bytes) = its position 2 dy + dx.  The prologue then walks WINDOWS instead of pixels:
+  // P, gc and gpos once per window and channel group (a quarter of the loads of the full-resolution gate, which every pixel
+  // item fetched together with the same P again) and writes the product to the one position that has it, zeros to the others.
+  const float* up2_gc;
+  const unsigned char* up2_gpos;
   // Image layer folded into the epilogue of the layer above it (weights-in-registers kernel, PREC_BF16X3, N = 64, EPI_MUL):
   // S_1 = acc x gate never goes to memory.  The tile turns it into bf16 pairs in LDS, multiplies it with the tap-expanded
   // 64 -> 54 matrix `img_w` (the image layer's T = S_1 . W, cnn_kernels.h) and applies the 9-tap shift-and-add for the
@@ -499,7 +505,78 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
   // iteration (48 MFMAs per wave on the 8-wave tile) to land — launching it at the top of iteration kc+1 instead
   // left it half of that, which the HBM / MALL latency of the A rows did not fit into in the bf16x3 mode.
   if constexpr (BREG) {
-    if (PREC == PREC_BF16X3 && a.up2_src) {
+    if (PREC == PREC_BF16X3 && a.up2_src && a.up2_gc && a.tpt > 0) {
+      // compact pool interface, compact gate: item = (window of the resident image, 8-channel group)
+      const int Hp = a.H >> 1, Wp = a.W >> 1;
+      const int h0 = Y0 - img0 * a.H;                      // the tile's first image row (tiles are per token)
+      const int wy0 = (h0 - 1) >> 1, wx0 = (x0 - 1) >> 1;  // (arithmetic shifts: -1 >> 1 = -1, the window row / column outside the image)
+      const int nwx = ((x0 + a.tw) >> 1) - wx0 + 1, nwy = ((h0 + a.th) >> 1) - wy0 + 1;
+      const int items = nwy * nwx * 8;
+      const int ntok = img0 < a.NB ? img0 : a.NB - 1;
+      const int img = a.row2img ? a.row2img[ntok] : ntok;
+      const float inv_nwx = 1.0f / (float)nwx;
+      constexpr int UW = 2;                                // items in flight per thread (4 x 16 B + 8 B of loads each)
+      typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+      for (int it0 = tid; it0 < items; it0 += NT * UW) {
+        f32x4 pv[UW][2], gv[UW][2];
+        u32x2_ qv[UW];
+        int wyv[UW], wxv[UW], cgv[UW];
+        bool okv[UW];
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          const int item = it0 + u * NT;
+          const int cg = item & 7, wdx = item >> 3;
+          int wr, wc;
+          divmod(wdx, nwx, inv_nwx, wr, wc);
+          const int wy = wy0 + wr, wx = wx0 + wc;
+          cgv[u] = cg; wyv[u] = wy; wxv[u] = wx;
+          okv[u] = item < items && wy >= 0 && wy < Hp && wx >= 0 && wx < Wp && cg * 8 < a.Cin;
+          // unconditional loads from a clamped (always valid) window; the values of an invalid item are zeroed below
+          const int wyc = wy < 0 ? 0 : (wy >= Hp ? Hp - 1 : wy), wxc = wx < 0 ? 0 : (wx >= Wp ? Wp - 1 : wx);
+          const int cgc = cg * 8 < a.Cin ? cg : 0;
+          const size_t wo = ((size_t)wyc * Wp + wxc) * a.Cin + cgc * 8;
+          const float* pp = a.up2_src + (size_t)ntok * Hp * Wp * a.Cin + wo;
+          const float* gp = a.up2_gc + (size_t)img * Hp * Wp * a.Cin + wo;
+          pv[u][0] = *reinterpret_cast<const f32x4*>(pp); pv[u][1] = *reinterpret_cast<const f32x4*>(pp + 4);
+          gv[u][0] = *reinterpret_cast<const f32x4*>(gp); gv[u][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+          qv[u] = *reinterpret_cast<const u32x2_*>(a.up2_gpos + (size_t)img * Hp * Wp * a.Cin + wo);
+        }
+#pragma unroll
+        for (int u = 0; u < UW; ++u) {
+          if (it0 + u * NT >= items) continue;
+          float r[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { r[e] = pv[u][0][e] * gv[u][0][e]; r[4 + e] = pv[u][1][e] * gv[u][1][e]; }
+          bf16x8 hi, lo;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float rq = okv[u] ? r[q] : 0.f;
+            hi[q] = (__bf16)rq;
+            lo[q] = (__bf16)(rq - (float)hi[q]);
+          }
+          const u32x4 hiw = __builtin_bit_cast(u32x4, hi), low = __builtin_bit_cast(u32x4, lo);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {                    // the window's four pixels: position j = 2 dy + dx
+            const int hy = 2 * wyv[u] + (j >> 1) - (h0 - 1), hx = 2 * wxv[u] + (j & 1) - (x0 - 1);
+            if (hy < 0 || hy >= a.hrows || hx < 0 || hx >= HALO_PITCH) continue;
+            // 16-bit lane c of a dword pair keeps its value iff channel c's arg-max sits at position j
+            u32x4 mh, ml;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const unsigned p0 = (qv[u][d >> 1] >> (16 * (d & 1))) & 0xFFu, p1 = (qv[u][d >> 1] >> (16 * (d & 1) + 8)) & 0xFFu;
+              const unsigned m = (p0 == (unsigned)j ? 0x0000FFFFu : 0u) | (p1 == (unsigned)j ? 0xFFFF0000u : 0u);
+              mh[d] = hiw[d] & m;
+              ml[d] = low[d] & m;
+            }
+            const int row = hy * HALO_PITCH + hx;
+            const int swzu = ((hy * a.tw + hx - 1) >> 1) & 7;
+            const int dst = (cgv[u] >> 2) * STAGE + row * LDS_STRIDE + (((2 * (cgv[u] & 3)) ^ swzu) << 2);
+            *reinterpret_cast<u32x4*>(smem + dst) = mh;
+            *reinterpret_cast<u32x4*>(smem + (dst ^ 4)) = ml;
+          }
+        }
+      }
+    } else if (PREC == PREC_BF16X3 && a.up2_src) {
       // compact pool interface: resident image = P (pooled resolution) x pool gate, built here through registers.
       // item = (LDS row, 8-channel group of the 64 channels); chunk cc = group / 4 goes to LDS buffer cc.
       const int Hp = a.H >> 1, Wp = a.W >> 1;

@@ -44,6 +44,10 @@ struct ConvLayer {
   DevBuf bias;
   DevBuf G;        // [max_images][H][W][cout] relevance gate (not for the top layer)
   DevBuf P;        // [max_images][H/2][W/2][cout] pooled activations (pool_after layers; overlapped encode)
+  // the gate of a pooled layer in COMPACT form (value + position per window and channel), for the consumer of the compact
+  // pool interface; written by pool_gate_split_kernel, valid for the encode whose number gc_epoch holds
+  DevBuf Gc, Gpos;
+  long gc_epoch = -1;
   std::vector<float> raw_w, raw_b;   // host copies as set (HWIO / (cout,)): the fine-tune step's master weights start here
   DevBuf raw_w_dev, raw_b_dev;       // the same when the weights arrived through lrp_set_weight_dev (no host copy exists then)
   DevBuf fnorm;    // {largest absolute row sum of w, max|b|}: bound behind the scale of the pairs this layer emits (fwd_scale_kernel)
@@ -213,6 +217,13 @@ struct Encoder {
     LRP_TRY(s0.alloc(NT * max_tok_act * sizeof(float), total));
     LRP_TRY(s1.alloc(NT * max_tok_act * sizeof(float), total));
     for (size_t i = 0; i + 1 < layers.size(); ++i) LRP_TRY(layers[i].G.alloc(B * layers[i].act_elems() * sizeof(float), total));
+    for (size_t i = 0; i + 1 < layers.size(); ++i) {
+      ConvLayer& Lc = layers[i];                         // (the condition of Encoder::explain for the compact interface, weights aside)
+      if (Lc.pool_after && Lc.cin <= 64 && conv_cinp(Lc.cout) <= 64 && !(Lc.cout & 7) && !(Lc.H & 1) && !(Lc.W & 1)) {
+        LRP_TRY(Lc.Gc.alloc(B * Lc.act_elems() / 4 * sizeof(float), total));
+        LRP_TRY(Lc.Gpos.alloc(B * Lc.act_elems() / 4, total));
+      }
+    }
     for (size_t i = 0; i + 1 < layers.size(); ++i)
       if (layers[i].pool_after) LRP_TRY(layers[i].P.alloc(B * layers[i].act_elems() / 4 * sizeof(float), total));
     {
@@ -549,9 +560,11 @@ struct Encoder {
   }
 
   // ---- forward once per image -------------------------------------------------------------
+  long encode_epoch = 0;   // bumped by every encode: a layer's compact gate is current iff its gc_epoch equals this
   int encode(const float* images_dev, int B, hipStream_t st) {
     if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
     LRP_TRY(check_ready());
+    ++encode_epoch;
     const size_t img_elems = (size_t)img_h * img_w * 3;
     if (gates_pending) {                               // the previous encode's side work still owns G / bufZ / bufXs
       LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));
@@ -671,7 +684,9 @@ struct Encoder {
             if (emit_pool) {
               // pooled activations as pairs (and fp32 only where the fine-tune step looks for them), arg-max gate: one pass
               hipLaunchKernelGGL(pool_gate_split_kernel, dim3(stream_grid(n / 32)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
-                                 L.G.as<float>(), pin, keep_acts ? L.P.as<float>() : (float*)nullptr, oscale_of(li), B, L.H, L.W, L.cout);
+                                 L.G.as<float>(), pin, keep_acts ? L.P.as<float>() : (float*)nullptr, oscale_of(li), B, L.H, L.W, L.cout,
+                                 L.Gc.as<float>(), L.Gpos.as<unsigned char>());
+              if (L.Gc.p) layers[li].gc_epoch = encode_epoch;
             } else {
               hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);
               hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
@@ -1000,6 +1015,10 @@ struct Encoder {
         }
         if (compact_in) {                                 // this layer reads the compact form its producer left
           ca.up2_src = S; ca.up2_gate = L.G.as<float>();     // (ca.in = S stays a valid pointer; it is not read)
+          static const bool gc_on = [] { const char* e = getenv("LRP_UP2_GC"); return !e || atoi(e) != 0; }();
+          if (gc_on && L.Gc.p && L.gc_epoch == encode_epoch) {   // ... with the gate in compact form too (per-token tiles only)
+            ca.up2_gc = L.Gc.as<float>(); ca.up2_gpos = L.Gpos.as<unsigned char>();
+          }
           compact_in = false;
         }
         // does THIS launch write the compact form?  Its consumer is layer li - 1 (N = P.cin, at 2x this resolution)
