@@ -219,7 +219,8 @@ struct Encoder {
     for (size_t i = 0; i + 1 < layers.size(); ++i) LRP_TRY(layers[i].G.alloc(B * layers[i].act_elems() * sizeof(float), total));
     for (size_t i = 0; i + 1 < layers.size(); ++i) {
       ConvLayer& Lc = layers[i];                         // (the condition of Encoder::explain for the compact interface, weights aside)
-      if (Lc.pool_after && Lc.cin <= 64 && conv_cinp(Lc.cout) <= 64 && !(Lc.cout & 7) && !(Lc.H & 1) && !(Lc.W & 1)) {
+      if (Lc.pool_after && !(Lc.cout & 7) && !(Lc.H & 1) && !(Lc.W & 1) &&
+          ((Lc.cin <= 64 && conv_cinp(Lc.cout) <= 64) || conv_takes_pw(Lc.cin, Lc.H, Lc.W))) {
         LRP_TRY(Lc.Gc.alloc(B * Lc.act_elems() / 4 * sizeof(float), total));
         LRP_TRY(Lc.Gpos.alloc(B * Lc.act_elems() / 4, total));
       }
@@ -1026,6 +1027,14 @@ struct Encoder {
             !(P.cout & 7) && conv_takes_breg(P.cin, P.H, P.W, P.w_bwd_frag.p != nullptr)) {
           epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
           compact_in = true;
+        } else if (P.pool_after && up2_on && split && !f16 && walk == 0 && !layer_hook && li >= 2 && !(P.cout & 7) && P.Gc.p &&
+                   P.gc_epoch == encode_epoch && conv_takes_pw(P.cin, P.H, P.W)) {
+          // ... or by the pipelined 128 x 128 halo kernel's window loader (needs the compact gate of this encode)
+          static const bool gc_on2 = [] { const char* e = getenv("LRP_UP2_GC"); return !e || atoi(e) != 0; }();
+          if (gc_on2) {
+            epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
+            compact_in = true;
+          }
         }
       }
       ProfileRec pr{};
