@@ -211,6 +211,9 @@ struct ConvArgs {
   // item fetched together with the same P again) and writes the product to the one position that has it, zeros to the others.
   const float* up2_gc;
   const unsigned char* up2_gpos;
+  // up2_pairs = 1 (pipelined halo kernels): up2_src holds S_c = acc x compact gate at pooled resolution as bf16 pairs (its
+  // producer ran EPI_MUL with the COMPACT gate as its gate): the consumer needs only the position bytes
+  int up2_pairs;
   // Image layer folded into the epilogue of the layer above it (weights-in-registers kernel, PREC_BF16X3, N = 64, EPI_MUL):
   // S_1 = acc x gate never goes to memory.  The tile turns it into bf16 pairs in LDS, multiplies it with the tap-expanded
   // 64 -> 54 matrix `img_w` (the image layer's T = S_1 . W, cnn_kernels.h) and applies the 9-tap shift-and-add for the
@@ -504,73 +507,76 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
   // has finished reading buffer kc&1) and is waited for at the barrier of iteration kc+1, so a load has a whole
   // iteration (48 MFMAs per wave on the 8-wave tile) to land — launching it at the top of iteration kc+1 instead
   // left it half of that, which the HBM / MALL latency of the A rows did not fit into in the bf16x3 mode.
-  // ---- compact pool interface in the PIPELINED halo kernel (!BREG; block2_conv2 behind block3_conv1): the resident image of
-  // the next channel chunk is built from (P, compact gate) through registers while the current chunk's taps run, instead of
-  // arriving by DMA from the 4x-expanded tensor.  One (window, 8-channel group) item per thread and chunk — the launcher
-  // checks that the tile's windows x 4 groups fit the block — loaded right after the barrier of tap 5, written to the other
-  // A buffer before the barrier of tap 7 (two barriers before the first read).  Per-token tiles (tpt > 0) as in the BREG form.
+  // ---- compact pool interface in the PIPELINED halo kernels (!BREG; ConvArgs::up2_pairs): the producer has written
+  // S_c = acc x (compact gate) at POOLED resolution as bf16 pairs, and the resident image of the next channel chunk is built
+  // from (S_c, position bytes) through registers while the current chunk's taps run, instead of arriving by DMA from the
+  // 4x-expanded, 75 %-zero tensor.  Item = (resident row, window column, 8-channel group): it loads its window's pairs
+  // (32 B) and position bytes (8 B) and writes the row's two pixels of that window — the value where the position matches,
+  // zeros elsewhere (and zeros for separator rows / rows outside the stack).  At most two items per thread and chunk (the
+  // launcher checks), handled one after the other so that only ten registers are in flight: item 0 is loaded right after
+  // the barrier of tap 3 and written before the barrier of tap 5, item 1 after tap 5 / before tap 7; every write is two
+  // barriers ahead of the chunk's first read, into the A buffer last read a chunk ago.  Works on stack tiles and per-token tiles.
   typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
-  struct PwItem { f32x4 p0, p1, g0, g1; u32x2w q; };
+  struct PwItem { u32x4 hi, lo; u32x2w q; };
   [[maybe_unused]] const bool pw = HALO && !BREG && PREC == PREC_BF16X3 && a.up2_src != nullptr;
-  [[maybe_unused]] bool pw_act = false, pw_ok = false;
-  [[maybe_unused]] int pw_wy = 0, pw_wx = 0, pw_g = 0, pw_h0 = 0;
-  [[maybe_unused]] const float* pw_p = nullptr;
-  [[maybe_unused]] const float* pw_gc = nullptr;
-  [[maybe_unused]] const unsigned char* pw_q = nullptr;
+  [[maybe_unused]] int pw_wx0 = 0, pw_nwx = 1, pw_items = 0, pw_ri0 = 0, pw_ri1 = 0;
+  [[maybe_unused]] float pw_inv_nwx = 1.f;
   if constexpr (HALO && !BREG && PREC == PREC_BF16X3) {
     if (pw) {
-      const int Hp = a.H >> 1, Wp = a.W >> 1;
-      pw_h0 = Y0 - img0 * a.H;
-      const int wy0 = (pw_h0 - 1) >> 1, wx0 = (x0 - 1) >> 1;
-      const int nwx = ((x0 + a.tw) >> 1) - wx0 + 1, nwy = ((pw_h0 + a.th) >> 1) - wy0 + 1;
-      pw_act = tid < nwy * nwx * 4;
-      int wr, wc;
-      divmod(tid >> 2, nwx, 1.0f / (float)nwx, wr, wc);
-      pw_wy = wy0 + wr; pw_wx = wx0 + wc; pw_g = tid & 3;
-      pw_ok = pw_act && pw_wy >= 0 && pw_wy < Hp && pw_wx >= 0 && pw_wx < Wp;
-      const int wyc = pw_wy < 0 ? 0 : (pw_wy >= Hp ? Hp - 1 : pw_wy), wxc = pw_wx < 0 ? 0 : (pw_wx >= Wp ? Wp - 1 : pw_wx);
-      const int ntok = img0 < a.NB ? img0 : a.NB - 1;
-      const int img = a.row2img ? a.row2img[ntok] : ntok;
-      const size_t wo = ((size_t)wyc * Wp + wxc) * a.Cin + pw_g * 8;
-      pw_p = a.up2_src + (size_t)ntok * Hp * Wp * a.Cin + wo;
-      pw_gc = a.up2_gc + (size_t)img * Hp * Wp * a.Cin + wo;
-      pw_q = a.up2_gpos + (size_t)img * Hp * Wp * a.Cin + wo;
+      pw_wx0 = (x0 - 1) >> 1;                           // (arithmetic shift: the window column outside the image for x0 = 0)
+      pw_nwx = ((x0 + a.tw) >> 1) - pw_wx0 + 1;
+      pw_inv_nwx = 1.0f / (float)pw_nwx;
+      pw_items = a.hrows * pw_nwx * 4;
+      pw_ri0 = a.row2img ? a.row2img[img0 < a.NB ? img0 : a.NB - 1] : img0;
+      pw_ri1 = a.row2img ? a.row2img[img0 + 1 < a.NB ? img0 + 1 : a.NB - 1] : img0 + 1;
     }
   }
-  [[maybe_unused]] auto pw_load = [&](PwItem& w, int chunk) {      // (unconditional: an invalid item reads a clamped window, zeroed at the store)
-    const int co = (chunk << 5) + pw_g * 8 < a.Cin ? (chunk << 5) : 0;
-    w.p0 = *reinterpret_cast<const f32x4*>(pw_p + co); w.p1 = *reinterpret_cast<const f32x4*>(pw_p + co + 4);
-    w.g0 = *reinterpret_cast<const f32x4*>(pw_gc + co); w.g1 = *reinterpret_cast<const f32x4*>(pw_gc + co + 4);
-    w.q = *reinterpret_cast<const u32x2w*>(pw_q + co);
+  struct PwPos { const float* sp; const unsigned char* qp; bool valid; int hy, wx, g, dy; };
+  [[maybe_unused]] auto pw_locate = [&](int it, int chunk) {
+    PwPos r;
+    r.g = it & 3;
+    int wxi;
+    divmod(it >> 2, pw_nwx, pw_inv_nwx, r.hy, wxi);
+    r.wx = pw_wx0 + wxi;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+    const int E = Y0 + img0 - 1 + r.hy;
+    int n, h;
+    divmod(E < 0 ? 0 : E, a.H + 1, inv_H1, n, h);
+    r.valid = it < pw_items && E >= 0 && h < a.H && n < a.NB && r.wx >= 0 && r.wx < Wp && (chunk << 5) + r.g * 8 < a.Cin;
+    r.dy = h & 1;
+    // unconditional loads from a clamped (always valid) place; an invalid item's values are zeroed at the store
+    const int nc = r.valid ? n : 0, wyc = r.valid ? (h >> 1) : 0, wxc = r.valid ? r.wx : 0, co = r.valid ? (chunk << 5) + r.g * 8 : 0;
+    const int rel = nc - img0;
+    const int img = rel == 0 ? pw_ri0 : rel == 1 ? pw_ri1 : (a.row2img ? a.row2img[nc] : nc);
+    r.sp = a.up2_src + (((size_t)nc * Hp + wyc) * Wp + wxc) * a.Cin + co;
+    r.qp = a.up2_gpos + (((size_t)img * Hp + wyc) * Wp + wxc) * a.Cin + co;
+    return r;
   };
-  [[maybe_unused]] auto pw_store = [&](const PwItem& w, int chunk, int abuf) {
-    const bool ok = pw_ok && (chunk << 5) + pw_g * 8 < a.Cin;
-    float r[8];
+  [[maybe_unused]] auto pw_load = [&](PwItem& w, int it, int chunk) {
+    const PwPos r = pw_locate(it, chunk);
+    w.hi = *reinterpret_cast<const u32x4*>(r.sp);
+    w.lo = *reinterpret_cast<const u32x4*>(r.sp + 4);
+    w.q = *reinterpret_cast<const u32x2w*>(r.qp);
+  };
+  [[maybe_unused]] auto pw_store = [&](const PwItem& w, int it, int chunk, int abuf) {
+    if (it >= pw_items) return;
+    const PwPos r = pw_locate(it, chunk);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { r[e] = w.p0[e] * w.g0[e]; r[4 + e] = w.p1[e] * w.g1[e]; }
-    bf16x8 hi, lo;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float rq = ok ? r[q] : 0.f;
-      hi[q] = (__bf16)rq;
-      lo[q] = (__bf16)(rq - (float)hi[q]);
-    }
-    const u32x4 hiw = __builtin_bit_cast(u32x4, hi), low = __builtin_bit_cast(u32x4, lo);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int hy = 2 * pw_wy + (j >> 1) - (pw_h0 - 1), hx = 2 * pw_wx + (j & 1) - (x0 - 1);
-      if (hy < 0 || hy >= a.hrows || hx < 0 || hx >= HALO_PITCH) continue;
+    for (int dx = 0; dx < 2; ++dx) {
+      const int hx = 2 * r.wx + dx - (x0 - 1);
+      if (hx < 0 || hx >= HALO_PITCH) continue;
+      const unsigned j = (unsigned)((r.dy << 1) | dx);  // this pixel's position in its window
       u32x4 mh, ml;
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int d = 0; d < 4; ++d) {                       // 16-bit lane c keeps its value iff channel c's arg-max sits at position j
         const unsigned p0 = (w.q[d >> 1] >> (16 * (d & 1))) & 0xFFu, p1 = (w.q[d >> 1] >> (16 * (d & 1) + 8)) & 0xFFu;
-        const unsigned m = (p0 == (unsigned)j ? 0x0000FFFFu : 0u) | (p1 == (unsigned)j ? 0xFFFF0000u : 0u);
-        mh[d] = hiw[d] & m;
-        ml[d] = low[d] & m;
+        const unsigned m = r.valid ? ((p0 == j ? 0x0000FFFFu : 0u) | (p1 == j ? 0xFFFF0000u : 0u)) : 0u;
+        mh[d] = w.hi[d] & m;
+        ml[d] = w.lo[d] & m;
       }
-      const int row = hy * HALO_PITCH + hx;
-      const int swzu = ((hy * a.tw + hx - 1) >> 1) & 7;
-      const int dst = abuf * STAGE + row * LDS_STRIDE + (((2 * pw_g) ^ swzu) << 2);
+      const int row = r.hy * HALO_PITCH + hx;
+      const int swzu = ((r.hy * a.tw + hx - 1) >> 1) & 7;
+      const int dst = abuf * STAGE + row * LDS_STRIDE + (((2 * r.g) ^ swzu) << 2);
       *reinterpret_cast<u32x4*>(smem + dst) = mh;
       *reinterpret_cast<u32x4*>(smem + (dst ^ 4)) = ml;
     }
@@ -708,7 +714,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
   } else {
     if constexpr (HALO) {
       if (pw) {
-        if (pw_act) { pw_load(pwi, 0); pw_store(pwi, 0, 0); }
+        pw_load(pwi, tid, 0); pw_store(pwi, tid, 0, 0);
+        if (tid + NT < pw_items) { pw_load(pwi, tid + NT, 0); pw_store(pwi, tid + NT, 0, 0); }
       } else {
         for (int p = wave_s; p < halo_np; p += NW) fire_halo_piece(prep_halo_piece(p, 0, true), p, 0);
         if (wave_s < halo_np) fire_halo_piece(prep_halo_piece(wave_s, 1, cpt > 1), wave_s, 1);   // slot 0 of chunk 1 (see the loop)
@@ -972,7 +979,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
       if (++ctap == 9) { ctap = 0; ++ccc; }
       if (pw) {
         hpp = -1;
-        if (ctap == 7 && ccc + 1 < cpt && pw_act) pw_store(pwi, ccc + 1, (ccc & 1) ^ 1);
+        if (ccc + 1 < cpt) {
+          if (ctap == 5) pw_store(pwi, tid, ccc + 1, (ccc & 1) ^ 1);
+          else if (ctap == 7) pw_store(pwi, tid + NT, ccc + 1, (ccc & 1) ^ 1);
+        }
       } else {
         hpp = ctap * NW + wave_s;
         if (hpp >= halo_np) hpp = -1;
@@ -983,7 +993,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
     fire_chunk(cp, buf);
     if constexpr (HALO) {
       if (pw) {
-        if (ctap == 5 && ccc + 1 < cpt && pw_act) pw_load(pwi, ccc + 1);
+        if (ccc + 1 < cpt) {
+          if (ctap == 3) pw_load(pwi, tid, ccc + 1);
+          else if (ctap == 5 && tid + NT < pw_items) pw_load(pwi, tid + NT, ccc + 1);
+        }
       } else if (hpp >= 0 && more && ccc + 1 < cpt) fire_halo_piece(hp, hpp, (ccc & 1) ^ 1);
     }
     // keep the MFMAs below the DMA launch: without this the compiler hoists all of them above it (they do not
@@ -1724,15 +1737,19 @@ inline bool conv_takes_breg(int n_out, int H, int W, bool have_frag) {
   return conv_halo_geom(128, H, W, tw, th, hrows) >= 0.9f;
 }
 
-// Would a 3x3 MUL launch with N = n_out on H x W take the pipelined 128 x 128 halo kernel AND fit its window loader of the
-// compact pool interface (one (window, 8-channel group) item per thread and channel chunk)?  LRP_UP2_PW=0 disables.
-inline bool conv_takes_pw(int n_out, int H, int W) {
+// Would a split-bf16 3x3 MUL launch (N = n_out columns, NB x H x W rows) take a pipelined halo kernel — 128 x 128 or the 8-wave
+// 256 x 256 — and fit its loader of the compact pool interface (two items per thread and channel chunk)?  Mirrors the tile
+// choice of conv_launch_epi; LRP_UP2_PW=0 disables.
+inline bool conv_takes_pw(int n_out, int NB, int H, int W) {
   static const int on = [] { const char* e = getenv("LRP_UP2_PW"); return e ? atoi(e) : 1; }();
-  if (!on || conv_halo_mode() <= 0 || conv_pick_tile(n_out).BN != 128 || (n_out % 256) == 0 || (H & 1) || (W & 1)) return false;
+  if (!on || conv_halo_mode() <= 0 || conv_pick_tile(n_out).BN != 128 || (H & 1) || (W & 1)) return false;
+  const long mrows = (long)NB * H * W;
+  int BM = 128, threads = 256;
+  if ((n_out % 256) == 0 && conv_tile_override() != 1 && conv_tile_override() != 128 && ((mrows + 255) / 256) * (n_out / 256) >= 400) { BM = 256; threads = 512; }
+  if (BM == 128 && conv_small_tile_on() && ((mrows + 127) / 128) * ((n_out + 127) / 128) <= conv_small_tile_blocks()) return false;
   int tw, th, hrows;
-  if (conv_halo_geom(128, H, W, tw, th, hrows) < 0.9f) return false;
-  const int nwy = (th + 2) / 2 + 1, nwx = (tw + 2) / 2 + 1;       // windows a (th + 2) x (tw + 2) resident image can touch
-  return nwy * nwx * 4 <= 256;
+  if (conv_halo_geom(BM, H, W, tw, th, hrows) < 0.9f) return false;
+  return hrows * ((tw + 2) / 2 + 1) * 4 <= 2 * threads;
 }
 
 // device table of a.order for this call's token -> image map (see TileOrder); nullptr when the stack order is as good
@@ -1890,22 +1907,10 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     }
     if (a.img_part) return hipErrorInvalidValue;     // the folded image layer exists for the weights-in-registers kernel only
     if (a.up2_src) {
-      // compact pool interface into the pipelined 128 x 128 halo kernel (conv_takes_pw): per-token tiles, window loader
-      if constexpr ((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && PREC == PREC_BF16X3 && TERMS == 7) {
-        if (!a.up2_gc || !a.up2_gpos || a.taps != 9 || !conv_takes_pw(a.N, a.H, a.W)) return hipErrorInvalidValue;
-        (void)conv_halo_geom(128, a.H, a.W, a.tw, a.th, a.hrows);
-        a.nyh = a.NB * a.H;
-        a.cols_t = (a.W + a.tw - 1) / a.tw;
-        a.tpt = (a.H + a.th - 1) / a.th;
-        a.hrows = a.th + 2;
-        a.m_tiles = a.NB * a.tpt * a.cols_t;
-        a.n_tiles = (a.N + 127) / 128;
-        a.tile_map = conv_tile_order(a, st);
-        hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true, false, TERMS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
-        return hipGetLastError();
-      } else {
+      // compact pool interface into a pipelined halo kernel (ConvArgs::up2_pairs): the launch must reach one (conv_takes_pw)
+      if (!((EPI == EPI_MUL || EPI == EPI_MUL_UP2) && PREC == PREC_BF16X3 && TERMS == 7) || !a.up2_pairs || !a.up2_gpos || a.taps != 9 ||
+          !conv_takes_pw(a.N, a.NB, a.H, a.W))
         return hipErrorInvalidValue;
-      }
     }
     if (small_tile) {
       a.m_tiles = (a.M + 63) / 64;

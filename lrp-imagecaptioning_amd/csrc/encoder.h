@@ -220,7 +220,7 @@ struct Encoder {
     for (size_t i = 0; i + 1 < layers.size(); ++i) {
       ConvLayer& Lc = layers[i];                         // (the condition of Encoder::explain for the compact interface, weights aside)
       if (Lc.pool_after && !(Lc.cout & 7) && !(Lc.H & 1) && !(Lc.W & 1) &&
-          ((Lc.cin <= 64 && conv_cinp(Lc.cout) <= 64) || conv_takes_pw(Lc.cin, Lc.H, Lc.W))) {
+          ((Lc.cin <= 64 && conv_cinp(Lc.cout) <= 64) || conv_pick_tile(Lc.cin).BN == 128)) {
         LRP_TRY(Lc.Gc.alloc(B * Lc.act_elems() / 4 * sizeof(float), total));
         LRP_TRY(Lc.Gpos.alloc(B * Lc.act_elems() / 4, total));
       }
@@ -956,7 +956,7 @@ struct Encoder {
     // loads), block1_conv2 3.87 -> 4.14 ms (its prologue now multiplies and splits in registers instead of a plain LDS-DMA),
     // walk 26.3 -> 25.7-25.9 ms; heat-map parity unchanged].  LRP_UP2_COMPACT=0 disables.
     static const bool up2_on = [] { const char* e = getenv("LRP_UP2_COMPACT"); return !e || atoi(e) != 0; }();
-    bool compact_in = false;                             // S (the current layer's input) is in the compact form
+    int compact_in = 0;                                  // S (the current layer's input) is in a compact form: 1 fp32 P (BREG consumer), 2 pairs of S_c (pipelined consumer)
     int fold_tw = 0, fold_th = 0;
     // Image layer folded into the epilogue of the layer above it (ConvArgs::img_part): S_1 — 4.1 GB written, 4.5 GB read at
     // the bench configuration — never goes to memory; per tile 160 positions x 6 partial sums do, and a streaming pass
@@ -1014,27 +1014,28 @@ struct Encoder {
           (void)conv_halo_geom(128, L.H, L.W, fold_tw, fold_th, hr_);
           ca.img_w = P.w_bwd_s.as<float>(); ca.img_part = Snext; ca.out = nullptr;
         }
-        if (compact_in) {                                 // this layer reads the compact form its producer left
+        if (compact_in == 2) {                            // pairs of S_c at pooled resolution: the pipelined kernels' loader
+          ca.up2_src = S; ca.up2_pairs = 1; ca.up2_gpos = L.Gpos.as<unsigned char>();
+          compact_in = 0;
+        } else if (compact_in) {                          // this layer reads the compact form its producer left
           ca.up2_src = S; ca.up2_gate = L.G.as<float>();     // (ca.in = S stays a valid pointer; it is not read)
           static const bool gc_on = [] { const char* e = getenv("LRP_UP2_GC"); return !e || atoi(e) != 0; }();
           if (gc_on && L.Gc.p && L.gc_epoch == encode_epoch) {   // ... with the gate in compact form too (per-token tiles only)
             ca.up2_gc = L.Gc.as<float>(); ca.up2_gpos = L.Gpos.as<unsigned char>();
           }
-          compact_in = false;
+          compact_in = 0;
         }
         // does THIS launch write the compact form?  Its consumer is layer li - 1 (N = P.cin, at 2x this resolution)
         if (P.pool_after && up2_on && split && !f16 && walk == 0 && !layer_hook && li >= 2 && P.cin <= 64 && conv_cinp(P.cout) <= 64 &&
             !(P.cout & 7) && conv_takes_breg(P.cin, P.H, P.W, P.w_bwd_frag.p != nullptr)) {
           epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
-          compact_in = true;
+          compact_in = 1;
         } else if (P.pool_after && up2_on && split && !f16 && walk == 0 && !layer_hook && li >= 2 && !(P.cout & 7) && P.Gc.p &&
-                   P.gc_epoch == encode_epoch && conv_takes_pw(P.cin, P.H, P.W)) {
-          // ... or by the pipelined 128 x 128 halo kernel's window loader (needs the compact gate of this encode)
-          static const bool gc_on2 = [] { const char* e = getenv("LRP_UP2_GC"); return !e || atoi(e) != 0; }();
-          if (gc_on2) {
-            epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
-            compact_in = true;
-          }
+                   P.gc_epoch == encode_epoch && conv_takes_pw(P.cin, n, P.H, P.W)) {
+          // ... or by a pipelined halo kernel (ConvArgs::up2_pairs): this launch multiplies with the consumer's COMPACT gate
+          // (one value per window and channel, at this layer's resolution) and writes S_c as pairs at pooled resolution
+          epi = EPI_MUL; ca.aux = P.Gc.as<float>();
+          compact_in = 2;
         }
       }
       ProfileRec pr{};
