@@ -583,8 +583,9 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
   };
   [[maybe_unused]] PwItem pwi{};
   if constexpr (BREG) {
-    if (PREC == PREC_BF16X3 && a.up2_src && a.up2_gc && a.tpt > 0) {
+    if (PREC == PREC_BF16X3 && a.up2_src && (a.up2_gc || a.up2_pairs) && a.up2_gpos && a.tpt > 0) {
       // compact pool interface, compact gate: item = (window of the resident image, 8-channel group)
+      const bool pairs = a.up2_pairs != 0;
       const int Hp = a.H >> 1, Wp = a.W >> 1;
       const int h0 = Y0 - img0 * a.H;                      // the tile's first image row (tiles are per token)
       const int wy0 = (h0 - 1) >> 1, wx0 = (x0 - 1) >> 1;  // (arithmetic shifts: -1 >> 1 = -1, the window row / column outside the image)
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
       constexpr int UW = 2;                                // items in flight per thread (4 x 16 B + 8 B of loads each)
       typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
       for (int it0 = tid; it0 < items; it0 += NT * UW) {
-        f32x4 pv[UW][2], gv[UW][2];
+        f32x4 pv[UW][2], gv[UW][2] = {};
         u32x2_ qv[UW];
         int wyv[UW], wxv[UW], cgv[UW];
         bool okv[UW];
@@ -614,25 +615,34 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
           const int cgc = cg * 8 < a.Cin ? cg : 0;
           const size_t wo = ((size_t)wyc * Wp + wxc) * a.Cin + cgc * 8;
           const float* pp = a.up2_src + (size_t)ntok * Hp * Wp * a.Cin + wo;
-          const float* gp = a.up2_gc + (size_t)img * Hp * Wp * a.Cin + wo;
           pv[u][0] = *reinterpret_cast<const f32x4*>(pp); pv[u][1] = *reinterpret_cast<const f32x4*>(pp + 4);
-          gv[u][0] = *reinterpret_cast<const f32x4*>(gp); gv[u][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+          if (!pairs) {                                   // (block-uniform; pairs mode: up2_src already holds P x gate as [hi8 | lo8])
+            const float* gp = a.up2_gc + (size_t)img * Hp * Wp * a.Cin + wo;
+            gv[u][0] = *reinterpret_cast<const f32x4*>(gp); gv[u][1] = *reinterpret_cast<const f32x4*>(gp + 4);
+          }
           qv[u] = *reinterpret_cast<const u32x2_*>(a.up2_gpos + (size_t)img * Hp * Wp * a.Cin + wo);
         }
 #pragma unroll
         for (int u = 0; u < UW; ++u) {
           if (it0 + u * NT >= items) continue;
-          float r[8];
+          u32x4 hiw, low;
+          if (pairs) {
+            const u32x4 z4u = {0u, 0u, 0u, 0u};
+            hiw = okv[u] ? __builtin_bit_cast(u32x4, pv[u][0]) : z4u;
+            low = okv[u] ? __builtin_bit_cast(u32x4, pv[u][1]) : z4u;
+          } else {
+            float r[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { r[e] = pv[u][0][e] * gv[u][0][e]; r[4 + e] = pv[u][1][e] * gv[u][1][e]; }
-          bf16x8 hi, lo;
+            for (int e = 0; e < 4; ++e) { r[e] = pv[u][0][e] * gv[u][0][e]; r[4 + e] = pv[u][1][e] * gv[u][1][e]; }
+            bf16x8 hi, lo;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const float rq = okv[u] ? r[q] : 0.f;
-            hi[q] = (__bf16)rq;
-            lo[q] = (__bf16)(rq - (float)hi[q]);
+            for (int q = 0; q < 8; ++q) {
+              const float rq = okv[u] ? r[q] : 0.f;
+              hi[q] = (__bf16)rq;
+              lo[q] = (__bf16)(rq - (float)hi[q]);
+            }
+            hiw = __builtin_bit_cast(u32x4, hi); low = __builtin_bit_cast(u32x4, lo);
           }
-          const u32x4 hiw = __builtin_bit_cast(u32x4, hi), low = __builtin_bit_cast(u32x4, lo);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {                    // the window's four pixels: position j = 2 dy + dx
             const int hy = 2 * wyv[u] + (j >> 1) - (h0 - 1), hx = 2 * wxv[u] + (j & 1) - (x0 - 1);
@@ -1899,7 +1909,8 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
             a.m_tiles = a.NB * a.tpt * a.cols_t;
           }
           a.tile_map = conv_tile_order(a, st);
-          if (a.up2_src && (PREC != PREC_BF16X3 || a.CinP > 64 || !a.up2_gate || (a.H & 1) || (a.W & 1))) return hipErrorInvalidValue;
+          if (a.up2_src && (PREC != PREC_BF16X3 || a.CinP > 64 || (!a.up2_gate && !a.up2_pairs) || (a.H & 1) || (a.W & 1))) return hipErrorInvalidValue;
+          if (a.up2_pairs && (!a.up2_gpos || !a.img_part)) return hipErrorInvalidValue;   // (pairs need the window loader: per-token tiles = the folded launch)
           hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 1, EPI, PREC, true, true, TERMS>), dim3(a.m_tiles), dim3(256), 0, st, a);
           return hipGetLastError();
         }

@@ -1014,7 +1014,7 @@ struct Encoder {
           (void)conv_halo_geom(128, L.H, L.W, fold_tw, fold_th, hr_);
           ca.img_w = P.w_bwd_s.as<float>(); ca.img_part = Snext; ca.out = nullptr;
         }
-        if (compact_in == 2) {                            // pairs of S_c at pooled resolution: the pipelined kernels' loader
+        if (compact_in == 2 || compact_in == 3) {         // pairs of S_c at pooled resolution (pipelined kernels' loader / the folded BREG launch)
           ca.up2_src = S; ca.up2_pairs = 1; ca.up2_gpos = L.Gpos.as<unsigned char>();
           compact_in = 0;
         } else if (compact_in) {                          // this layer reads the compact form its producer left
@@ -1028,8 +1028,20 @@ struct Encoder {
         // does THIS launch write the compact form?  Its consumer is layer li - 1 (N = P.cin, at 2x this resolution)
         if (P.pool_after && up2_on && split && !f16 && walk == 0 && !layer_hook && li >= 2 && P.cin <= 64 && conv_cinp(P.cout) <= 64 &&
             !(P.cout & 7) && conv_takes_breg(P.cin, P.H, P.W, P.w_bwd_frag.p != nullptr)) {
-          epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
-          compact_in = 1;
+          // pairs mode as below when the consumer will run the folded launch (per-token tiles: its window loader) and this
+          // encode left a compact gate; else the plain fp32 product and the consumer multiplies
+          static const bool gc_on3 = [] {
+            const char *e = getenv("LRP_UP2_GC"), *e2 = getenv("LRP_UP2_BREG_PAIRS");
+            return (!e || atoi(e) != 0) && (!e2 || atoi(e2) != 0);
+          }();
+          const bool cons_fold = li == 2 && fold_on && img_fused() && !layers[0].pool_after && P.cin == 64 && layers[0].w_bwd_s.p != nullptr;
+          if (gc_on3 && cons_fold && P.Gc.p && P.gc_epoch == encode_epoch) {
+            epi = EPI_MUL; ca.aux = P.Gc.as<float>();
+            compact_in = 3;
+          } else {
+            epi = EPI_MUL; ca.gate_none = 1; ca.out_plain = 1;
+            compact_in = 1;
+          }
         } else if (P.pool_after && up2_on && split && !f16 && walk == 0 && !layer_hook && li >= 2 && !(P.cout & 7) && P.Gc.p &&
                    P.gc_epoch == encode_epoch && conv_takes_pw(P.cin, n, P.H, P.W)) {
           // ... or by a pipelined halo kernel (ConvArgs::up2_pairs): this launch multiplies with the consumer's COMPACT gate
