@@ -146,3 +146,40 @@ def test_maxpool_exact_ties_follow_first_in_scan_order(prec):
     # element for element: relevance lands on exactly the pixels the oracle routes it to
     assert np.array_equal(out != 0, ref != 0)
 
+
+
+RAGGED_CFG = [("c1", 3, 64, False), ("c2", 64, 64, True), ("c3", 64, 128, False), ("c4", 128, 256, True), ("c5", 256, 256, False)]
+
+
+def test_compact_pool_interfaces_on_ragged_stack_tiles():
+    """The compact pool interfaces (conv_igemm.h ConvArgs::up2_pairs) away from VGG16's friendly geometry: a 60 x 80 image,
+    so that behind the second pool the 128 x 128 halo kernel's tiles are 9 stack rows x 14 columns on 30 x 40 maps — tiles
+    straddle tokens (separator rows inside the resident image), the last column tile is ragged (12 of 14 columns) — and its
+    in-loop loader builds eight channel chunks from (pairs, position bytes); behind the first pool the weights-in-registers
+    kernel takes pairs into its folded launch on 60 x 80 maps (last column tile 10 of 14).  36 relevance maps over 3 images
+    (enough rows for the large-tile paths), tokens interleaved, against the float64 literal graph."""
+    from lrp_imagecaptioning_amd.engine import LRPEngine
+    rs = np.random.RandomState(11)
+    w = vgg_weights(rs, RAGGED_CFG, bias_std=0.3)
+    layers = C.vgg_layers(w, RAGGED_CFG)
+    B, T, H, W = 3, 12, 60, 80
+    X = rs.uniform(-120, 130, size=(B, H, W, 3)).astype(np.float32)
+    eng = LRPEngine(decoder="adaptive", cnn_cfg=RAGGED_CFG, img_hw=(H, W), L=(H // 4) * (W // 4), D=256, H=32, E=32, V=50,
+                    max_images=B, max_tokens=B * T, max_caption_len=4)
+    eng.set_weights(w)
+    eng.encode_images(X)
+    feat_ref = C.forward(layers, X)
+    feat = eng.get_features().cpu().numpy().reshape(feat_ref.shape)
+    assert rel_l1(feat, feat_ref) < 1e-5
+    idx = [(3 * k + k // 5) % B for k in range(B * T)]                 # interleaved, uneven token -> image map
+    R = (rs.standard_normal((B * T,) + feat_ref.shape[1:]) * feat_ref[idx]).astype(np.float32)
+    R[5] = 0.0                                                          # an all-zero relevance map stays all zero
+    out = eng.cnn_explain(idx, R).cpu().numpy()
+    ref = C.analyze(layers, X[idx], R)
+    assert np.isfinite(out).all() and not out[5].any()
+    errs = [rel_l1(out[i], ref[i]) for i in range(B * T) if i != 5]
+    report("cnn_ragged_compact", max_rel_l1=max(errs))
+    assert max(errs) < TOL, errs
+    # the same maps explained a few at a time (small grids: expanded interface, 64 x 64 tiles) agree bit for bit
+    part = eng.cnn_explain(idx[:2], R[:2]).cpu().numpy()
+    assert np.array_equal(part, out[:2])
