@@ -342,15 +342,18 @@ def main():
         assert all(bool(torch.isfinite(o).all()) for o in outs)
         return dt
 
-    def dominant_kernel():
-        """reverse-walk launches of ONE step, HIP events on the launch stream (untimed, nothing else in flight)"""
-        pipe.reset()
+    def dominant_kernel(reps=3):
+        """reverse-walk launches of `reps` whole steps on handle 0, HIP events on the launch stream (one handle alone: nothing
+        else in flight); returns launches per step and the per-step averages of their summed time and algorithmic FLOPs"""
         eng.profile_enable(True)
-        step()
-        torch.cuda.synchronize()
+        for _ in range(reps):
+            pipe.reset()                                        # (every profiled step goes to handle 0)
+            step()
+            torch.cuda.synchronize()
         n_launch, ms, flop = eng.profile_query()
         eng.profile_enable(False)
-        return n_launch, ms, flop
+        pipe.reset()
+        return n_launch // reps, ms / reps, flop / reps
 
     def roofline_block(precision, n_launch, ms, flop, traffic, traffic_src):
         split = precision != "fp32"
