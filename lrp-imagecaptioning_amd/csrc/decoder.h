@@ -1024,11 +1024,11 @@ struct Decoder {
       hipLaunchKernelGGL(bx_head_kernel, dim3(n), dim3(256), 0, st, x);
       LRP_HIP_CHECK(hipGetLastError());
       const int steps = a.single_step ? 1 : t_max;
+      hipLaunchKernelGGL(bx_pre_kernel, dim3(n), dim3(256), 0, st, x, 0);
+      LRP_HIP_CHECK(hipGetLastError());
       for (int s = 0; s < steps; ++s) {
-        hipLaunchKernelGGL(bx_pre_kernel, dim3(n), dim3(256), 0, st, x, s);
-        LRP_HIP_CHECK(hipGetLastError());
         LRP_TRY(gemm_nt(bx_q32.as<float>(), n, H, bxWg1, 2 * E + H, bx_acc32.as<float>(), st));
-        hipLaunchKernelGGL(bx_post_kernel, dim3(n), dim3(256), 0, st, x, s);
+        hipLaunchKernelGGL(bx_post_kernel, dim3(n), dim3(256), 0, st, x, s, s + 1 < steps ? 1 : 0);   // post(s) + pre(s + 1): one launch
         LRP_HIP_CHECK(hipGetLastError());
       }
       hipLaunchKernelGGL(bx_tail_kernel, dim3(n, (D + 63) / 64), dim3(64), (size_t)E * sizeof(double), st, x);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void bx_head_kernel(BxArgs a) {
 }
 
 // cell rules of scan step s (E:604-619) -> q; units that are done write a zero row
-__global__ __launch_bounds__(256) void bx_pre_kernel(BxArgs a, int s) {
+__device__ __forceinline__ void bx_pre_body(const BxArgs& a, int s) {
   const int H = a.H, S = a.Tm + 1;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int b = a.img_idx[n], i = a.tpos[n] - 1 - s;
@@ -77,26 +77,33 @@ __global__ __launch_bounds__(256) void bx_pre_kernel(BxArgs a, int s) {
     q[j] = (float)(r_g / stab((double)a.gt[r1 + j]));
   }
 }
+__global__ __launch_bounds__(256) void bx_pre_kernel(BxArgs a, int s) { bx_pre_body(a, s); }
 
-// input rule of scan step s (E:620-632): r_x = x * (W_g q), routed to r_words / r_glob / r_h
-__global__ __launch_bounds__(256) void bx_post_kernel(BxArgs a, int s) {
+// input rule of scan step s (E:620-632): r_x = x * (W_g q), routed to r_words / r_glob / r_h — and, next != 0, the cell rules
+// of step s + 1 behind it in the same launch (a unit is one workgroup in both: the barrier between them orders r_h)
+__global__ __launch_bounds__(256) void bx_post_kernel(BxArgs a, int s, int next) {
   __shared__ double red[4];
   const int H = a.H, E = a.E, Tm = a.Tm, S = Tm + 1, Nd = 2 * E + H;
   const int n = blockIdx.x, tid = threadIdx.x;
   const int b = a.img_idx[n], i = a.tpos[n] - 1 - s;
-  if (i < 0 || (a.single_step && s > 0)) return;
-  const size_t r0 = ((size_t)b * S + i) * H;
-  const float* acc = a.acc32 + (size_t)n * Nd;
-  double wsum = 0.0;
-  for (int d = tid; d < Nd; d += 256) {
-    const float x = d < 2 * E ? a.xt[((size_t)b * Tm + i) * 2 * E + d] : a.ht[r0 + d - 2 * E];
-    const double rx = (double)x * (double)acc[d];
-    if (d < E) wsum += rx;
-    else if (d < 2 * E) a.rglob[(size_t)n * E + d - E] += rx;
-    else a.rh[(size_t)n * H + d - 2 * E] = rx;
+  if (!(i < 0 || (a.single_step && s > 0))) {            // (block-uniform)
+    const size_t r0 = ((size_t)b * S + i) * H;
+    const float* acc = a.acc32 + (size_t)n * Nd;
+    double wsum = 0.0;
+    for (int d = tid; d < Nd; d += 256) {
+      const float x = d < 2 * E ? a.xt[((size_t)b * Tm + i) * 2 * E + d] : a.ht[r0 + d - 2 * E];
+      const double rx = (double)x * (double)acc[d];
+      if (d < E) wsum += rx;
+      else if (d < 2 * E) a.rglob[(size_t)n * E + d - E] += rx;
+      else a.rh[(size_t)n * H + d - 2 * E] = rx;
+    }
+    const double ws = block_sum_d(wsum, red);
+    if (tid == 0 && a.rwords_out) a.rwords_out[(size_t)n * Tm + i] = ws;
   }
-  const double ws = block_sum_d(wsum, red);
-  if (tid == 0 && a.rwords_out) a.rwords_out[(size_t)n * Tm + i] = ws;
+  if (next) {
+    __syncthreads();                                     // this unit's r_h of step s is complete (global writes of the workgroup)
+    bx_pre_body(a, s + 1);
+  }
 }
 
 // ravg[d] = avg[d] * sum_e WglobT[e][d] q[e]  (float64, e in order)
