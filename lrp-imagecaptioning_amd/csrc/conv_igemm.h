@@ -1886,6 +1886,16 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   // the same chain of MFMAs in the same k order, so the results are bit-identical to the large tiles (batch invariance).
   const bool small_tile = conv_small_tile_on() && t.BM == 128 && t.BN >= 64 && (long)a.m_tiles * a.n_tiles <= conv_small_tile_blocks() &&
                           !a.up2_src && !a.img_part;
+  // In between (at most one large tile per CU, but too many for the 64 x 64 tiles to stay resident): 128 x 64 tiles put two
+  // workgroups on a CU and halve a k-step — same chains, same bits [MI355X, one image, ten words: block4's walk launches
+  // (252 large tiles) 115 -> ~80 us, explain 1.62 -> 1.51 ms].  LRP_CONV_MID=0 disables (read per launch, like LRP_CONV_SMALL).
+  const char* mid_env = getenv("LRP_CONV_MID");
+  const bool mid_on = !mid_env || atoi(mid_env) != 0;
+  if (mid_on && !small_tile && conv_small_tile_on() && t.BM == 128 && t.BN == 128 && (a.N % 64) == 0 && !a.up2_src && !a.img_part &&
+      (long)a.m_tiles * a.n_tiles <= 2 * conv_small_tile_blocks()) {
+    t = {128, 64};
+    a.n_tiles = (a.N + 63) / 64;
+  }
 
   if constexpr (PREC != PREC_FP32 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL)) {
     const int mode = conv_halo_mode();

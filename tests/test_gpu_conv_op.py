@@ -168,6 +168,7 @@ SMALL_CASES = [  # NB, H, W, Cin, Cout
     (10, 14, 14, 256, 128),   # ten words: 16 x 1 large tiles
     (1, 28, 28, 72, 64),      # N = 64 tile family, Cin not a multiple of 32
     (2, 7, 5, 40, 192),       # ragged M, N = 192
+    (10, 28, 28, 256, 256),   # 62 x 2 large tiles (forward) / 62 x 2 (backward): between 128 and 256 -> the 128 x 64 tiles
 ]
 
 
@@ -191,5 +192,6 @@ def test_small_tiles_are_bit_identical_to_large_tiles(case, split, mode, monkeyp
     outs = {}
     for small in ("1", "0"):
         monkeypatch.setenv("LRP_CONV_SMALL", small)
+        monkeypatch.setenv("LRP_CONV_MID", small)             # the 128 x 64 tiles of the grids in between follow the same switch here
         outs[small] = op_conv(*args, split_bf16=split).clone()
     assert torch.equal(outs["1"], outs["0"]), float((outs["1"] - outs["0"]).abs().max())
