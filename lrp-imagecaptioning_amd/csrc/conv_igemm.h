@@ -197,7 +197,8 @@ struct ConvArgs {
   // from that image, so a scale per image is as legal as one per call, and the result for an image no longer depends on
   // which other images share its batch.
   int scale_per_img, img_rows, n_imgs;
-  // Compact pool interface (weights-in-registers kernel, PREC_BF16X3, Cin <= 64): the relevance entering this layer came
+  // Compact pool interface (PREC_BF16X3; first form: the weights-in-registers kernel, Cin <= 64, fields up2_src / up2_gate /
+  // up2_gc; general form: every halo kernel through up2_pairs below): the relevance entering this layer came
   // through a 2x2 max-pool, i.e. S_in[n][y][x][c] = P[n][y/2][x/2][c] * G_up[img(n)][y][x][c] with exactly one non-zero per
   // window and channel.  Instead of reading that 4x-expanded, 75 %-zero tensor (which its producer would have had to write),
   // the tile's resident image is BUILT from P (fp32, pooled resolution, written by the producer with gate_none) and the
