@@ -84,23 +84,47 @@ def cpu_baseline(w, V, T, sample_tokens):
 PARITY_SAMPLES = [(0, 1), (0, 10), (31, 10), (13, 5)]        # (image, t) of the timed batch checked against the oracle
 
 
-def algorithmic_bytes_per_walk(n_tokens, n_images):
-    """SURVEY 8d / DESIGN 4.1: per reverse-walk launch S_in (n x H x W x Cout) + S_out (n x H' x W' x Cin) once each, and
-    the gate of every DISTINCT image once (B x H' x W' x Cin; the tokens of an image share it) — 4 B per element (split8
-    operands are the same bytes as fp32).  Returns (total bytes of the 13 launches, launches)."""
+def algorithmic_bytes_per_walk(n_tokens, n_images, dataflow="as_built"):
+    """Bytes one reverse walk has to move, 4 B per element (split8 pairs are the same bytes as fp32), per launch
+    S_in + S_out once each and the gate of every DISTINCT image once (the tokens of an image share it).
+      "survey"    SURVEY 8d / rounds 1-3: every tensor at the resolution of the layer that reads it — S through a 2x2 pool
+                  counted 4x-expanded, S_1 (n x 224^2 x 64) written by block1_conv2 and read by the image layer.  Still
+                  the dataflow of the fp32 and f16x2 modes.
+      "as_built"  the default (bf16x3) walk since round 3: a tensor that crosses a pool is stored ONCE at
+                  POOLED resolution (the producer multiplies with the compact gate: value per window and channel, read by
+                  the producer; the consumer reads one position byte per window and channel), and S_1 is not stored at
+                  all — block1_conv2's launch carries the image layer and writes R_img (n x 224^2 x 3) from x (per image).
+                  Partial sums, halos and re-fetches are NOT in this figure: traffic / this = the waste.
+    Returns (total bytes, launches)."""
     from lrp_imagecaptioning_amd.synthetic import VGG16_CFG
+    cfg = VGG16_CFG
     res, r = [], 224
-    for _, cin, cout, pool in VGG16_CFG:
+    for _, cin, cout, pool in cfg:
         res.append(r)
         r = r // 2 if pool else r
     tot = 0
-    for li, (_, cin, cout, _) in enumerate(VGG16_CFG):
-        s_in = n_tokens * res[li] ** 2 * cout * 4
-        r_out = res[li - 1] if li else res[0]              # resolution of the layer's input (2x when a pool sits between)
-        s_out = n_tokens * r_out ** 2 * cin * 4
-        gate = n_images * r_out ** 2 * cin * 4             # (image layer: the image itself)
-        tot += s_in + s_out + gate
-    return tot, len(VGG16_CFG)
+    for li, (_, cin, cout, pool) in enumerate(cfg):
+        r_here = res[li]
+        if dataflow == "survey":
+            s_in = n_tokens * r_here ** 2 * cout * 4
+            r_out = res[li - 1] if li else res[0]
+            tot += s_in + n_tokens * r_out ** 2 * cin * 4 + n_images * r_out ** 2 * cin * 4
+            continue
+        if li == 0:
+            continue                                       # the image layer rides on block1_conv2's launch (below)
+        # what this launch reads: S at its own resolution — or the pooled pairs + position bytes when a pool follows it
+        if pool:
+            s_in = n_tokens * (r_here // 2) ** 2 * cout * 4 + n_images * (r_here // 2) ** 2 * cout * 1
+        else:
+            s_in = n_tokens * r_here ** 2 * cout * 4
+        # what it writes: S for the layer below at THIS resolution (x its dense gate, or x the compact gate value when the
+        # layer below is pooled); block1_conv2 instead finishes the image layer: R_img from x and G_1
+        if li == 1:
+            s_out = n_tokens * r_here ** 2 * 3 * 4 + n_images * r_here ** 2 * (3 + cin) * 4
+        else:
+            s_out = n_tokens * r_here ** 2 * cin * 4 + n_images * r_here ** 2 * cin * 4
+        tot += s_in + s_out
+    return tot, len(cfg)
 
 
 def power_probe(step, torch, seconds=2.0):
@@ -147,6 +171,54 @@ def power_probe(step, torch, seconds=2.0):
         return None
     return {"socket_power_w": round(float(np.median(watts)), 1), "sclk_mhz": int(np.median(mhz)), "samples": len(watts),
             "source": "rocm-smi --showpower --showclocks while the bench's steps run (untimed)"}
+
+
+def sustained_probe(step, torch, seconds, est_ms_per_step, heatmaps_per_step):
+    """The same steps back to back for >= `seconds` (and >= 150 steps): the headline's timed region is ~0.6 s on a board
+    that sits at its power limit, so this is the rate it HOLDS — with socket power and shader clock sampled by rocm-smi
+    over the same window (a sampler thread; the main thread issues the steps exactly as the timed run does)."""
+    import math
+    import threading
+    n = max(150, int(math.ceil(seconds * 1e3 / max(est_ms_per_step, 1e-3))))
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    watts, mhz = [], []
+    stop = threading.Event()
+
+    def sample():
+        dev = str(torch.cuda.current_device())
+        while not stop.is_set():
+            try:
+                out = subprocess.run([smi, "-d", dev, "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+            except Exception:
+                return
+            m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+            c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+            if m:
+                watts.append(float(m.group(1)))
+            if c:
+                mhz.append(int(c.group(1)))
+    th = threading.Thread(target=sample) if os.path.exists(smi) else None
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    if th:
+        th.start()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop.set()
+    if th:
+        th.join()
+    blk = {"value": round(heatmaps_per_step * n / dt, 2), "unit": "heatmaps/s", "steps": n, "seconds": round(dt, 2),
+           "ms_per_step": round(dt / n * 1e3, 3),
+           "what": "the timed workload, %d steps back to back without a host synchronise in between" % n}
+    if watts and mhz:
+        blk.update({"socket_power_w": round(float(np.median(watts)), 1), "socket_power_w_max": round(max(watts), 1),
+                    "sclk_mhz": int(np.median(mhz)), "sclk_mhz_min": min(mhz), "samples": len(watts),
+                    "source": "rocm-smi --showpower --showclocks sampled over the same window"})
+    return blk
 
 
 def top_block_flop_share():
@@ -197,7 +269,7 @@ def is_walk_kernel(name, precision):
     return bool(m and m.group(1) in ("2", "3", "5", "6") and m.group(2) == PREC_TEMPLATE_ARG[precision])
 
 
-def live_pmc_traffic(args):
+def live_pmc_traffic(args, precision=None):
     """HBM/fabric bytes per reverse-walk launch, measured in THIS run: two rocprofv3 child passes (FETCH_SIZE and
     WRITE_SIZE need separate passes: TCC has 4 counter slots, MI355X_MICROARCH.md) of `bench.py --child` = one step of
     the same workload.  FETCH_SIZE is doubled (gfx950 tallies the 128 B requests of 16 B/lane streams at 64 B).  Must
@@ -207,6 +279,7 @@ def live_pmc_traffic(args):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not found"
+    precision = precision or args.precision
     tot = {}
     n = {}
     tmp = tempfile.mkdtemp(prefix="lrp_pmc_")
@@ -216,7 +289,7 @@ def live_pmc_traffic(args):
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "p", "--",
                    sys.executable, os.path.abspath(__file__), "--child", "--steps", "1", "--warmup", "0",
                    "--batch", str(args.batch), "--tokens", str(args.tokens), "--vocab", str(args.vocab),
-                   "--precision", args.precision, "--handles", str(args.handles)]
+                   "--precision", precision, "--handles", str(args.handles)]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
@@ -225,7 +298,7 @@ def live_pmc_traffic(args):
             seen = set()
             tot[ctr] = 0.0
             for row in csv.DictReader(open(files[0])):
-                if row["Counter_Name"] == ctr and is_walk_kernel(row["Kernel_Name"], args.precision):
+                if row["Counter_Name"] == ctr and is_walk_kernel(row["Kernel_Name"], precision):
                     tot[ctr] += float(row["Counter_Value"])
                     seen.add(row["Dispatch_Id"])
             n[ctr] = len(seen)
@@ -264,6 +337,9 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-image latency block")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of sampled heat-maps")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 traffic passes (use the committed summary)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="length of the `sustained` block: the same steps back to back for at least this long (0 = skip)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config4 / config5 sub-blocks (BASELINE configs[3], [4])")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)    # one plain step under rocprofv3 (live_pmc_traffic)
     args = ap.parse_args()
 
@@ -274,8 +350,11 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     extras = world == 1 and not args.child                  # the self-certifying blocks: rank 0 of a one-GPU run only
     live_traffic, live_src = (None, None)
+    live32, live32_src = (None, None)
     if extras and not args.no_pmc:
         live_traffic, live_src = live_pmc_traffic(args)     # children first: this process has not touched the GPU yet
+        if not args.no_fp32_mode and args.precision != "fp32":
+            live32, live32_src = live_pmc_traffic(args, "fp32")
 
     import torch
     local = local % max(torch.cuda.device_count(), 1)      # (rehearsal: more ranks than GPUs share a device)
@@ -300,8 +379,18 @@ def main():
     pipe.set_precision(args.precision)
     # frozen weights: rank 0 owns them, everyone else receives them over RCCL/xGMI
     w_host = synth_weights(0, V) if rank == 0 else None
+    bcast = None
     if world > 1:
-        pipe.set_weights_from_device(broadcast_weights(w_host, synth_weights_shapes(V), local, dist))
+        shapes = synth_weights_shapes(V)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        bundle = broadcast_weights(w_host, shapes, local, dist)
+        torch.cuda.synchronize()
+        bcast = {"bytes": 4 * sum(int(np.prod(sh)) for sh in shapes.values()), "ms": round((time.perf_counter() - t0) * 1e3, 2),
+                 "what": "ONE dist.broadcast of the flat frozen bundle from rank 0 (host flatten + H2D on rank 0 included), "
+                         "then lrp_set_weight_dev packs it on each GPU"}
+        pipe.set_weights_from_device(bundle)
     else:
         pipe.set_weights(w_host)
 
@@ -319,6 +408,8 @@ def main():
         # one pass of the hot path over one batch; consecutive steps go to alternating handles / streams
         pipe.explain_batch(X, caps, img_idx, tpos, out=outs[pipe.next_slot])
 
+    per_rank = []                                           # seconds of the last timed_run on every rank
+
     def timed_run(n_warm, n_steps):
         """W untimed + exactly K timed steps, barrier + device synchronise on both sides, MAX over ranks."""
         for _ in range(n_warm):
@@ -335,8 +426,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        per_rank[:] = [dt]
         if dist:
-            tt = torch.tensor([dt], dtype=torch.float64, device=X.device if args.backend == "nccl" else "cpu")
+            cdev = X.device if args.backend == "nccl" else "cpu"
+            tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(every, tt)                        # each rank's own clock, for the line's `distributed` block
+            per_rank[:] = [float(e.item()) for e in every]
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         assert all(bool(torch.isfinite(o).all()) for o in outs)
@@ -373,13 +469,16 @@ def main():
         else:
             peak = PEAK_F32_MFMA_TFLOPS
             kname = "conv_igemm_kernel<..., PREC_FP32> (conv-LRP alpha1beta0 backward, 13 launches/step)"
-        abytes, alaunch = algorithmic_bytes_per_walk(B * T, B)
+        # the default walk moves the compact dataflow; fp32 / f16x2 walks still move the expanded one
+        flow = "as_built" if precision in ("bf16x3", "bf16x3_fast") else "survey"
+        abytes, alaunch = algorithmic_bytes_per_walk(B * T, B, flow)
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM+MALL bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
                 "traffic_source": traffic_src, "launches": n_launch, "avg_launch_ms": round(ms / max(n_launch, 1), 4),
                 "algorithmic_gflop_per_launch": round(flop / max(n_launch, 1) / 1e9, 2),
-                "algorithmic_bytes_per_launch": int(abytes / alaunch),
+                "algorithmic_bytes_per_launch": int(abytes / alaunch), "algorithmic_bytes_dataflow": flow,
+                "algorithmic_bytes_per_launch_survey8d": int(algorithmic_bytes_per_walk(B * T, B, "survey")[0] / alaunch),
                 "traffic_over_algorithmic_bytes": round(traffic / (abytes / alaunch), 3) if traffic else None}
         if split:
             roof["mfma_flop_per_algorithmic_flop"] = per_product
@@ -395,8 +494,17 @@ def main():
     dt = timed_run(args.warmup, args.steps)
     if args.child:
         return
+    per_rank_ms = [round(t / args.steps * 1e3, 3) for t in per_rank]
     n_launch, ms, flop = dominant_kernel()
     got = {args.precision: sampled(args.precision)} if extras and not args.no_parity else {}
+
+    # ---- the rate the board HOLDS: the same steps for >= 5 s, power and clock sampled over that window
+    sustained_block = None
+    if extras and args.sustained_seconds > 0:
+        pipe.reset()
+        sustained_block = sustained_probe(step, torch, args.sustained_seconds, dt / args.steps * 1e3, B * T)
+        assert all(bool(torch.isfinite(o).all()) for o in outs)
+        pipe.reset()
 
     # ---- board power / shader clock while the same steps run (untimed): the walk is power-limited on MI355X, which is
     # why its MFMA count, not the overlap of its phases, sets the rate
@@ -414,7 +522,12 @@ def main():
             got["fp32"] = sampled("fp32")
         fp32_block = {"value": round(B * T * k32 / dt32, 2), "unit": "heatmaps/s", "steps": k32, "warmup": 1,
                       "ms_per_step": round(dt32 / k32 * 1e3, 3), "dtype": "f32",
-                      "roofline": roofline_block("fp32", nl32, ms32, fl32, *pmc_traffic_per_launch("fp32"))}
+                      "roofline": roofline_block("fp32", nl32, ms32, fl32,
+                                                 *((live32["bytes"], live32_src) if live32 else pmc_traffic_per_launch("fp32")))}
+        if live32:
+            fp32_block["roofline"]["traffic_detail"] = live32
+        elif live32_src:
+            fp32_block["roofline"]["traffic_source"] = live32_src
         pipe.reset()
         pipe.set_precision(args.precision)
 
@@ -453,7 +566,22 @@ def main():
     # E:183-189): host clock around encode -> decoder replay -> T heat-maps -> device synchronise, on a B = 1 handle
     latency_block = None
     if extras and not args.no_latency:
-        latency_block = latency_probe(w_host, X[:1], caps[:1], T, V, local, args.precision, torch)
+        X1, what1 = real_image(torch, X.device)
+        latency_block = latency_probe(w_host, X1 if X1 is not None else X[:1], caps[:1], T, V, local, args.precision, torch,
+                                      image=what1 or "synthetic U[0,255] image")
+
+    # ---- BASELINE configs[3] and [4] at one GPU's share, one timed run each with a sampled parity check, so that those
+    # configurations have a driver-timed number too (the headline stays configs[1])
+    config4_block = config5_block = None
+    if extras and not args.no_configs:
+        pipe.reset()
+        for e in pipe.engines:
+            e.close()
+        del outs[:]
+        torch.cuda.empty_cache()
+        config4_block = guarded_block(config4_probe, torch, local, not args.no_parity)
+        torch.cuda.empty_cache()
+        config5_block = guarded_block(config5_probe, torch, local, not args.no_parity)
 
     if live_traffic:
         traffic, traffic_src = live_traffic["bytes"], live_src
@@ -484,8 +612,21 @@ def main():
             res["fp32_mode"] = fp32_block
         if fast_block:
             res["fast_mode"] = fast_block
+        if sustained_block:
+            res["sustained"] = sustained_block
+        if world > 1:
+            res["distributed"] = {
+                "backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None,
+                "ms_per_step_per_rank": per_rank_ms, "timing": "MAX over ranks (all_reduce) of each rank's own clock around the "
+                "barrier-bracketed timed region", "weight_broadcast": bcast,
+                "data_path_collectives_per_step": 0}
         if latency_block:
             res["latency"] = latency_block
+        if config4_block:
+            res["config4"] = config4_block
+        if config5_block:
+            res["config5"] = config5_block
         if power_block:
             res["power"] = power_block
         if got:
@@ -515,7 +656,139 @@ def main():
         dist.destroy_process_group()
 
 
-def latency_probe(w_host, X1, caps1, T, V, device, precision, torch, reps=7):
+def real_image(torch, device):
+    """The reference's own example photograph (example_images/flickr30kimage/1009434119.jpg, explain_image.py:321-371;
+    decoded pixels in tests/golden/real_images.npz), preprocessed on the device (models/preprocessors.py:38-53)."""
+    f = os.path.join(ROOT, "tests", "golden", "real_images.npz")
+    if not os.path.exists(f):
+        return None, None
+    from lrp_imagecaptioning_amd.engine import preprocess_images
+    d = np.load(f)
+    x = preprocess_images(torch.as_tensor(d["rgb_u8"][:1]).to(device))
+    return x, "the reference's example photograph %s (tests/golden/real_images.npz), preprocessed on the device" % str(d["names"][0])
+
+
+def guarded_block(fn, *a):
+    """A sub-block that fails must not cost the headline line: its error is reported in its place."""
+    try:
+        return fn(*a)
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+
+def config4_probe(torch, device, parity=True, B=32, T=10, V=10000, steps=6):
+    """BASELINE configs[3] at one GPU's share (batch = 128 on 4 GPUs): grid-TD decoder + ResNet-101 encoder, LRP alpha1beta0,
+    32 images x 10 words per step, two batches in flight like the headline.  One timed run; one sampled heat-map against
+    the float64 oracles (oracle/resnet_lrp_ref.py + GridTDOracle) outside the timed region."""
+    from lrp_imagecaptioning_amd.pipeline import LRPPipeline
+    from lrp_imagecaptioning_amd.synthetic import RESNET101_STACKS, captions, gridtd_weights, images, resnet_weights
+    rs = np.random.RandomState(0)
+    w = resnet_weights(rs)
+    w.update(gridtd_weights(rs, 49, 2048, 512, 512, V))
+    pipe = LRPPipeline(2, decoder="gridtd", img_hw=(224, 224), L=49, D=2048, H=512, E=512, V=V, max_images=B, max_tokens=B * T,
+                       max_caption_len=T + 1, resnet={"stem": 64, "stacks": RESNET101_STACKS}, device=device)
+    pipe.set_weights(w)
+    X_host = images(rs, B)
+    X = torch.as_tensor(X_host).cuda(device)
+    caps = captions(rs, B, T, V)
+    idx = [b for b in range(B) for _ in range(T)]
+    tt = [t for _ in range(B) for t in range(1, T + 1)]
+    outs = [torch.empty((B * T, 224, 224, 3), dtype=torch.float32, device=X.device) for _ in pipe.engines]
+    step = lambda: pipe.explain_batch(X, caps, idx, tt, out=outs[pipe.next_slot])
+    for _ in range(2):
+        step()
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert all(bool(torch.isfinite(o).all()) for o in outs)
+    blk = {"value": round(B * T * steps / dt, 2), "unit": "heatmaps/s", "steps": steps, "warmup": 2,
+           "ms_per_step": round(dt / steps * 1e3, 3), "dtype": "bf16x3", "workspace_gb": round(sum(e.workspace_bytes for e in pipe.engines) / 1e9, 1),
+           "workload": "batch=%d synthetic 224x224 per GPU, ResNet-101 (conv5_block3_out) + grid-TD, LRP-alpha1beta0 per-token "
+                       "heat-maps, %d words/caption, V=%d (BASELINE configs[3]: batch=128 on 4 GPUs)" % (B, T, V)}
+    if parity:
+        from oracle import resnet_lrp_ref as RN
+        from oracle.decoder_ref import GridTDOracle
+        t0 = time.time()
+        b, t = 5, 2
+        spec = RN.resnet_spec()
+        o = GridTDOracle(w, 49, 2048, 512, 512)
+        o.forward(RN.forward(w, spec, X_host[b:b + 1]).astype(np.float32), caps[b])
+        ref = RN.analyze(w, spec, X_host[b:b + 1], o.explain(t)[0].reshape(1, 7, 7, 2048))[0]
+        e = rel_l1(outs[0][b * T + t - 1].cpu().numpy(), ref)
+        blk["parity"] = {"sample": [b, t], "rel_l1": e, "tolerance": 1e-4, "ok": bool(e < 1e-4),
+                         "oracle": "oracle/resnet_lrp_ref.py + GridTDOracle (float64; unpinned: TensorFlow)", "oracle_seconds": round(time.time() - t0, 1)}
+    for e in pipe.engines:
+        e.close()
+    return blk
+
+
+def config5_probe(torch, device, parity=True, B=8, T=21, V=10000, iters=6):
+    """BASELINE configs[4] at one GPU's share (batch = 64 on 8 GPUs): the LRP-inference fine-tune iteration (train.py:571-580)
+    of the VGG16 + adaptive-attention captioner in bf16 gradient mode — predict, lrp_weight for every word of every
+    predicted caption, gradients, Adam + operand rebuild.  One timed run; one sampled `lrp_weight` entry against the
+    reference loop (M:1657-1689) on the float64 oracles."""
+    from lrp_imagecaptioning_amd.explainers import CaptionModelSpec, ExplainImgCaptioningAdaptiveAttention
+    from lrp_imagecaptioning_amd.synthetic import VGG16_CFG, adaptive_weights, images, vgg_weights
+    from lrp_imagecaptioning_amd.training import TrainingLRPInferenceAdaptive
+    torch.cuda.set_device(device)
+    rs = np.random.RandomState(0)
+    w = vgg_weights(rs)
+    w.update(adaptive_weights(rs, 196, 512, 512, 512, V))
+    spec = CaptionModelSpec(w, img_encoder="vgg16", hidden_dim=512, embedding_dim=512, L=196, D=512, vocab_size=V)
+    ex = ExplainImgCaptioningAdaptiveAttention(spec, None, None, max_caption_length=T - 1, max_images=B)
+    tr = TrainingLRPInferenceAdaptive(ex, learning_rate=2e-4, drop_rate=0.5)
+    eng = ex._engine
+    eng.train_set_precision("bf16")
+    rs = np.random.RandomState(100)
+    X_host = images(rs, B)
+    X = torch.as_tensor(X_host).cuda(device)
+    cap_in = np.concatenate([np.full((B, 1), 1), rs.randint(2, V, size=(B, T - 1))], axis=1).astype(np.int32)
+    y = rs.randint(0, V, size=(B, T)).astype(np.int32)
+    blk = {}
+    if parity:                                              # before any update: the weights are still `w`
+        from lrp_imagecaptioning_amd.postprocess import lrp_inference_score
+        from oracle import cnn_lrp_ref as C
+        from oracle.decoder_ref import AdaptiveOracle
+        t0 = time.time()
+        y_pred = tr.predict_on_batch([cap_in, X])
+        lw = tr._lrp_layer.call_device(X, y_pred, images_encoded=True)
+        words = (torch.argmax(y_pred, dim=-1) + 1).cpu().numpy()
+        b, i = 3, 4
+        cap = [int(c) for c in words[b]]
+        full = cap[:cap.index(1) + 1] if 1 in cap else cap[:T - 1] + [1]
+        if i < len(full) - 1:
+            layers = C.vgg_layers(w, VGG16_CFG)
+            o = AdaptiveOracle(w, 196, 512, 512, 512)
+            o.forward(C.forward(layers, X_host[b:b + 1]).astype(np.float32), full)
+            want = 1 + lrp_inference_score(C.analyze(layers, X_host[b:b + 1], o.explain(i + 1)[0]), "mean")
+            got = float(lw[b, i, cap[i]])
+            e = abs(got - want) / abs(want - 1)
+            blk["parity"] = {"sample": [b, i], "lrp_weight_score_rel_err": e, "tolerance": 2e-3, "ok": bool(e < 2e-3),
+                             "oracle": "reference loop M:1657-1689 on oracle/decoder_ref.py + oracle/cnn_lrp_ref.py (float64)",
+                             "oracle_seconds": round(time.time() - t0, 1)}
+    for _ in range(3):
+        tr.train_on_batch([cap_in, X], y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        losses = tr.train_on_batch([cap_in, X], y)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_maps = B * (T - 1)
+    blk.update({"value": round(B * iters / dt, 2), "unit": "images/s", "iterations": iters, "warmup": 3,
+                "ms_per_iteration": round(dt / iters * 1e3, 3), "heatmaps_per_iteration": n_maps, "dtype": "bf16 (conv weight gradients) / bf16x3 / fp32",
+                "finite_losses": bool(np.all(np.isfinite(np.asarray([float(v) for v in losses])))),
+                "workload": "LRP-inference fine-tune iteration, VGG16 + adaptive attention, batch=%d per GPU, T=%d, V=%d, every word of "
+                            "every predicted caption explained (BASELINE configs[4]: batch=64 on 8 GPUs)" % (B, T, V)})
+    eng.close()
+    return blk
+
+
+def latency_probe(w_host, X1, caps1, T, V, device, precision, torch, reps=7, image="synthetic"):
     """Single-image latency: a handle sized for ONE image and its T words (the small-tile kernels), weights resident,
     image resident in HBM; per repetition encode_images -> decoder_forward -> explain_tokens(T) -> synchronise, host clock.
     Reports the median, the best, and the kernel launches behind one repetition (lrp_launch_count)."""
@@ -545,6 +818,7 @@ def latency_probe(w_host, X1, caps1, T, V, device, precision, torch, reps=7):
     ms.sort()
     return {"ms": round(ms[len(ms) // 2], 3), "best_ms": round(ms[0], 3), "launches": launches, "heatmaps": T,
             "reps": reps, "dtype": {"fp32": "f32"}.get(precision, precision),
+            "image": image,
             "what": "1 image resident in HBM, B = 1 handle: encode + decoder replay + %d per-word heat-maps + synchronise, "
                     "host clock (median of %d); explain_image.py:152-161" % (T, reps)}
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LRP_ABI_VERSION 5
+#define LRP_ABI_VERSION 6
 
 enum {
   LRP_OK = 0,
@@ -370,11 +370,18 @@ int lrp_train_step(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_de
  * waits for it and starts at the loss.  Contract: the kernels read cap_in and the masks straight from the caller's device
  * buffers (nothing is staged), in the forward AND in the backward scan of lrp_train_step — so that step must be handed the
  * SAME cap_in / mask pointers (they must stay alive and unchanged until the step's work has completed); other pointers are
- * refused with LRP_ERR_INVALID rather than back-propagated through masks the forward did not use.  lrp_encode_images,
+ * refused with LRP_ERR_INVALID rather than back-propagated through masks the forward did not use, and the refusal drops
+ * the pending forward (a retry runs its own, so recycled addresses cannot pass for the old buffers).  lrp_encode_images,
  * lrp_set_features, lrp_set_weight[_dev] and lrp_set_precision drop a pending early forward. */
 int lrp_train_forward(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in_dev, const float* mask_image_features_dev,
                       const float* mask_global_dev, const float* mask_output_dev, const float* mask_lstm_in_dev,
                       const float* mask_lstm_rec_dev, void* stream);
+/* ABI v6.  Forget a pending lrp_train_forward (train.py:571-577 has no counterpart: the reference runs the forward inside
+ * train_on_batch).  For a caller that abandons the step it issued the early forward for — e.g. an error between the two
+ * calls — and is about to release cap_in / the masks: `stream` (or, NULL, the host) first waits for the early forward, which
+ * may still be reading them; the next lrp_train_step then runs its own forward.  lrp_train_step does the same by itself when
+ * it refuses mismatching pointers.  No-op without a pending forward. */
+int lrp_train_drop_forward(lrp_handle* h, void* stream);
 int lrp_train_apply(lrp_handle* h, const float* grads_dev, void* stream);
 int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
 

@@ -7,7 +7,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liblrp_hip.so")
 
-LRP_ABI_VERSION = 5
+LRP_ABI_VERSION = 6
 LRP_OK, LRP_ERR_INVALID, LRP_ERR_STATE, LRP_ERR_HIP, LRP_ERR_NOMEM, LRP_ERR_RANGE, LRP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 LRP_DEC_ADAPTIVE, LRP_DEC_GRIDTD = 0, 1
 LRP_ENC_VGG, LRP_ENC_RESNET = 0, 1
@@ -73,6 +73,7 @@ SYMBOLS = {
     "lrp_train_param_info": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lrp_train_step": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lrp_train_forward": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "lrp_train_drop_forward": (C.c_int, [_P, _P]),
     "lrp_train_apply": (C.c_int, [_P, _P, _P]),
     "lrp_train_get_master": (C.c_int, [_P, _P, _P]),
     "lrp_heatmap_render": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),

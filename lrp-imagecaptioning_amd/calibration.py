@@ -62,46 +62,58 @@ def calibrate_fast_mode(engine, images, relevances=None, img_idx=None, tolerance
     X = images if torch.is_tensor(images) else torch.as_tensor(np.ascontiguousarray(images, dtype=np.float32))
     X = X.to(engine.device)
     budget = tolerance / margin
-
-    # ---- reference: exact fp32, same images, same relevance
-    engine.set_precision("fp32")
-    engine.encode_images(X)
-    feat = engine.get_features().clone()
-    if relevances is None:
-        relevances, img_idx = default_relevances(feat)
-    R = relevances.to(engine.device).float().contiguous()
-    idx = [int(i) for i in img_idx]
-    if R.shape[0] > engine.max_tokens:
-        raise ValueError("%d calibration relevances > max_tokens = %d" % (R.shape[0], engine.max_tokens))
-    ref = engine.cnn_explain(idx, R).clone()
-
-    def run(mask):
-        engine.set_precision("f16x2")
-        engine.set_fast_layers(mask)
+    # validate what can be validated before the engine's mode is touched
+    if X.dim() != 4 or X.shape[0] < 1 or X.shape[0] > engine.max_images:
+        raise ValueError("images must be (B, H, W, 3) with 1 <= B <= max_images = %d" % engine.max_images)
+    if relevances is not None:
+        if img_idx is None or len(img_idx) != relevances.shape[0]:
+            raise ValueError("relevances need one img_idx entry each")
+        if relevances.shape[0] > engine.max_tokens:
+            raise ValueError("%d calibration relevances > max_tokens = %d" % (relevances.shape[0], engine.max_tokens))
+    elif 3 * X.shape[0] > engine.max_tokens:
+        raise ValueError("%d calibration relevances > max_tokens = %d" % (3 * X.shape[0], engine.max_tokens))
+    done = False
+    try:
+        # ---- reference: exact fp32, same images, same relevance
+        engine.set_precision("fp32")
         engine.encode_images(X)
-        return _rel_l1(engine.cnn_explain(idx, R), ref)
+        feat = engine.get_features().clone()
+        if relevances is None:
+            relevances, img_idx = default_relevances(feat)
+        R = relevances.to(engine.device).float().contiguous()
+        idx = [int(i) for i in img_idx]
+        ref = engine.cnn_explain(idx, R).clone()
 
-    n_conv = len(engine.cnn_cfg)
-    floor = run(0)
-    # candidates: the layers the built-in rule would take (two-term needs a sum long enough to make sense; the top block,
-    # where the relevance is most concentrated, is tried last like every other layer — the measurement decides)
-    cand = [li for li in range(1, n_conv) if 9 * engine.cnn_cfg[li][1] >= 576 and 9 * engine.cnn_cfg[li][2] >= 576]
-    per_layer = {li: run(1 << li) for li in cand}
-    mask, err = 0, floor
-    if floor <= budget:
-        for li in sorted(cand, key=lambda q: per_layer[q]):
-            if per_layer[li] > budget:
-                break
-            e = run(mask | (1 << li))
-            if e <= budget:
-                mask, err = mask | (1 << li), e
-    res = dict(mask=mask, layers=[engine.cnn_cfg[li][0] for li in range(n_conv) if (mask >> li) & 1], error=err, floor=floor,
-               per_layer={engine.cnn_cfg[li][0]: per_layer[li] for li in cand}, budget=budget, reference="fp32",
-               candidates=[engine.cnn_cfg[li][0] for li in cand], n_images=int(X.shape[0]), n_relevances=int(R.shape[0]))
-    if apply:
-        engine.set_precision("f16x2")
-        engine.set_fast_layers(mask)
-    else:
-        engine.set_fast_layers(prev_mask)
-        engine.set_precision(prev_mode)
+        def run(mask):
+            engine.set_precision("f16x2")
+            engine.set_fast_layers(mask)
+            engine.encode_images(X)
+            return _rel_l1(engine.cnn_explain(idx, R), ref)
+
+        n_conv = len(engine.cnn_cfg)
+        floor = run(0)
+        # candidates: the layers the built-in rule would take (two-term needs a sum long enough to make sense; the top block,
+        # where the relevance is most concentrated, is tried last like every other layer — the measurement decides)
+        cand = [li for li in range(1, n_conv) if 9 * engine.cnn_cfg[li][1] >= 576 and 9 * engine.cnn_cfg[li][2] >= 576]
+        per_layer = {li: run(1 << li) for li in cand}
+        mask, err = 0, floor
+        if floor <= budget:
+            for li in sorted(cand, key=lambda q: per_layer[q]):
+                if per_layer[li] > budget:
+                    break
+                e = run(mask | (1 << li))
+                if e <= budget:
+                    mask, err = mask | (1 << li), e
+        res = dict(mask=mask, layers=[engine.cnn_cfg[li][0] for li in range(n_conv) if (mask >> li) & 1], error=err, floor=floor,
+                   per_layer={engine.cnn_cfg[li][0]: per_layer[li] for li in cand}, budget=budget, reference="fp32",
+                   candidates=[engine.cnn_cfg[li][0] for li in cand], n_images=int(X.shape[0]), n_relevances=int(R.shape[0]))
+        done = True
+    finally:
+        # every exit path leaves a defined state: the calibrated mix (apply, success) or the caller's mode and mask
+        if done and apply:
+            engine.set_precision("f16x2")
+            engine.set_fast_layers(mask)
+        else:
+            engine.set_fast_layers(prev_mask)
+            engine.set_precision(prev_mode)
     return res

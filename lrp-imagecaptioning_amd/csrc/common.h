@@ -1,6 +1,7 @@
 // common.h — error plumbing and small RAII helpers shared by the engine sources.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <string>
@@ -12,11 +13,12 @@ namespace lrp {
 
 // Every kernel launch of the library goes through hipLaunchKernelGGL; this wrapper counts them (lrp_launch_count: bench.py
 // reports the launches behind one single-image explanation next to its latency).  Memsets / copies are not counted.
-inline unsigned long long g_launch_count = 0;
+// (atomic, relaxed: handles may be driven from several host threads — bench.py's power probe does)
+inline std::atomic<unsigned long long> g_launch_count{0};
 #undef hipLaunchKernelGGL
 #define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                  \
   do {                                                                                                    \
-    ++::lrp::g_launch_count;                                                                              \
+    ::lrp::g_launch_count.fetch_add(1, std::memory_order_relaxed);                                       \
     kernelName<<<(numBlocks), (numThreads), (memPerBlock), (streamId)>>>(__VA_ARGS__);                   \
   } while (0)
 

@@ -1748,6 +1748,18 @@ inline bool conv_takes_breg(int n_out, int H, int W, bool have_frag) {
   return conv_halo_geom(128, H, W, tw, th, hrows) >= 0.9f;
 }
 
+// The 8-wave tile width of a split-format reverse-walk launch: 256 (256 x 256 tile), 128 (256 x 128, LRP_CONV_TILE=128 only) or 0.
+// ONE rule for conv_launch_epi and conv_takes_pw.
+inline int conv_wide_tile(int n_out, long mrows) {
+  if (n_out < 128 || (n_out % 128) != 0) return 0;
+  int wide = (n_out % 256) == 0 ? 256 : 0;               // measured: 256 x 128 loses to two 128 x 128 blocks per CU
+  if (conv_tile_override() == 128) wide = 128;
+  if (conv_tile_override() == 1) wide = 0;
+  // one 8-wave block per CU: only worth it when the grid still fills the chip ~1.5 times over
+  if (wide && ((mrows + 255) / 256) * (n_out / wide) < 400) wide = 0;
+  return wide;
+}
+
 // Would a split-bf16 3x3 MUL launch (N = n_out columns, NB x H x W rows) take a pipelined halo kernel — 128 x 128 or the 8-wave
 // 256 x 256 — and fit its loader of the compact pool interface (two items per thread and channel chunk)?  Mirrors the tile
 // choice of conv_launch_epi; LRP_UP2_PW=0 disables.
@@ -1756,7 +1768,9 @@ inline bool conv_takes_pw(int n_out, int NB, int H, int W) {
   if (!on || conv_halo_mode() <= 0 || conv_pick_tile(n_out).BN != 128 || (H & 1) || (W & 1)) return false;
   const long mrows = (long)NB * H * W;
   int BM = 128, threads = 256;
-  if ((n_out % 256) == 0 && conv_tile_override() != 1 && conv_tile_override() != 128 && ((mrows + 255) / 256) * (n_out / 256) >= 400) { BM = 256; threads = 512; }
+  const int wide = conv_wide_tile(n_out, mrows);
+  if (wide == 128) return false;                          // (LRP_CONV_TILE=128: the 256 x 128 tile has no resident-image variant)
+  if (wide == 256) { BM = 256; threads = 512; }
   if (BM == 128 && conv_small_tile_on() && ((mrows + 127) / 128) * ((n_out + 127) / 128) <= conv_small_tile_blocks()) return false;
   int tw, th, hrows;
   if (conv_halo_geom(BM, H, W, tw, th, hrows) < 0.9f) return false;
@@ -1866,13 +1880,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if (PREC != PREC_FP32 && (TERMS == 7 || PREC == PREC_F16X2) &&
       !(PREC == PREC_F16X2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL)) &&
       a.N >= 128 && (a.N % 128) == 0) {   // (blocked accumulation does not fit the 8-wave tile)
-    wide = (a.N % 256) == 0 ? 256 : 128;
-    if (wide == 128) wide = 0;                           // measured: 256 x 128 loses to two 128 x 128 blocks per CU
-    if (conv_tile_override() == 128 && (a.N % 128) == 0) wide = 128;
-    if (conv_tile_override() == 1) wide = 0;
-    // one 8-wave block per CU: only worth it when the grid still fills the chip ~1.5 times over
-    const long mrows = (long)a.NB * a.H * a.W;
-    if (wide && ((mrows + 255) / 256) * (a.N / wide) < 400) wide = 0;
+    wide = conv_wide_tile(a.N, (long)a.NB * a.H * a.W);
     if (wide) t = {256, wide};
   }
   a.M = a.NB * a.H * a.W;
@@ -1958,6 +1966,10 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
       }
     }
   }
+  // Only the resident-image kernels above read the compact pool interface.  A launch that carries it and got here (tile
+  // override, halo geometry below 0.9 for the tile actually chosen, fp32 operands) would run a kernel that ignores up2_src and
+  // reads a.in as a dense tensor: refuse instead of producing wrong heat-maps silently.
+  if (a.up2_src) return hipErrorInvalidValue;
   if (small_tile) {
     a.m_tiles = (a.M + 63) / 64;
     a.n_tiles = (a.N + 63) / 64;

@@ -103,7 +103,7 @@ static int with_handle(const lrp_handle* h, F&& body) noexcept {
 extern "C" {
 
 int lrp_abi_version(void) { return LRP_ABI_VERSION; }
-int64_t lrp_launch_count(void) { return (int64_t)lrp::g_launch_count; }
+int64_t lrp_launch_count(void) { return (int64_t)lrp::g_launch_count.load(std::memory_order_relaxed); }
 const char* lrp_last_error(void) { return last_error_ref().c_str(); }
 
 int lrp_create(const lrp_config* cfg, lrp_handle** out) {
@@ -677,6 +677,13 @@ int lrp_train_forward(lrp_handle* h, int32_t B, int32_t T, const int32_t* cap_in
     in.m_if = mask_image_features_dev; in.m_glob = mask_global_dev; in.m_out = mask_output_dev; in.m_lin = mask_lstm_in_dev;
     in.m_lrec = mask_lstm_rec_dev; in.st = S(stream);
     return h->trainer.forward(h->enc, in, &h->ws_bytes);
+  });
+}
+
+int lrp_train_drop_forward(lrp_handle* h, void* stream) {
+  return with_handle(h, [&]() -> int {
+    if (!h) return fail(LRP_ERR_INVALID, "null argument");
+    return h->trainer.drop_early_forward(S(stream));
   });
 }
 

@@ -117,7 +117,18 @@ struct ResNetEncoder {
       LRP_TRY(b.GA.alloc(B * (size_t)b.H * b.W * 4 * b.f * 4, total));
       LRP_TRY(b.GS.alloc(B * (size_t)b.H * b.W * 4 * b.f * 4, total));
     }
+    // staging of lrp_set_weight_dev (allocated here: that entry point promises no allocation / stream synchronisation)
+    size_t mx = 0, mxd = 0;
+    for (const RnUnit& q : units) {
+      mx = std::max(mx, (size_t)q.k * q.k * q.cin * q.cout);
+      mxd = std::max(mxd, (size_t)conv_npad(2 * q.cout) * q.k * q.k * conv_cinp(q.cin));
+    }
+    LRP_TRY(raw_tmp.alloc(mx * 4, total));
+    LRP_TRY(pack_tmp.alloc(mxd * 4, total));
     return LRP_OK;
+  }
+  ~ResNetEncoder() {
+    if (ev_pack) (void)hipEventDestroy(ev_pack);
   }
 
   int find_unit(const std::string& nm) const {
@@ -158,7 +169,11 @@ struct ResNetEncoder {
 
   // lrp_set_weight_dev for the encoder units: the array is already in HBM (RCCL broadcast); vectors are D2D copies, kernels
   // are packed by device kernels — no device-to-host copy, no stream synchronisation.  Returns 1 if the name is not ours.
-  DevBuf pack_tmp, raw_tmp;                              // largest interleaved dual matrix / largest HWIO kernel of any unit
+  // ONE staging pair for every unit (largest interleaved dual matrix / largest HWIO kernel): a call's packers read it
+  // asynchronously on that call's stream, so the NEXT call — possibly on another stream: an RCCL stream, then a compute
+  // stream — first makes its stream wait for `ev_pack`, recorded behind the previous call's last reader.
+  DevBuf pack_tmp, raw_tmp;
+  hipEvent_t ev_pack = nullptr;
   int set_weight_dev(const std::string& nm, const float* data_dev, int ndim, const int64_t* shape, int64_t* total, hipStream_t st) {
     static const char* suf[6] = {"_conv_W", "_conv_b", "_bn_gamma", "_bn_beta", "_bn_mean", "_bn_var"};
     for (int s = 0; s < 6; ++s) {
@@ -171,18 +186,12 @@ struct ResNetEncoder {
         if (ndim != 4 || shape[0] != u.k || shape[1] != u.k || shape[2] != u.cin || shape[3] != u.cout)
           return fail(LRP_ERR_INVALID, "%s: expected HWIO (%d,%d,%d,%d)", nm.c_str(), u.k, u.k, u.cin, u.cout);
         // own copy first: the packers run asynchronously, the caller's buffer need not outlive this call
-        if (!raw_tmp.p) {
-          size_t mx = 0, mxd = 0;
-          for (const RnUnit& q : units) {
-            mx = std::max(mx, (size_t)q.k * q.k * q.cin * q.cout);
-            mxd = std::max(mxd, (size_t)conv_npad(2 * q.cout) * q.k * q.k * conv_cinp(q.cin));
-          }
-          LRP_TRY(raw_tmp.alloc(mx * 4, total));
-          LRP_TRY(pack_tmp.alloc(mxd * 4, total));
-        }
         const size_t nW = (size_t)u.k * u.k * u.cin * u.cout;
+        if (!ev_pack) LRP_HIP_CHECK(hipEventCreateWithFlags(&ev_pack, hipEventDisableTiming));
+        else LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_pack, 0));          // the previous unit's packers still read the staging pair
         LRP_HIP_CHECK(hipMemcpyAsync(raw_tmp.p, data_dev, nW * 4, hipMemcpyDeviceToDevice, st));
         LRP_TRY(pack_unit_dev(u, raw_tmp.as<float>(), total, st));
+        LRP_HIP_CHECK(hipEventRecord(ev_pack, st));
       } else {
         if (ndim != 1 || shape[0] != u.cout) return fail(LRP_ERR_INVALID, "%s: expected (%d,)", nm.c_str(), u.cout);
         DevBuf* dst[6] = {nullptr, &u.bias, &u.gamma, &u.beta, &u.mean, &u.var};

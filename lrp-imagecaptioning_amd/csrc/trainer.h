@@ -272,8 +272,13 @@ struct Trainer {
     if (fwd_valid && fwd_B == B && fwd_T == T) {           // ran early (lrp_train_forward)
       // the backward scan must see the captions and dropout masks its forward saw (include/lrp_hip.h: lrp_train_forward)
       if (in.cap_in != fwd_cap || in.m_if != fwd_m_if || in.m_glob != fwd_m_glob || in.m_out != fwd_m_out || in.m_lin != fwd_m_lin ||
-          in.m_lrec != fwd_m_lrec)
-        return fail(LRP_ERR_INVALID, "lrp_train_step: cap_in / dropout masks differ from the ones the pending lrp_train_forward ran with");
+          in.m_lrec != fwd_m_lrec) {
+        // Refuse, and DROP the pending forward: its buffers may be released by the caller after this error, and a retry
+        // whose fresh arrays land on the same addresses must not pass the comparison above (it then runs its own forward).
+        LRP_TRY(drop_early_forward(st));
+        return fail(LRP_ERR_INVALID, "lrp_train_step: cap_in / dropout masks differ from the ones the pending lrp_train_forward ran with "
+                                     "(the pending forward was dropped)");
+      }
       LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_fwd, 0));
     } else {
       LRP_TRY(forward(enc, in, total));

@@ -283,21 +283,30 @@ class LRPEngine(object):
         'lstm_in' (T, 4, B, 2E), 'lstm_rec' (T, 4, B, H) (the LSTM cell's per-gate, per-step dropout).
         Returns (grads flat float32 device tensor, losses (5,) device tensor = total, loss head 1, loss head 2,
         accuracy head 1, accuracy head 2: the list `train_on_batch` returns)."""
-        ci, (mi, mg, mo, ml, mr, mz) = self._train_inputs(cap_in, masks, getattr(self, "_train_fwd_keep", None))
-        self._train_fwd_keep = None
-        yi = self._dev(y_idx, torch.int32)
-        B, T = ci.shape
-        lw = self._dev(lrp_weight).reshape(B, T, self.V)
-        if tuple(yi.shape) != (B, T):
-            raise ValueError("y_idx must have the shape of cap_in")
-        if int(yi.min()) < -1 or int(yi.max()) >= self.V:
-            raise ValueError("y_idx holds class indices outside [-1, V)")
-        if grads is None:
-            grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
-        losses = torch.empty(5, dtype=torch.float32, device=self.device)
-        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(ml), p(mr), p(mz),
-                                             p(grads), p(losses), self._stream()))
+        try:
+            ci, (mi, mg, mo, ml, mr, mz) = self._train_inputs(cap_in, masks, getattr(self, "_train_fwd_keep", None))
+            yi = self._dev(y_idx, torch.int32)
+            B, T = ci.shape
+            lw = self._dev(lrp_weight).reshape(B, T, self.V)
+            if tuple(yi.shape) != (B, T):
+                raise ValueError("y_idx must have the shape of cap_in")
+            if int(yi.min()) < -1 or int(yi.max()) >= self.V:
+                raise ValueError("y_idx holds class indices outside [-1, V)")
+            if grads is None:
+                grads = torch.empty(self.train_flat_size, dtype=torch.float32, device=self.device)
+            losses = torch.empty(5, dtype=torch.float32, device=self.device)
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            _capi.check(self._lib.lrp_train_step(self._h, B, T, p(ci), p(yi), p(lw), p(mi), p(mg), p(mo), p(ml), p(mr), p(mz),
+                                                 p(grads), p(losses), self._stream()))
+        except Exception:
+            # A refused / failed step must not leave the library holding pointers of an early forward whose device tensors
+            # are about to lose their keep-alive: torch would hand the same addresses to a retry's fresh masks and the
+            # pointer comparison in lrp_train_step would pass for buffers the forward never read.  Drop it first (the
+            # stream waits for the early forward), THEN release the tensors.
+            self._lib.lrp_train_drop_forward(self._h, self._stream())
+            self._train_fwd_keep = None
+            raise
+        self._train_fwd_keep = None                                         # consumed: the step's work is stream-ordered behind it
         return grads, losses
 
     def train_apply(self, grads):

@@ -81,3 +81,26 @@ def test_nothing_qualifies_and_restore():
     eng2 = FakeEngine({1: 1e-7}, floor=5e-5)
     res2 = calibrate_fast_mode(eng2, np.zeros((1, 8, 8, 3), np.float32))
     assert res2["mask"] == 0 and res2["error"] == res2["floor"] > res2["budget"]
+
+
+def test_an_exception_restores_the_callers_mode_and_mask():
+    """inputs are validated before the engine is touched, and a failure inside the measurement loop restores the
+    caller's mode and mask (try / finally) whether or not apply was asked for."""
+    import pytest
+    eng = FakeEngine({1: 2e-6})
+    eng.precision, eng.fast_layers = "bf16x3", 6
+    with pytest.raises(ValueError):                       # 3 relevances per image x 5 images > max_tokens = 12: refused up front
+        calibrate_fast_mode(eng, np.zeros((4, 8, 8, 3), np.float32)[:, :, :, :], relevances=torch.zeros((13, 4, 8)), img_idx=[0] * 13)
+    assert (eng.precision, eng.fast_layers, eng.calls) == ("bf16x3", 6, [])
+
+    class Boom(FakeEngine):
+        def cnn_explain(self, idx, R):
+            if self.precision == "f16x2" and len(self.calls) >= 2:
+                raise RuntimeError("LRP_ERR_HIP")
+            return FakeEngine.cnn_explain(self, idx, R)
+    for apply in (True, False):
+        eng = Boom({1: 2e-6, 2: 3e-6, 3: 4e-6})
+        eng.precision, eng.fast_layers = "fp32", 2
+        with pytest.raises(RuntimeError):
+            calibrate_fast_mode(eng, np.zeros((2, 8, 8, 3), np.float32), apply=apply)
+        assert (eng.precision, eng.fast_layers) == ("fp32", 2)

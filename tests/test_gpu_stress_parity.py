@@ -99,51 +99,128 @@ def test_vgg16_trained_like_weights_every_mode(name, density, sigma):
     assert max(r["dense"], r["onehot"], r["top20"]) < max(F16X2_WORST_CASE, 3 * noise["dense"]), r
 
 
-def test_trained_like_weights_through_the_decoder():
+DECODER_SEEDS = [(1, 5, 6), (2, 7, 8), (3, 9, 10), (4, 11, 12)]      # (encoder kernels, decoder weights, caption)
+
+
+def _undecidable_units(dec, w, feat_tol=1e-5):
+    """Units (location i, channel h) of relu(F.W_if + b_if) (E:378-381) whose float64 pre-activation is smaller than
+    `feat_tol` x sum_d |F[i,d] W[d,h]| + |b_h|: an evaluation whose features are only `feat_tol` close to float64 — the
+    reference's own float32 forward is 2e-6 away — cannot decide that ReLU."""
+    mag = np.abs(dec.F) @ np.abs(w["image_features_W"]) + np.abs(w["image_features_b"])
+    return {tuple(u) for u in np.argwhere(np.abs(dec.if_pre) < feat_tol * mag)}
+
+
+def _units(us):
+    return sorted([int(i), int(h)] for i, h in us)
+
+
+def _flips(dec_a, dec_b):
+    return {tuple(u) for u in np.argwhere((dec_a.if_pre > 0) != (dec_b.if_pre > 0))}
+
+
+@pytest.mark.parametrize("seeds", DECODER_SEEDS, ids=lambda s: "seed%d" % s[0])
+def test_trained_like_weights_through_the_decoder(seeds):
     """The same statistics end to end: decoder LRP (AdaptiveOracle, pinned by the reference's own outputs) -> CNN LRP, one
-    image, three words, every mode.  On these sparse features the decoder's LRP is ill-conditioned — it divides by cell
-    states and pre-activations, and a 2e-6 relative difference in the CNN features moves the heat-map by 1e-4 ... 7e-4
-    [measured on CPU: float32 vs float64 encoder forward in front of the same oracle decoder; the amplification varies by
-    two orders of magnitude with the rounding pattern] — so 'features equal to float64 within 1e-5' and 'explanation equal
-    given the features' are checked separately, and the end-to-end figure is recorded with the amplification beside it:
-      * features vs the float64 forward: 1e-5;
-      * the oracle decoder run on the ENGINE's features -> float64 literal graph vs the engine's heat-map: 1e-4
-        (decoder kernels + CNN walk on decoder-produced, concentrated, signed relevance);
-      * the CNN half alone on the engine's own R_feat: 1e-4."""
+    image, every default-grade mode, four draws of encoder kernels / decoder weights / caption.
+
+    On these sparse features the reference's algorithm has ONE discrete switch inside float32 noise, located in round 4
+    (DESIGN section 6): the ReLU of `_image_features = relu(F.W_if + b_if)` (E:378-381).  The attention-sum rule gives a
+    unit (i, h) the relevance r_ctx[h].alpha_i.V[i,h]/st(ctx[h]) (E:648-653) and the image_features rule divides it by
+    st(pre-activation) again (E:654-659): the product is r_ctx[h].alpha_i/ctx[h] x V/(V + 1e-7) — a FULL-SIZE share however
+    small V[i,h] is, and exactly 0 when the pre-activation is <= 0.  A pre-activation of +9e-7 in the reference's float32
+    forward and -3e-7 in float64 (seed 1: location 19, channel 295) therefore moves the heat-map by 1e-4 ... 7e-4 — the
+    bimodal figure VERDICT r3 reproduced — while every other decoder quantity agrees to 4e-7.
+
+    Asserted, bf16x3 (default) and fp32:
+      * features vs the float64 forward < 1e-5;
+      * the engine decides differently from float64 only on units no evaluation at that feature tolerance can decide
+        (_undecidable_units), and with those decisions aligned in the float64 reference (like an exact max-pool tie)
+        the END-TO-END heat-map is within 1e-4;
+      * un-aligned, END TO END: < max(1e-4, 3 x the reference's own float32 noise) where that noise is the distance of
+        the float32 pipeline (float32 C.forward -> AdaptiveOracle -> float32 literal graph: what TF/numpy compute) from
+        the float64 one, taken over both states of the switch when the engine and the float32 pipeline fell on
+        different sides of it;
+      * the oracle decoder on the ENGINE's features -> float64 literal graph vs the engine's heat-map < 1e-4;
+      * (first seed) the CNN half alone on the engine's own R_feat < 1e-4; f16x2 recorded, bounded by its worst case."""
     from lrp_imagecaptioning_amd.engine import LRPEngine
     from oracle.decoder_ref import AdaptiveOracle
-    w, X = _weights(0.05, 1.5)
+    ws, ds, cs = seeds
+    first = seeds == DECODER_SEEDS[0]
+    w, X = _weights(0.05, 1.5, ws)
     V = 500
-    w.update(adaptive_weights(np.random.RandomState(5), 196, 512, 512, 512, V))
-    cap = captions(np.random.RandomState(6), 1, 3, V)
+    w.update(adaptive_weights(np.random.RandomState(ds), 196, 512, 512, 512, V))
+    cap = captions(np.random.RandomState(cs), 1, 3, V)
     layers = C.vgg_layers(w, VGG16_CFG)
-    toks = (1, 3)
+    toks = (1, 3) if first else (3,)
+    nt = len(toks)
+    Xn = np.repeat(X, nt, 0)
+
+    def decoder_on(feat):
+        d = AdaptiveOracle(w, 196, 512, 512, 512)
+        d.forward(feat.astype(np.float32), cap[0])
+        return d
+
+    def heatmaps(dec, dtype=torch.float64):
+        return C.analyze(layers, Xn, np.concatenate([dec.explain(t)[0] for t in toks]), dtype)
+
+    def dist(a, b):
+        return max(rel_l1(a[i], b[i]) for i in range(nt))
+
     feat_ref = C.forward(layers, X)
-    dec = AdaptiveOracle(w, 196, 512, 512, 512)
-    dec.forward(feat_ref.astype(np.float32), cap[0])
-    ref64 = {t: C.analyze(layers, X, dec.explain(t)[0])[0] for t in toks}
+    dec64 = decoder_on(feat_ref)
+    ref64 = heatmaps(dec64)
+    undecidable = _undecidable_units(dec64, w)
+    # the reference's own arithmetic: float32 forward -> numpy decoder -> float32 literal graph
+    dec32 = decoder_on(C.forward(layers, X, torch.float32))
+    noise32 = dist(heatmaps(dec32, torch.float32), ref64)
+    flips32 = _flips(dec32, dec64)
+    assert flips32 <= undecidable, (flips32, undecidable)
+
+    def aligned_reference(flips, dec_side):
+        """float64 pipeline with the listed units' ReLU decisions taken from `dec_side`"""
+        d = decoder_on(feat_ref)
+        for u in flips:
+            d.if_pre[u], d.Vfeat[u] = dec_side.if_pre[u], dec_side.Vfeat[u]
+        return heatmaps(d)
+
+    report("stress_e2e_reference", seed=ws, tokens=list(toks), float32_pipeline=noise32,
+           float32_pipeline_flipped_units=_units(flips32), undecidable_units=_units(undecidable),
+           min_margin=float(np.min(np.abs(dec64.if_pre) / (np.abs(dec64.F) @ np.abs(w["image_features_W"])
+                                                            + np.abs(w["image_features_b"])))))
     eng = LRPEngine(decoder="adaptive", V=V, max_images=1, max_tokens=2, max_caption_len=4)
     eng.set_weights(w)
-    for prec in ("bf16x3", "fp32", "f16x2"):
+    for prec in (("bf16x3", "fp32", "f16x2") if first else ("bf16x3", "fp32")):
         eng.set_precision(prec)
         eng.encode_images(X)
         feat = eng.get_features().cpu().numpy().reshape(feat_ref.shape)
         e_feat = rel_l1(feat, feat_ref)
         eng.decoder_forward(cap)
-        out, Rf, _, _ = eng.explain_tokens([0, 0], list(toks), want_R_feat=True)
-        out, Rf = out.cpu().numpy(), Rf.cpu().numpy().reshape(2, 14, 14, 512)
-        cnn_only = C.analyze(layers, np.repeat(X, 2, 0), Rf)
-        e_cnn = max(rel_l1(out[i], cnn_only[i]) for i in range(2))
-        dec_e = AdaptiveOracle(w, 196, 512, 512, 512)                 # the oracle decoder on the engine's features
-        dec_e.forward(feat.astype(np.float32), cap[0])
-        e_given = max(rel_l1(out[i], C.analyze(layers, X, dec_e.explain(t)[0])[0]) for i, t in enumerate(toks))
-        e_all = max(rel_l1(out[i], ref64[t]) for i, t in enumerate(toks))
-        report("stress_decoder_" + prec, features=e_feat, cnn_half_on_engine_R_feat=e_cnn, given_engine_features=e_given,
-               end_to_end_vs_float64_pipeline=e_all, amplification=e_all / max(e_feat, 1e-30))
+        out, Rf, _, _ = eng.explain_tokens([0] * nt, list(toks), want_R_feat=True)
+        out, Rf = out.cpu().numpy(), Rf.cpu().numpy().reshape(nt, 14, 14, 512)
+        dec_e = decoder_on(feat)                                      # the oracle decoder on the engine's features
+        e_given = dist(out, heatmaps(dec_e))
+        e_all = dist(out, ref64)
+        flips = _flips(dec_e, dec64)
+        aligned = aligned_reference(flips, dec_e) if flips else ref64
+        e_aligned = dist(out, aligned)
+        # both states of the reference's switch: the float32 pipeline's side and, where the engine fell on the other
+        # side of an undecidable unit, the float64 reference moved to that side
+        noise = max(noise32, dist(aligned, ref64))
+        rec = dict(seed=ws, features=e_feat, given_engine_features=e_given, end_to_end_vs_float64_pipeline=e_all,
+                   end_to_end_decisions_aligned=e_aligned, flipped_units=_units(flips),
+                   reference_float32_noise=noise32, reference_noise_both_states=noise)
+        if first:
+            cnn_only = C.analyze(layers, Xn, Rf)
+            rec["cnn_half_on_engine_R_feat"] = e_cnn = dist(out, cnn_only)
+        report("stress_decoder_" + prec, **rec)
         assert e_feat < 1e-5, (prec, e_feat)
         if prec != "f16x2":
-            assert e_cnn < TOL, (prec, e_cnn)
+            assert flips <= undecidable, (prec, flips, undecidable)
             assert e_given < TOL, (prec, e_given)
+            assert e_aligned < TOL, (prec, rec)
+            assert e_all < max(TOL, 3 * noise), (prec, rec)
+            if first:
+                assert e_cnn < TOL, (prec, e_cnn)
         else:
             assert e_cnn < F16X2_WORST_CASE, e_cnn
 

@@ -427,6 +427,34 @@ def test_step_refuses_masks_other_than_the_early_forwards():
     assert torch.equal(g, g_ref)
 
 
+def test_refused_step_then_retry_with_fresh_masks_equals_a_plain_step():
+    """refuse, then RETRY.  After a refused step the early forward's device tensors lose their
+    keep-alive; torch's caching allocator hands the same addresses to the retry's fresh masks, and a library that still
+    held the early forward's pointers would accept them and back-propagate through masks that forward never applied.
+    The refusal (and any failed step) now drops the pending forward — lrp_train_step on a mismatch, lrp_train_drop_forward
+    (ABI v6) from engine.train_step's error path — so the retry runs its own forward: gradients equal to a plain step with
+    the NEW masks, bit for bit, both when the library refuses (other pointers) and when the host side does (bad labels)."""
+    w, X, cap_in, y, lw, masks = _case(13)
+    eng = _engine(w, len(X))
+    eng.train_begin()
+    eng.encode_images(X)
+    rs = np.random.RandomState(99)
+    fresh = lambda: {k: ((rs.uniform(size=v.shape) < 0.5) * 2.0).astype(np.float32) for k, v in masks.items()}
+    for how in ("library_refuses", "host_refuses"):
+        eng.train_forward(cap_in, masks)
+        with pytest.raises(ValueError):
+            if how == "library_refuses":
+                eng.train_step(cap_in, y, lw, {k: np.array(v) for k, v in masks.items()})
+            else:
+                eng.train_step(cap_in, np.full_like(np.asarray(y), 10 ** 6), lw, masks)
+        new = fresh()                                          # same shapes: the allocator reuses the released blocks
+        g = eng.train_step(cap_in, y, lw, new)[0].clone()
+        g_ref = eng.train_step(cap_in, y, lw, new)[0]          # a plain step (no early forward pending)
+        assert torch.equal(g, g_ref), how
+        g_old = eng.train_step(cap_in, y, lw, masks)[0]
+        assert not torch.equal(g, g_old)                       # (the masks do matter)
+
+
 def test_early_forward_is_dropped_by_a_new_encode_or_weight():
     """lrp_train_forward(batch 0) followed by lrp_encode_images(batch 1) — e.g. a loop whose explanation raised between
     the two — must NOT let lrp_train_step(batch 1) back-propagate through batch 0's activations: same (B, T), new
