@@ -272,6 +272,17 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
                 const float* aux_dev, float* out_dev, int32_t NB, int32_t H, int32_t W,
                 int32_t Cin, int32_t Cout, int32_t taps, int32_t mode, void* stream);
 
+/* ABI v6.  The conv-LRP launch BEHIND a 2x2 max-pool (AlphaBetaRule RR:274-322 for a conv whose output feeds MaxPooling2D: the
+ * relevance arrives through the pool's gradient routing, RA:470-480 -> IL:138-157, i.e. one non-zero per window and channel)
+ * on the 2:4-sparse matrix cores (csrc/conv_sparse.h): out[n][y][x][ci] = gate[n][y][x][ci] x sum over taps, co of
+ * S[n][y+dy][x+dx][co] w+[..], with S given in COMPACT form — sc_dev (NB, Hp, Wp, Cout) fp32 = the value of each window's
+ * non-zero, pos_dev (same shape, bytes) = its position 2 dy + dx.  w_hwio_host (3, 3, Cin, Cout) like lrp_op_conv's backward
+ * modes; gate_dev / out_dev (NB, 2 Hp, 2 Wp, Cin) fp32.  Split-bf16 arithmetic (three matrix instructions per product).
+ * Needs Cin % 256 == 0, Cout % 16 == 0.  reps >= 1 repeats the launch (profiling).  Same values as lrp_op_conv mode 2 with
+ * LRP_CONV_SPLIT_BF16 on the expanded tensor up to the summation order (tests/test_gpu_conv_sparse.py). */
+int lrp_op_conv_pool_sparse(const float* sc_dev, const unsigned char* pos_dev, const float* w_hwio_host, const float* gate_dev,
+                            float* out_dev, int32_t NB, int32_t Hp, int32_t Wp, int32_t Cin, int32_t Cout, int32_t reps, void* stream);
+
 /* Operator-level entries for the other rules LRPSequentialPresetA can reach (not on the
  * truncated-VGG16 path; ResNet-101 "next" row).  All pointers device memory unless `_host`.
  * EpsilonRule with bias=False (RR:113-144, RA:706-711): x (N,Din), W_host (Din,Dout) Keras
@@ -388,6 +399,13 @@ int lrp_train_get_master(lrp_handle* h, float* flat_dev, void* stream);
 /* ABI v4.  Kernel launches issued by this library since it was loaded (all handles, this process; copies and memsets not
  * counted): bench.py brackets one single-image explanation with it (`latency.launches`). */
 int64_t lrp_launch_count(void);
+
+/* ABI v6.  The library's A/B switches (LRP_CONV_HALO, LRP_UP2_PW, LRP_IMG_FOLD, ... — measurement knobs and
+ * tested fall-backs, every one exercised by tests/test_gpu_switches.py) are read from the environment once per process, not on
+ * the launch path; this re-reads them.  For tests and measurement scripts: call it between launches, never while another
+ * thread is inside the library.  A switch that changes how lrp_encode_images lays out its caches takes effect at the next
+ * lrp_encode_images.  The reference has no counterpart. */
+int lrp_reload_switches(void);
 
 const char* lrp_last_error(void);
 int lrp_abi_version(void);

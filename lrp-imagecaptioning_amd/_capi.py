@@ -74,6 +74,8 @@ SYMBOLS = {
     "lrp_train_step": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "lrp_train_forward": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "lrp_train_drop_forward": (C.c_int, [_P, _P]),
+    "lrp_reload_switches": (C.c_int, []),
+    "lrp_op_conv_pool_sparse": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "lrp_train_apply": (C.c_int, [_P, _P, _P]),
     "lrp_train_get_master": (C.c_int, [_P, _P, _P]),
     "lrp_heatmap_render": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P]),

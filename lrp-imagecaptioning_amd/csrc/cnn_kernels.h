@@ -38,40 +38,6 @@ __global__ __launch_bounds__(256) void im2col_image_kernel(const float* __restri
   *reinterpret_cast<f32x4*>(A1 + idx * 8 + 4) = *reinterpret_cast<const f32x4*>(v + 4);
 }
 
-// The same matrix as the operand of the fp16-pair GEMM: per pixel 8 split8 groups [8 x fp16 hi | 8 x fp16 lo] of the patch
-// values x scale[image] (a power of two from the image's own measured maximum: exact), one group per thread, 32-byte stores.
-// The image layer then runs on the f16 MFMA like every other layer of the dual forward (3 MFMAs of 32 cycles per 16 k
-// instead of 8 fp32 MFMAs of 64) and its GEMM becomes store-bound.  OPT-IN (LRP_FWD_L0_F16=1) [MI355X: encode of 32 images
-// 6.8 -> 6.4 ms, but the 22-bit products of the FIRST layer — whose error every later layer inherits — put the features of
-// the sparse trained-like nets at 1.0e-5 instead of 6.3e-6 from float64 (tests/test_gpu_stress_parity.py; He-normal
-// VGG16: 7.2e-7 either way): the default keeps the exact fp32 MFMA here].
-__global__ __launch_bounds__(256) void im2col_image_pairs_kernel(const float* __restrict__ img, float* __restrict__ A1,
-                                                                 const float* __restrict__ scale, int NB, int H, int W) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // (pixel, group)
-  const size_t total = (size_t)NB * H * W * 8;
-  if (idx >= total) return;
-  const int g = (int)(idx & 7);
-  const size_t m = idx >> 3;
-  const int HW = H * W;
-  const int n = (int)(m / HW), rem = (int)(m - (size_t)n * HW);
-  const int h = rem / W, w = rem - h * W;
-  const bool neg = g >= 4;                                 // groups 0-3: x+ patch (k 0..31), 4-7: x- patch
-  const float sc = scale[n];
-  float v[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int kk = 8 * (g & 3) + q;
-    float x = 0.f;
-    if (kk < 27) {
-      const int t = kk / 3, c = kk - 3 * t;
-      const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-      if (hh >= 0 && hh < H && ww >= 0 && ww < W) x = img[(((size_t)n * H + hh) * W + ww) * 3 + c];
-    }
-    v[q] = (neg ? (x < 0.f ? x : 0.f) : (x >= 0.f ? x : 0.f)) * sc;
-  }
-  split8h_store(v, A1 + idx * 8);
-}
-
 // No pool after layer l:  G_l = a_l / safe(Z_l)     (x_{l+1} = a_l)
 // (a and g may be the same buffer: the overlapped encode keeps a_l in the gate's storage until the gate is due)
 __global__ __launch_bounds__(256) void gate_kernel(const f32x4* a, const f32x4* __restrict__ z, f32x4* g, size_t n4) {
@@ -155,28 +121,6 @@ __global__ __launch_bounds__(256) void split_copy_kernel(const float* __restrict
     *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
     *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
     split8_store(v, xs + i * 8);
-  }
-}
-
-// fp32 NHWC -> the two operand tensors of the three-way split forward product: x1 = [h8 | m8], x2 = [h8 | l8]
-__global__ __launch_bounds__(256) void split3_copy_kernel(const float* __restrict__ x, float* __restrict__ x1,
-                                                          float* __restrict__ x2, size_t n8) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
-    float v[8];
-    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + i * 8);
-    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + i * 8 + 4);
-    bf16x8 h, m, l;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      h[q] = (__bf16)v[q];
-      const float r1 = v[q] - (float)h[q];
-      m[q] = (__bf16)r1;
-      l[q] = (__bf16)(r1 - (float)m[q]);
-    }
-    u32x4* d1 = reinterpret_cast<u32x4*>(x1 + i * 8);
-    u32x4* d2 = reinterpret_cast<u32x4*>(x2 + i * 8);
-    d1[0] = __builtin_bit_cast(u32x4, h); d1[1] = __builtin_bit_cast(u32x4, m);
-    d2[0] = __builtin_bit_cast(u32x4, h); d2[1] = __builtin_bit_cast(u32x4, l);
   }
 }
 

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,42 @@ inline std::atomic<unsigned long long> g_launch_count{0};
   } while (0)
 
 std::string& last_error_ref();
+
+// A/B switches kept for measurement and as tested fall-backs (every one of them is exercised by
+// tests/test_gpu_switches.py against the default path).  Read from the environment ONCE per process — no getenv on the launch
+// path — and again by lrp_reload_switches() (include/lrp_hip.h), which is how a test or a measurement script flips one.
+struct Switches {
+  int conv_halo = 1;        // LRP_CONV_HALO  0 never / 1 when a tile shape fills >= 90 % of the M tile / 2 always (ragged shapes: tests)
+  int conv_breg = 1;        // LRP_CONV_BREG=0     N <= 64 backward convs without the weights-in-registers kernel
+  int conv_tile = 0;        // LRP_CONV_TILE  0 auto / 1 never the 8-wave tiles / 128 cap them at 256 x 128
+  int conv_small = 1;       // LRP_CONV_SMALL=0    small grids keep the 128-row tiles (no 64 x 64 tiles)
+  int conv_mid = 1;         // LRP_CONV_MID=0      no 128 x 64 tiles for the grids just above the small ones
+  int epi_fast = 1;         // LRP_EPI_FAST=0      MUL / MUL_UP2 epilogues always through the general pass loop
+  int up2_pw = 1;           // LRP_UP2_PW=0        pooled boundaries of the pipelined halo kernels through the expanded tensor
+  int tile_order = 1;       // LRP_TILE_ORDER=0    reverse-walk launches in stack order
+  int fwd_emit = 1;         // LRP_FWD_EMIT=0      forward: split / absmax / pool passes between the convs
+  int fwd_il = 1;           // LRP_FWD_IL=0        dual forward matrix with stacked rows: separate gate pass (decided when lrp_set_weight packs)
+  int img_fused = 1;        // LRP_IMG_FUSED=0     image layer as T GEMM + separate stencil kernel
+  int up2_compact = 1;      // LRP_UP2_COMPACT=0   expanded pool interface between block2_conv1 and block1_conv2
+  int up2_gc = 1;           // LRP_UP2_GC=0        that interface with the full-resolution pool gate
+  int up2_breg_pairs = 1;   // LRP_UP2_BREG_PAIRS=0  block2_conv1 writes its plain fp32 product instead of pairs
+  int img_fold = 1;         // LRP_IMG_FOLD=0      image layer as its own launch
+  int dec_batched = 1;      // LRP_DEC_BATCHED=0   decoder LRP: one workgroup per unit instead of the step-synchronous scan
+  int dec_mfma_fwd = 1;     // LRP_DEC_MFMA_FWD=0  decoder forward: VALU skinny GEMMs
+  void load() {
+    *this = Switches();
+    auto rd = [](const char* name, int& v) { if (const char* e = getenv(name)) v = atoi(e); };
+    rd("LRP_CONV_HALO", conv_halo); rd("LRP_CONV_BREG", conv_breg); rd("LRP_CONV_TILE", conv_tile); rd("LRP_CONV_SMALL", conv_small);
+    rd("LRP_CONV_MID", conv_mid); rd("LRP_EPI_FAST", epi_fast); rd("LRP_UP2_PW", up2_pw); rd("LRP_TILE_ORDER", tile_order);
+    rd("LRP_FWD_EMIT", fwd_emit); rd("LRP_FWD_IL", fwd_il); rd("LRP_IMG_FUSED", img_fused); rd("LRP_UP2_COMPACT", up2_compact);
+    rd("LRP_UP2_GC", up2_gc); rd("LRP_UP2_BREG_PAIRS", up2_breg_pairs); rd("LRP_IMG_FOLD", img_fold); rd("LRP_DEC_BATCHED", dec_batched);
+    rd("LRP_DEC_MFMA_FWD", dec_mfma_fwd);
+  }
+};
+inline Switches& sw() {
+  static Switches s = [] { Switches t; t.load(); return t; }();
+  return s;
+}
 
 inline int fail(int code, const char* fmt, ...) {
   char buf[512];

@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <vector>
 
+#include "common.h"
+
 namespace lrp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1698,31 +1700,19 @@ inline ConvTile conv_pick_tile(int N) {
 inline int conv_npad(int N) { ConvTile t = conv_pick_tile(N); return (N + t.BN - 1) / t.BN * t.BN; }
 inline int conv_cinp(int Cin) { return (Cin + 31) / 32 * 32; }
 
-// experiment knob (env LRP_CONV_TILE): 0 = auto, 1 = never use the 8-wave tiles, 128 = cap them at 256 x 128
-inline int conv_tile_override() {
-  static const int v = [] { const char* e = getenv("LRP_CONV_TILE"); return e ? atoi(e) : 0; }();
-  return v;
-}
+// switch LRP_CONV_TILE: 0 = auto, 1 = never use the 8-wave tiles, 128 = cap them at 256 x 128
+inline int conv_tile_override() { return sw().conv_tile; }
 
-// small grids take 64 x 64 tiles (conv_launch_epi): LRP_CONV_SMALL=0 disables, LRP_CONV_SMALL_BLOCKS = the 128-row grid size
-// up to which they are used (default 128: 4x as many 64 x 64 workgroups = the 512 that are resident at once; beyond that a
-// second round of small tiles costs more than the large tiles' idle CUs [MI355X, one image, 252 large tiles: 115 -> 145 us])
+// small grids take 64 x 64 tiles (conv_launch_epi): LRP_CONV_SMALL=0 disables; they are used up to a 128-row grid of 128 tiles
+// (4x as many 64 x 64 workgroups = the 512 that are resident at once; beyond that a second round of small tiles costs more
+// than the large tiles' idle CUs [MI355X, one image, 252 large tiles: 115 -> 145 us])
 constexpr int CONV_SMALL_NS = 4;                       // LDS stages of the 64 x 64 tile's k pipeline (4 x 16 KB: two workgroups per CU... see NS)
-inline bool conv_small_tile_on() {                      // (read per launch so that a test can flip it)
-  const char* e = getenv("LRP_CONV_SMALL");
-  return !e || atoi(e) != 0;
-}
-inline long conv_small_tile_blocks() {
-  static const long v = [] { const char* e = getenv("LRP_CONV_SMALL_BLOCKS"); return e ? atol(e) : 128L; }();
-  return v;
-}
+inline bool conv_small_tile_on() { return sw().conv_small != 0; }
+constexpr long conv_small_tile_blocks() { return 128L; }
 
-// halo-resident variant: env LRP_CONV_HALO = 0 never, 1 (default) when a tile shape fills >= 90 % of the M tile,
-// 2 always (tests: ragged tile shapes).  Read per launch so a test can flip it.
-inline int conv_halo_mode() {
-  const char* e = getenv("LRP_CONV_HALO");
-  return e ? atoi(e) : 1;
-}
+// halo-resident variant: switch LRP_CONV_HALO = 0 never, 1 (default) when a tile shape fills >= 90 % of the M tile,
+// 2 always (tests: ragged tile shapes)
+inline int conv_halo_mode() { return sw().conv_halo; }
 // best (tw, th, pitch) for a BM-row tile on an H x W image stack; returns the fraction of MFMA rows doing real work
 inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) {
   const int avail = conv_halo_rows(BM) / HALO_PITCH;   // resident image rows that fit
@@ -1742,8 +1732,7 @@ inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) 
 // Would a 3x3 MUL launch with N = n_out, input H x W, take the weights-in-registers kernel?  (Encoder::explain asks before it
 // chooses the compact pool interface, which only that kernel reads.)
 inline bool conv_takes_breg(int n_out, int H, int W, bool have_frag) {
-  static const int breg = [] { const char* e = getenv("LRP_CONV_BREG"); return e ? atoi(e) : 1; }();
-  if (!breg || !have_frag || conv_halo_mode() <= 0 || n_out > 64 || n_out <= 32) return false;
+  if (!sw().conv_breg || !have_frag || conv_halo_mode() <= 0 || n_out > 64 || n_out <= 32) return false;
   int tw, th, hrows;
   return conv_halo_geom(128, H, W, tw, th, hrows) >= 0.9f;
 }
@@ -1764,8 +1753,7 @@ inline int conv_wide_tile(int n_out, long mrows) {
 // 256 x 256 — and fit its loader of the compact pool interface (two items per thread and channel chunk)?  Mirrors the tile
 // choice of conv_launch_epi; LRP_UP2_PW=0 disables.
 inline bool conv_takes_pw(int n_out, int NB, int H, int W) {
-  static const int on = [] { const char* e = getenv("LRP_UP2_PW"); return e ? atoi(e) : 1; }();
-  if (!on || conv_halo_mode() <= 0 || conv_pick_tile(n_out).BN != 128 || (H & 1) || (W & 1)) return false;
+  if (!sw().up2_pw || conv_halo_mode() <= 0 || conv_pick_tile(n_out).BN != 128 || (H & 1) || (W & 1)) return false;
   const long mrows = (long)NB * H * W;
   int BM = 128, threads = 256;
   const int wide = conv_wide_tile(n_out, mrows);
@@ -1779,8 +1767,7 @@ inline bool conv_takes_pw(int n_out, int NB, int H, int W) {
 
 // device table of a.order for this call's token -> image map (see TileOrder); nullptr when the stack order is as good
 inline const int* conv_tile_order(const ConvArgs& a, hipStream_t st) {
-  static const int on = [] { const char* e = getenv("LRP_TILE_ORDER"); return e ? atoi(e) : 1; }();
-  if (!on || !a.order || !a.row2img_host || a.NB < 2 || a.th < 1) return nullptr;
+  if (!sw().tile_order || !a.order || !a.row2img_host || a.NB < 2 || a.th < 1) return nullptr;
   TileOrder& o = *a.order;
   const int tiles_y = a.tpt > 0 ? a.NB * a.tpt : (a.nyh + a.th - 1) / a.th;
   const bool same = o.H == a.H && o.th == a.th && o.nyh == a.nyh && o.cols_t == a.cols_t && o.tpt == a.tpt && (int)o.sig.size() == a.NB &&
@@ -1788,8 +1775,7 @@ inline const int* conv_tile_order(const ConvArgs& a, hipStream_t st) {
   if (same) return o.identity ? nullptr : o.dev;
   o.sig.assign(a.row2img_host, a.row2img_host + a.NB);
   o.H = a.H; o.th = a.th; o.nyh = a.nyh; o.cols_t = a.cols_t; o.tpt = a.tpt;
-  static const int band = [] { const char* e = getenv("LRP_TILE_BAND"); return e && atoi(e) > 0 ? atoi(e) : 1; }();
-  static const int strip = [] { const char* e = getenv("LRP_TILE_STRIP"); return e ? atoi(e) : 2; }();   // column tiles per strip; 0 = whole rows
+  constexpr int band = 1, strip = 2;                   // row band of `band` tile rows per token; column tiles per strip (measured, round 2)
   std::vector<long long> key((size_t)tiles_y);
   for (int ty = 0; ty < tiles_y; ++ty) {
     int Ym = a.tpt > 0 ? (ty / a.tpt) * a.H + (ty % a.tpt) * a.th + a.th / 2 : ty * a.th + a.th / 2;
@@ -1872,7 +1858,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   if (PREC == PREC_FP32 && t.BN == 128 && (a.N % 64) == 0) {
     // few M rows (the per-image forward at batch 32): 128 x 128 tiles leave CUs idle; halve the tile
     // [MI355X] encode of 32 images 14.06 -> 13.54 ms with the threshold at 2200 blocks (~4 waves of 512 slots)
-    static const int thr = [] { const char* e = getenv("LRP_SMALLTILE_BLOCKS"); return e ? atoi(e) : 2200; }();
+    constexpr int thr = 2200;
     const long blocks = (((long)a.NB * a.H * a.W + 127) / 128) * ((a.N + 127) / 128);
     if (blocks < thr) t = {128, 64};
   }
@@ -1887,7 +1873,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   a.m_tiles = (a.M + t.BM - 1) / t.BM;
   a.n_tiles = (a.N + t.BN - 1) / t.BN;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  { const char* e = getenv("LRP_EPI_FAST"); a.epi_generic = (e && atoi(e) == 0) ? 1 : 0; }
+  a.epi_generic = sw().epi_fast ? 0 : 1;
   // Small grids (one image, a handful of words: explain_image.py's own call): with 128-row tiles the 14 x 14 / 28 x 28
   // layers are 16-250 workgroups, each walking K = 2304-4608 alone — the launch takes as long as ONE tile's K loop
   // [MI355X, B = 1, T = 10: 115-119 us per block4 / block5 launch, forward and backward].  64 x 64 tiles (4 waves of
@@ -1897,9 +1883,8 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
                           !a.up2_src && !a.img_part;
   // In between (at most one large tile per CU, but too many for the 64 x 64 tiles to stay resident): 128 x 64 tiles put two
   // workgroups on a CU and halve a k-step — same chains, same bits [MI355X, one image, ten words: block4's walk launches
-  // (252 large tiles) 115 -> ~80 us, explain 1.62 -> 1.51 ms].  LRP_CONV_MID=0 disables (read per launch, like LRP_CONV_SMALL).
-  const char* mid_env = getenv("LRP_CONV_MID");
-  const bool mid_on = !mid_env || atoi(mid_env) != 0;
+  // (252 large tiles) 115 -> ~80 us, explain 1.62 -> 1.51 ms].  LRP_CONV_MID=0 disables.
+  const bool mid_on = sw().conv_mid != 0;
   if (mid_on && !small_tile && conv_small_tile_on() && t.BM == 128 && t.BN == 128 && (a.N % 64) == 0 && !a.up2_src && !a.img_part &&
       (long)a.m_tiles * a.n_tiles <= 2 * conv_small_tile_blocks()) {
     t = {128, 64};
@@ -1912,8 +1897,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
     // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
     if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
       // N <= 64: resident image + weights in registers, no barrier per tap (LRP_CONV_BREG=0 disables)
-      static const int breg = [] { const char* e = getenv("LRP_CONV_BREG"); return e ? atoi(e) : 1; }();
-      if (a.taps == 9 && mode > 0 && breg && t.BN == 64 && a.n_tiles == 1 && a.wpk_frag) {
+      if (a.taps == 9 && mode > 0 && sw().conv_breg && t.BN == 64 && a.n_tiles == 1 && a.wpk_frag) {
         // (256-row tiles, 8 waves, one block per CU, halve the weight traffic per pixel but lose more to the single
         // block per CU  [MI355X: block1_conv2 bwd 4.19 ms vs 3.83 ms with these 128-row tiles, 3 blocks per CU])
         const float u = conv_halo_geom(t.BM, a.H, a.W, a.tw, a.th, a.hrows);
@@ -1999,11 +1983,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
 
 // prec = PREC_BF16X3 exists for the reverse-walk epilogues (MUL, MUL_UP2, STORE) and the forward Z+ conv (BIAS)
 inline hipError_t conv_launch(int epi, const ConvArgs& a, hipStream_t st, int prec = PREC_FP32, int terms = 7) {
-  if (prec == PREC_BF16X3 && terms != 7) {             // the two passes of the three-way split forward product
-    if (epi == EPI_BIAS && terms == 15) return conv_launch_epi<EPI_BIAS, PREC_BF16X3, 15>(a, st);
-    if (epi == EPI_BIAS_RELU && terms == 3) return conv_launch_epi<EPI_BIAS_RELU, PREC_BF16X3, 3>(a, st);
-    return hipErrorInvalidValue;
-  }
+  if (prec == PREC_BF16X3 && terms != 7) return hipErrorInvalidValue;   // (the two-pass three-way split forward product of rounds 1-2 is gone)
   if (prec == PREC_F16X2) {                            // reverse walk of the VGG encoder only
     // terms 7: S(hi + lo) x w(hi + lo) without lo*lo — three MFMAs; terms 5: the weights' lo half dropped — two.  Which
     // layers take which is the caller's rule (Encoder::explain: two-term up to the last pool, measured there).
@@ -2096,22 +2076,6 @@ inline void pack_frag64(const float* split8_pk, int taps, int CP, float* dst) {
             const int c = 4 * (q >> 1) + 2 * hh + (q & 1);          // 16 B chunk of the 128 B tap-chunk row
             memcpy(dst + ((((size_t)kc * 4 + q) * 2 + hh) * 64 + n) * 4, split8_pk + (size_t)n * K + t * CP + cc * 32 + c * 4, 16);
           }
-    }
-}
-
-// three-way split x = h + m + l; out1 = [h8 | m8] (== pack_split8), out2 = [h8 | l8]
-inline void pack_split8_3way(const float* src, size_t n_floats, float* out1, float* out2) {
-  unsigned short* d1 = reinterpret_cast<unsigned short*>(out1);
-  unsigned short* d2 = reinterpret_cast<unsigned short*>(out2);
-  for (size_t g = 0; g < n_floats / 8; ++g)
-    for (int q = 0; q < 8; ++q) {
-      const float x = src[g * 8 + q];
-      const unsigned short h = f32_to_bf16_rne(x);
-      const float r1 = x - bf16_to_f32(h);
-      const unsigned short m = f32_to_bf16_rne(r1);
-      const unsigned short l = f32_to_bf16_rne(r1 - bf16_to_f32(m));
-      d1[g * 16 + q] = h; d1[g * 16 + 8 + q] = m;
-      d2[g * 16 + q] = h; d2[g * 16 + 8 + q] = l;
     }
 }
 

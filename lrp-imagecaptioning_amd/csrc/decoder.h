@@ -940,27 +940,18 @@ struct Decoder {
         g[(size_t)d * H + j] = d < Kx ? Wi[(size_t)d * 4 * H + 2 * H + j] : Wh[(size_t)(d - Kx) * 4 * H + 2 * H + j];
     return g;
   }
-  // tail GEMM of the decoder LRP (R at the image_features layer back to the CNN features): exact fp32 MFMA by default —
-  // its split-bf16 form saves 0.2 ms of a 40 ms step and costs the decoder half 5x of its parity margin
-  // (R_feat 3-10e-6 instead of 0.4-1.2e-6 vs the float64 oracle).  LRP_DEC_TAIL_SPLIT=1 re-enables it.
-  static bool tail_split() {
-    static const bool v = [] { const char* e = getenv("LRP_DEC_TAIL_SPLIT"); return e && atoi(e) != 0; }();
-    return v;
-  }
+  // tail GEMM of the decoder LRP (R at the image_features layer back to the CNN features): exact fp32 MFMA — its split-bf16 form
+  // saved 0.2 ms of a 40 ms step and cost the decoder half 5x of its parity margin (R_feat 3-10e-6 instead of 0.4-1.2e-6 vs
+  // the float64 oracle); it was kept behind LRP_DEC_TAIL_SPLIT until round 4.
+  static constexpr bool tail_split() { return false; }
   DevBuf sg_ws;                                        // K-split partials of the forward's matrix-core products
   static constexpr size_t SG_WS_FLOATS = (size_t)4 << 20;
   int need_sg_ws() {
     if (!sg_ws.p) { int64_t dummy = 0; LRP_TRY(sg_ws.alloc(SG_WS_FLOATS * sizeof(float), &dummy)); }
     return LRP_OK;
   }
-  static bool mfma_forward() {
-    static const bool v = [] { const char* e = getenv("LRP_DEC_MFMA_FWD"); return !e || atoi(e) != 0; }();
-    return v;
-  }
-  static bool batched_scan() {            // LRP_DEC_BATCHED=0: one workgroup per unit (dec_explain_adaptive_kernel)
-    const char* e = getenv("LRP_DEC_BATCHED");
-    return !e || atoi(e) != 0;
-  }
+  static bool mfma_forward() { return sw().dec_mfma_fwd != 0; }   // LRP_DEC_MFMA_FWD=0: VALU skinny GEMMs in the forward
+  static bool batched_scan() { return sw().dec_batched != 0; }    // LRP_DEC_BATCHED=0: one workgroup per unit (dec_explain_adaptive_kernel)
   int bx_prepare(int64_t* total, hipStream_t st = nullptr) {
     if (bx_ready) return LRP_OK;
     const size_t NT = NT_max;

@@ -26,9 +26,7 @@ struct ConvLayer {
   DevBuf w_fwd;    // dual-packed forward weights  (a_l | Z+_l)          [fp32 mode, and the image layer]
   DevBuf w_fwd_a;  // forward weights w, fp32                            [mixed mode: exact activation conv]
   DevBuf w_fwd_zs; // forward weights w+, split8                         [mixed mode: bf16x3 denominator conv]
-  DevBuf w_fwd_as; // forward weights w, split8 = [h | m] of the three-way split   [activation conv, passes A / fast mode]
-  DevBuf w_fwd_al; // forward weights w, [h | l] of the three-way split            [activation conv, pass B]
-  DevBuf w_fwd_ah; // forward weights w as fp16 pairs [hi8 | lo8]                   [activation conv on the f16 MFMA]
+  DevBuf w_fwd_as; // forward weights w, split8                                    [activation conv, LRP_PREC_BF16X3_FAST]
   DevBuf w_fwd_h;  // the dual matrix (w | w+) of w_fwd as fp16 pairs, one common scale (record wds)   [a_l and Z+_l in one pass, default]
   DevBuf wds;
   DevBuf w_bwd;    // w+ (and w- for the image layer), tap-flipped, packed for convT-as-conv
@@ -37,7 +35,7 @@ struct ConvLayer {
   DevBuf w_bwd_full_s;  // the same in split8 form: backward-data conv of the fine-tune step on the bf16 matrix cores
   DevBuf w_bwd_h;     // w_bwd in fp16 split8 form [hi8 | lo8] (PREC_F16X2 reverse walk: only hi is read), and ...
   DevBuf w_bwd_frag_h;   // ... fragment-major for the weights-in-registers kernel
-  DevBuf wbs, wfs;    // device records {2^k, 2^-k, norm, k} of the fp16 copies' power-of-two scales (backward / forward matrix)
+  DevBuf wbs;         // device record {2^k, 2^-k, norm, k} of the fp16 backward copy's power-of-two scale
   DevBuf w_fwd_il;    // the dual forward matrix with its rows interleaved per 32 channels ([w | w+] side by side): fp32 source of w_fwd_h
   std::unique_ptr<TileOrder> order{new TileOrder};   // tile-row order of this layer's reverse launch (conv_igemm.h)
   DevBuf w_bwd_frag;  // w_bwd_s fragment-major (layers whose backward conv has N = cin <= 64: weights-in-registers kernel)
@@ -86,9 +84,7 @@ struct Encoder {
   // otherwise bit li (lrp_set_fast_layers: a per-model choice, e.g. from calibration.py's measured per-layer error).
   int64_t t2_mask_user = -1;
   bool two_term(int li) const {
-    static const int t2env = [] { const char* e = getenv("LRP_F16_T2MASK"); return e ? (int)strtol(e, nullptr, 0) : -1; }();
     if (li <= 0 || li >= (int)layers.size()) return false;
-    if (t2env >= 0) return ((t2env >> li) & 1) != 0;                  // (experiments)
     if (t2_mask_user >= 0) return ((t2_mask_user >> li) & 1) != 0;
     int last_pool = -1;
     for (size_t q = 0; q < layers.size(); ++q)
@@ -99,11 +95,7 @@ struct Encoder {
                            // 1e-4 bar; tests/test_gpu_stress_parity.py), so the default is the three-MFMA split-bf16 walk.
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
   DevBuf out_scale;                   // ... and 2^k of the pairs a layer emits for its consumer (no split pass in between)
-  DevBuf unit_norm;                   // {1, 0}: fwd_scale_kernel's "bound" is then the measured maximum itself (the images' pairs)
-  static bool fwd_emit() {            // LRP_FWD_EMIT=0: split passes between the convs as in round 2
-    const char* e = getenv("LRP_FWD_EMIT");
-    return !e || atoi(e) != 0;
-  }
+  static bool fwd_emit() { return sw().fwd_emit != 0; }   // LRP_FWD_EMIT=0: split passes between the convs as in round 2
   DevBuf tok_exp, tok_max, tok_fac;   // its per-token scale exponents / measured maxima [layers + 1][max_tokens], factors [max_tokens]
   std::vector<ProfileRec> prof;
   // Overlapped encode (mixed-precision mode): the caller's stream runs only the activation chain a_1..a_top (what
@@ -118,10 +110,7 @@ struct Encoder {
     if (ev_fwd) (void)hipEventDestroy(ev_fwd);
     if (ev_gates) (void)hipEventDestroy(ev_gates);
   }
-  static bool img_fused() {                            // LRP_IMG_FUSED=0: separate T GEMM + img_stencil_kernel
-    const char* e = getenv("LRP_IMG_FUSED");
-    return !e || atoi(e) != 0;
-  }
+  static bool img_fused() { return sw().img_fused != 0; }   // LRP_IMG_FUSED=0: separate T GEMM + img_stencil_kernel
   // First layer whose ACTIVATION conv runs split-bf16 too.  A ~1e-5 relative error in a_l is harmless by itself, but
   // upstream of a 2x2 max-pool it flips the arg-max of near-tied windows (~1e-5 of them), and a flipped window moves
   // its whole relevance to a neighbour pixel: measured on VGG16, relative L1 of the heat-maps 5e-6 ... 3.6e-5 instead
@@ -129,55 +118,17 @@ struct Encoder {
   // decoder consumes 10x less exact, 7.4e-7 -> 7.8e-6, for 0.5 ms); lrp_set_precision(LRP_PREC_BF16X3_FAST): every layer
   // but the image layer (-5 ms, heat-map parity <= 4e-5).
   bool fwd_fast = false;
-  int fwd_split_from() const {
-    if (const char* e = getenv("LRP_FWD_SPLIT_FROM")) return atoi(e);
-    return fwd_fast ? 1 : 1000;
-  }
-  // Activation chain on the fp16 MFMA (default): operands as fp16 pairs hi + lo (22 mantissa bits, x scaled by a power
-  // of two per layer from its measured maximum), product hi*hi' + hi*lo' + lo*hi' in THREE MFMAs with blocked fp32
-  // accumulation — the fp32-grade product the three-way bf16 split needs six for (two passes).  [CPU emulation: features
-  // 6.5e-7 vs 6.1e-7 for plain fp32; MI355X: DESIGN 4.1]  LRP_FWD_F16=0 restores the bf16 two-pass chain.
-  static bool fwd_f16() {
-    const char* e = getenv("LRP_FWD_F16");
-    return !e || atoi(e) != 0;
-  }
-  // ... and the denominators Z+_l from the SAME pass: weights (w | w+) stacked along N like the fp32 kernel's dual
-  // matrix, one A operand staged for both, gates on the caller's stream behind the next layer's split — the side-stream
-  // Z+ chain (its own split pass, 11 more conv launches at low priority) disappears.  LRP_FWD_DUAL=0 restores it.
-  static bool fwd_dual() {
-    const char* e = getenv("LRP_FWD_DUAL");
-    return !e || atoi(e) != 0;
-  }
+  int fwd_split_from() const { return fwd_fast ? 1 : 1000; }
+  // Activation chain and denominators in ONE pass on the fp16 MFMA: operands as fp16 pairs hi + lo (22 mantissa bits, x scaled by
+  // a power of two per layer and image), product hi*hi' + hi*lo' + lo*hi' in three MFMAs with blocked fp32 accumulation,
+  // weights (w | w+) stacked along N.  (Rounds 1-2 kept the earlier arrangements — two-pass three-way bf16 split, single
+  // activation conv + side-stream Z+ chain — behind LRP_FWD_F16 / LRP_FWD_DUAL / LRP_FWD_X6; removed in round 4: untested.)
   // fp16-pair dual forward with interleaved weight rows: a_l and the gate G_l = a_l / safe(Z+_l) leave the conv's epilogue
   // together where no pool follows (conv_igemm.h ConvArgs::dual_il) — no Z+ tensor, no gate pass.  LRP_FWD_IL=0: stacked rows.
-  static bool fwd_il() {
-    const char* e = getenv("LRP_FWD_IL");
-    return !e || atoi(e) != 0;
-  }
+  static bool fwd_il() { return sw().fwd_il != 0; }
   // the image layer's fp32 dual GEMM with interleaved rows: gate, pairs and maximum leave its epilogue (no gate / absmax / split pass)
   static bool image_layer_interleaved(const ConvLayer& L) { return fwd_il() && !(L.cout & 31) && conv_npad(2 * L.cout) == 2 * L.cout && !L.pool_after; }
   static bool dual_interleaved(const ConvLayer& L) { return fwd_il() && !(L.cout & 31) && conv_npad(2 * L.cout) == 2 * L.cout; }
-  static bool fwd_z2() {
-    const char* e = getenv("LRP_FWD_Z2");
-    return !e || atoi(e) != 0;
-  }
-  static bool fwd_x6() {                               // LRP_FWD_X6=0: exact activation convs on the fp32 MFMA instead
-    const char* e = getenv("LRP_FWD_X6");
-    return !e || atoi(e) != 0;
-  }
-  static bool train_split_enabled() {                  // LRP_TRAIN_SPLIT=0: exact-fp32 backward-data convs in the fine-tune step
-    const char* e = getenv("LRP_TRAIN_SPLIT");
-    return !e || atoi(e) != 0;
-  }
-  static bool gate_fused() {
-    const char* e = getenv("LRP_GATE_FUSED");
-    return !e || atoi(e) != 0;
-  }
-  static bool overlap_enabled() {
-    const char* e = getenv("LRP_ENCODE_OVERLAP");
-    return !e || atoi(e) != 0;
-  }
-
   int init(const lrp_config& c, int64_t* total) {
     img_h = c.img_h; img_w = c.img_w; max_images = c.max_images; max_tokens = c.max_tokens;
     if (c.n_conv < 1 || c.n_conv > LRP_MAX_CONV) return fail(LRP_ERR_INVALID, "n_conv=%d out of range", c.n_conv);
@@ -240,9 +191,6 @@ struct Encoder {
     LRP_TRY(act_max.alloc((layers.size() + 1) * B * ACT_MAX_SLOTS * sizeof(unsigned), total));
     LRP_TRY(act_unscale.alloc((layers.size() + 1) * B * sizeof(float), total));
     LRP_TRY(out_scale.alloc((layers.size() + 1) * B * sizeof(float), total));
-    LRP_TRY(unit_norm.alloc(2 * sizeof(float), total));
-    const float un[2] = {1.f, 0.f};
-    LRP_HIP_CHECK(hipMemcpy(unit_norm.p, un, sizeof(un), hipMemcpyHostToDevice));
     for (ConvLayer& L : layers) LRP_TRY(L.fnorm.alloc(2 * sizeof(float), total));
     return LRP_OK;
   }
@@ -294,6 +242,7 @@ struct Encoder {
         }
       LRP_TRY(L.w_fwd.alloc(pk.size() * sizeof(float), total));
       LRP_HIP_CHECK(hipMemcpy(L.w_fwd.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+      if (!image_layer_interleaved(L)) L.w_fwd_il.release();   // (the layout of a layer's copies is decided HERE; encode() asks which copies exist)
       if (image_layer_interleaved(L)) {
         LRP_TRY(L.w_fwd_il.alloc(pk.size() * sizeof(float), total));
         hipLaunchKernelGGL(dual_interleave_rows_kernel, dim3(stream_grid((size_t)2 * L.cout * K)), dim3(256), 0, nullptr, L.w_fwd.as<float>(),
@@ -345,8 +294,10 @@ struct Encoder {
             memcpy(&il[(size_t)(64 * (c / 32) + 32 * half + (c & 31)) * K], &pk[(size_t)(half * L.cout + c) * K], (size_t)K * sizeof(float));
         LRP_TRY(L.w_fwd_il.alloc(il.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_il.p, il.data(), il.size() * sizeof(float), hipMemcpyHostToDevice));
+      } else {
+        L.w_fwd_il.release();
       }
-      LRP_TRY(make_f16_operand(dual_interleaved(L) ? L.w_fwd_il.as<float>() : L.w_fwd.as<float>(), pk.size(), 0, 0, L.w_fwd_h, L.wds,
+      LRP_TRY(make_f16_operand(L.w_fwd_il.p ? L.w_fwd_il.as<float>() : L.w_fwd.as<float>(), pk.size(), 0, 0, L.w_fwd_h, L.wds,
                                total, nullptr));
       {  // mixed-precision forward: w (fp32) and w+ (split8) as separate N = cout matrices
         const int Npa = conv_npad(L.cout);
@@ -358,14 +309,9 @@ struct Encoder {
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_a.p, pa.data(), pa.size() * sizeof(float), hipMemcpyHostToDevice));
         LRP_TRY(L.w_fwd_zs.alloc(pzs.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_zs.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<float> pal(pa.size());
-        pack_split8_3way(pa.data(), pa.size(), pzs.data(), pal.data());
+        pack_split8(pa.data(), pa.size(), pzs.data());
         LRP_TRY(L.w_fwd_as.alloc(pzs.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_fwd_as.p, pzs.data(), pzs.size() * sizeof(float), hipMemcpyHostToDevice));
-        LRP_TRY(L.w_fwd_al.alloc(pal.size() * sizeof(float), total));
-        LRP_HIP_CHECK(hipMemcpy(L.w_fwd_al.p, pal.data(), pal.size() * sizeof(float), hipMemcpyHostToDevice));
-        LRP_TRY(L.w_fwd_ah.alloc(pal.size() * sizeof(float), total));
-        LRP_TRY(make_f16_operand(L.w_fwd_a.as<float>(), pal.size(), 0, 0, L.w_fwd_ah, L.wfs, total, nullptr));
       }
       const int Npb = conv_npad(L.cin), Kb = 9 * conv_cinp(L.cout);
       pk.assign((size_t)Npb * Kb, 0.f);
@@ -432,6 +378,8 @@ struct Encoder {
       if (image_layer_interleaved(L)) {
         LRP_TRY(mk(L.w_fwd_il, (size_t)conv_npad(2 * L.cout) * 64));
         LRP_TRY(mk(L.w_fwd_h, (size_t)conv_npad(2 * L.cout) * 64));
+      } else {
+        L.w_fwd_il.release();
       }
       LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_h, nb));
       return LRP_OK;
@@ -440,8 +388,8 @@ struct Encoder {
     const size_t nf = (size_t)conv_npad(L.cout) * Kf, nb = (size_t)conv_npad(L.cin) * Kb;
     LRP_TRY(mk(L.w_fwd, (size_t)conv_npad(2 * L.cout) * Kf)); LRP_TRY(mk(L.w_fwd_h, (size_t)conv_npad(2 * L.cout) * Kf));
     if (dual_interleaved(L)) LRP_TRY(mk(L.w_fwd_il, (size_t)conv_npad(2 * L.cout) * Kf));
-    LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf)); LRP_TRY(mk(L.w_fwd_al, nf));
-    LRP_TRY(mk(L.w_fwd_ah, nf));
+    else L.w_fwd_il.release();
+    LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf));
     LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
     LRP_TRY(mk(L.w_bwd_h, nb));
     if (conv_npad(L.cin) == 64) { LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb)); LRP_TRY(mk(L.w_bwd_frag_h, (size_t)64 * Kb)); }
@@ -478,15 +426,13 @@ struct Encoder {
     };
     const size_t nf = (size_t)Npa * 9 * CPi, nb = (size_t)Npb * 9 * CPo;
     pack(L.w_fwd.as<float>(), 0, Np2, 1, 0);
-    if (dual_interleaved(L)) pack(L.w_fwd_il.as<float>(), 0, Np2, 2, 0);
-    LRP_TRY(make_f16_operand(dual_interleaved(L) ? L.w_fwd_il.as<float>() : L.w_fwd.as<float>(), (size_t)Np2 * 9 * CPi, 0, 0, L.w_fwd_h,
+    if (L.w_fwd_il.p) pack(L.w_fwd_il.as<float>(), 0, Np2, 2, 0);
+    LRP_TRY(make_f16_operand(L.w_fwd_il.p ? L.w_fwd_il.as<float>() : L.w_fwd.as<float>(), (size_t)Np2 * 9 * CPi, 0, 0, L.w_fwd_h,
                              L.wds, nullptr, st, false));
     pack(L.w_fwd_a.as<float>(), 0, Npa, 0, 0);
     pack(tmp, 0, Npa, 0, 1);
     split(tmp, L.w_fwd_zs.as<float>(), nf);
-    hipLaunchKernelGGL(split3_copy_kernel, dim3(stream_grid(nf / 8)), dim3(256), 0, st, L.w_fwd_a.as<float>(), L.w_fwd_as.as<float>(),
-                       L.w_fwd_al.as<float>(), nf / 8);
-    LRP_TRY(make_f16_operand(L.w_fwd_a.as<float>(), nf, 0, 0, L.w_fwd_ah, L.wfs, nullptr, st, false));
+    split(L.w_fwd_a.as<float>(), L.w_fwd_as.as<float>(), nf);
     pack(L.w_bwd.as<float>(), 1, Npb, 0, 1);
     split(L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb);
     if (L.w_bwd_frag.p)
@@ -586,9 +532,9 @@ struct Encoder {
     bool mixed = prec == PREC_BF16X3;
     for (const ConvLayer& L : layers)
       if (L.cout & 7) mixed = false;
-    const bool overlap = mixed && side && overlap_enabled() && layers.size() > 1;
+    const bool overlap = mixed && side && layers.size() > 1;
     std::vector<const float*> xin(layers.size() + 1, nullptr);   // overlapped path: input of every conv
-    bool dual = overlap && fwd_f16() && fwd_dual() && fwd_split_from() >= 1000;
+    bool dual = overlap && !fwd_fast;                    // (LRP_PREC_BF16X3_FAST: split-bf16 activation convs + side-stream Z+ chain)
     for (size_t li = 1; li < layers.size(); ++li)
       if (((layers[li].cin | layers[li].cout) & 7) || !layers[li].w_fwd_h.p) dual = false;
     // dual path: the producer hands its consumer the fp16 pairs directly (conv epilogue where no pool follows, the fused
@@ -599,7 +545,7 @@ struct Encoder {
     // and unscale records are then kept per IMAGE, so an image's result does not depend on the rest of its batch
     bool emit = dual && fwd_emit() && layers.size() > 1 && layers[0].w_fwd_il.p && !layers[0].pool_after && !(img_elems & 3);
     for (size_t li = 1; li < layers.size(); ++li)
-      if (!dual_interleaved(layers[li])) emit = false;
+      if (!layers[li].w_fwd_il.p) emit = false;          // (interleaved rows: decided when the weights were packed)
     const size_t per = emit ? (size_t)max_images : 1;    // records per layer
     auto slots_of = [&](size_t lev) { return act_max.as<unsigned>() + lev * per * ACT_MAX_SLOTS; };
     auto unscale_of = [&](size_t li) { return act_unscale.as<float>() + li * per; };
@@ -651,7 +597,7 @@ struct Encoder {
           cd.in_unscale = unscale_of(li);
           cd.act_max_out = slots_of(li);
           cd.scale_per_img = emit ? 1 : 0; cd.img_rows = L.H * L.W; cd.n_imgs = B;
-          cd.dual_il = dual_interleaved(L) ? 1 : 0;
+          cd.dual_il = L.w_fwd_il.p ? 1 : 0;
           const bool fused_gate = cd.dual_il && !top && !L.pool_after;
           if (fused_gate) {
             // a_l and G_l leave the epilogue together: a_l into a ping-pong buffer its consumer (the next layer's split)
@@ -672,9 +618,9 @@ struct Encoder {
           // products) are computed two-term as well — with the SAME rounded weights hi(w+) the walk multiplies with.
           // [MI355X: parity at the bench configuration 5.5e-6 -> 4.4e-6, 6 seeds median 4.2e-6 -> 3.3e-6: gate and
           // transposed conv now belong to one (slightly perturbed) network and the rounding largely cancels in R / Z+;
-          // two-term Z+ in EVERY layer: 1.0e-4, the top block again.]  LRP_FWD_Z2=0: three-term everywhere.
+          // two-term Z+ in EVERY layer: 1.0e-4, the top block again.]
           int fterms = 7;
-          if (cd.dual_il && walk_f16 && fwd_z2() && two_term((int)li)) fterms = 23;
+          if (cd.dual_il && walk_f16 && two_term((int)li)) fterms = 23;
           LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, cd, st, PREC_F16X2, fterms));
           if (top) break;
           in_pairs = emit_conv || emit_pool;
@@ -701,36 +647,7 @@ struct Encoder {
           }
           continue;
         }
-        if (fwd_f16() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
-          // fp32-grade product on the f16 matrix cores: x_l -> fp16 pairs scaled by 2^k (k from the maximum the producer
-          // measured), ONE conv pass, the epilogue undoes the scale, adds the bias and measures max|a_l| for the next layer
-          const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
-          unsigned* slots_in = slots_of(li - 1);
-          if (li == 1) {                                // (a_1 comes from the fp32 im2col GEMM, which keeps no maximum)
-            hipLaunchKernelGGL(absmax_slots_kernel, dim3(stream_grid(n8 * 2)), dim3(256), 0, st, reinterpret_cast<const f32x4*>(xin[li]),
-                               n8 * 2, slots_in);
-          }
-          hipLaunchKernelGGL(split_h_scaled_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8, slots_in,
-                             unscale_of(li), L.wfs.as<float>());
-          LRP_HIP_CHECK(hipGetLastError());
-          ConvArgs c1 = ca;
-          c1.in = bufXs.as<float>(); c1.wpk = L.w_fwd_ah.as<float>();
-          c1.in_unscale = unscale_of(li);
-          c1.act_max_out = slots_of(li);
-          LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, c1, st, PREC_F16X2));
-        } else if (fwd_x6() && !((L.cin | L.cout) & 7) && (int)li < fwd_split_from()) {
-          // fp32-grade product on the bf16 matrix cores: three-way split operands, two passes (see conv_igemm.h TERMS)
-          const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
-          hipLaunchKernelGGL(split3_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(),
-                             bufXl.as<float>(), n8);
-          LRP_HIP_CHECK(hipGetLastError());
-          ConvArgs c1 = ca;
-          c1.in = bufXs.as<float>(); c1.wpk = L.w_fwd_as.as<float>(); c1.out = bufZ.as<float>();       // pre-activation, big terms
-          LRP_HIP_CHECK(conv_launch(EPI_BIAS, c1, st, PREC_BF16X3, 15));
-          ConvArgs c2 = ca;
-          c2.in = bufXl.as<float>(); c2.wpk = L.w_fwd_al.as<float>(); c2.bias = nullptr; c2.addend = bufZ.as<float>();
-          LRP_HIP_CHECK(conv_launch(EPI_BIAS_RELU, c2, st, PREC_BF16X3, 3));
-        } else if ((int)li >= fwd_split_from()) {
+        if ((int)li >= fwd_split_from()) {
           // late layers: activation conv in split-bf16 as well (its error passes through few further layers)
           const size_t n8 = (size_t)B * L.H * L.W * L.cin / 8;
           hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, xin[li], bufXs.as<float>(), n8);
@@ -761,21 +678,14 @@ struct Encoder {
                            unscale_of(1));
         // the im2col matrix as fp16 pairs (scaled per image by its own maximum) and the GEMM on the f16 MFMA — unless the
         // fine-tune step is on: its weight gradient of this layer is a product over the fp32 im2col matrix (trainer.h)
-        static const bool l0_f16 = [] { const char* e = getenv("LRP_FWD_L0_F16"); return e && atoi(e) != 0; }();   // opt-in: cnn_kernels.h
-        const bool l0_pairs = l0_f16 && !keep_acts && L.w_fwd_h.p && L.wds.p;
-        if (l0_pairs) {
-          hipLaunchKernelGGL(fwd_scale_kernel, dim3(B), dim3(64), 0, st, img_slots, unit_norm.as<float>(), L.wds.as<float>(),
-                             oscale_of(layers.size()), unscale_of(0));
-          const size_t total = (size_t)B * img_h * img_w * 8;
-          hipLaunchKernelGGL(im2col_image_pairs_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, images.as<float>(),
-                             a1.as<float>(), oscale_of(layers.size()), B, img_h, img_w);
-        } else {
-          LRP_TRY(im2col_fp32());
-        }
+        // (the image layer stays on the exact fp32 MFMA: as fp16 pairs it is 0.2-0.4 ms faster per encode and puts the features of
+        //  ill-conditioned nets at 1.0e-5 instead of 6.3e-6 — first-layer errors are inherited by every later layer; round 3 kept
+        //  that variant behind LRP_FWD_L0_F16, round 4 removed it)
+        LRP_TRY(im2col_fp32());
         LRP_HIP_CHECK(hipGetLastError());
         ConvArgs c0{};
         c0.in = a1.as<float>(); c0.NB = B * L.H * L.W; c0.H = 1; c0.W = 1; c0.Cin = 64; c0.CinP = 64; c0.taps = 1;
-        c0.bias = L.bias.as<float>(); c0.wpk = l0_pairs ? L.w_fwd_h.as<float>() : L.w_fwd_il.as<float>(); c0.N = 2 * L.cout; c0.split = L.cout;
+        c0.bias = L.bias.as<float>(); c0.wpk = L.w_fwd_il.as<float>(); c0.N = 2 * L.cout; c0.split = L.cout;
         c0.in_unscale = unscale_of(0);
         c0.dual_il = 1; c0.dual_gate = 1;
         c0.out = keep_acts ? L.Akeep.as<float>() : nullptr; c0.skip_out = keep_acts ? 0 : 1;
@@ -783,7 +693,7 @@ struct Encoder {
         c0.pairs_out = pin; c0.pairs_scale = oscale_of(0);
         c0.act_max_out = slots_of(0);
         c0.scale_per_img = 1; c0.img_rows = L.H * L.W; c0.n_imgs = B;
-        LRP_HIP_CHECK(l0_pairs ? conv_launch(EPI_FWD_DUAL, c0, st, PREC_F16X2) : conv_launch(EPI_FWD_DUAL, c0, st));
+        LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, c0, st));
         in_pairs = true;
         xin[1] = keep_acts ? L.Akeep.as<float>() : nullptr;
         continue;
@@ -855,9 +765,8 @@ struct Encoder {
         cz.in = bufXs.as<float>(); cz.NB = B; cz.H = L.H; cz.W = L.W; cz.Cin = L.cin; cz.CinP = conv_cinp(L.cin); cz.taps = 9;
         cz.bias = L.bias.as<float>(); cz.wpk = L.w_fwd_zs.as<float>(); cz.N = L.cout;
         cz.out = top ? ztop.as<float>() : bufZ.as<float>();
-        if (!top && !L.pool_after && gate_fused()) {
-          // no pool behind this layer: G_l = a_l / safe(Z+_l) in the conv's epilogue, Z+_l never written (LRP_GATE_FUSED=0:
-          // separate gate_kernel pass)
+        if (!top && !L.pool_after) {
+          // no pool behind this layer: G_l = a_l / safe(Z+_l) in the conv's epilogue, Z+_l never written
           cz.gate_src = keep_acts ? L.Akeep.as<float>() : L.G.as<float>();
           cz.out = L.G.as<float>();
           LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, side, PREC_BF16X3));
@@ -905,7 +814,7 @@ struct Encoder {
     // Fine-tune step (layer_hook, walk = 1) in the default arithmetic: the backward-data convs run split-bf16 too —
     // bf16 operands (hi + lo), three MFMAs per product, fp32 accumulate; the hook still sees plain fp32 dZ (the weight
     // gradient reads it), so every layer's dZ is written fp32 and re-split by one streaming pass in front of its conv.
-    bool hook_split = prec == PREC_BF16X3 && walk == 1 && layer_hook != nullptr && train_split_enabled();
+    bool hook_split = prec == PREC_BF16X3 && walk == 1 && layer_hook != nullptr;
     for (const ConvLayer& L : layers)
       if (L.cout & 7) split = hook_split = false;       // split8 groups need widths % 8 == 0: exact fp32 otherwise
     for (size_t li = 1; li < layers.size(); ++li)
@@ -955,7 +864,7 @@ struct Encoder {
     // tensor is neither written nor read [MI355X, same box: block2_conv1 2.19 -> 1.48 ms (its store stream shrinks 4x, no gate
     // loads), block1_conv2 3.87 -> 4.14 ms (its prologue now multiplies and splits in registers instead of a plain LDS-DMA),
     // walk 26.3 -> 25.7-25.9 ms; heat-map parity unchanged].  LRP_UP2_COMPACT=0 disables.
-    static const bool up2_on = [] { const char* e = getenv("LRP_UP2_COMPACT"); return !e || atoi(e) != 0; }();
+    const bool up2_on = sw().up2_compact != 0;
     int compact_in = 0;                                  // S (the current layer's input) is in a compact form: 1 fp32 P (BREG consumer), 2 pairs of S_c (pipelined consumer)
     int fold_tw = 0, fold_th = 0;
     // Image layer folded into the epilogue of the layer above it (ConvArgs::img_part): S_1 — 4.1 GB written, 4.5 GB read at
@@ -964,7 +873,7 @@ struct Encoder {
     // in-tile stencil), image layer 1.29 -> 0.18 ms, walk 26.1-26.3 -> 25.3 ms; heat-maps unchanged to fp32 round-off,
     // batch invariance bit-exact].
     // LRP_IMG_FOLD=0 disables.
-    static const bool fold_on = [] { const char* e = getenv("LRP_IMG_FOLD"); return !e || atoi(e) != 0; }();
+    const bool fold_on = sw().img_fold != 0;
     for (int li = (int)layers.size() - 1; li >= 0; --li) {
       const ConvLayer& L = layers[li];
       if (layer_hook) {
@@ -1019,7 +928,7 @@ struct Encoder {
           compact_in = 0;
         } else if (compact_in) {                          // this layer reads the compact form its producer left
           ca.up2_src = S; ca.up2_gate = L.G.as<float>();     // (ca.in = S stays a valid pointer; it is not read)
-          static const bool gc_on = [] { const char* e = getenv("LRP_UP2_GC"); return !e || atoi(e) != 0; }();
+          const bool gc_on = sw().up2_gc != 0;
           if (gc_on && L.Gc.p && L.gc_epoch == encode_epoch) {   // ... with the gate in compact form too (per-token tiles only)
             ca.up2_gc = L.Gc.as<float>(); ca.up2_gpos = L.Gpos.as<unsigned char>();
           }
@@ -1030,10 +939,7 @@ struct Encoder {
             !(P.cout & 7) && conv_takes_breg(P.cin, P.H, P.W, P.w_bwd_frag.p != nullptr)) {
           // pairs mode as below when the consumer will run the folded launch (per-token tiles: its window loader) and this
           // encode left a compact gate; else the plain fp32 product and the consumer multiplies
-          static const bool gc_on3 = [] {
-            const char *e = getenv("LRP_UP2_GC"), *e2 = getenv("LRP_UP2_BREG_PAIRS");
-            return (!e || atoi(e) != 0) && (!e2 || atoi(e2) != 0);
-          }();
+          const bool gc_on3 = sw().up2_gc != 0 && sw().up2_breg_pairs != 0;
           const bool cons_fold = li == 2 && fold_on && img_fused() && !layers[0].pool_after && P.cin == 64 && layers[0].w_bwd_s.p != nullptr;
           if (gc_on3 && cons_fold && P.Gc.p && P.gc_epoch == encode_epoch) {
             epi = EPI_MUL; ca.aux = P.Gc.as<float>();

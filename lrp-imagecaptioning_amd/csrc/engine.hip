@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "conv_igemm.h"
+#include "conv_sparse.h"
 #include "decoder.h"
 #include "encoder.h"
 #include "resnet_encoder.h"
@@ -103,6 +104,10 @@ static int with_handle(const lrp_handle* h, F&& body) noexcept {
 extern "C" {
 
 int lrp_abi_version(void) { return LRP_ABI_VERSION; }
+int lrp_reload_switches(void) {
+  return guarded([&]() -> int { lrp::sw().load(); return LRP_OK; });
+}
+
 int64_t lrp_launch_count(void) { return (int64_t)lrp::g_launch_count.load(std::memory_order_relaxed); }
 const char* lrp_last_error(void) { return last_error_ref().c_str(); }
 
@@ -478,6 +483,40 @@ int lrp_op_conv(const float* in_dev, const float* w_hwio_host, const float* bias
     static const int epi_of_mode[4] = {EPI_BIAS_RELU, EPI_BIAS, EPI_MUL, EPI_MUL_UP2};
     LRP_HIP_CHECK(conv_launch(epi_of_mode[mode], ca, S(stream), split ? PREC_BF16X3 : PREC_FP32));
     LRP_HIP_CHECK(hipStreamSynchronize(S(stream)));      // weights are freed on return
+    return LRP_OK;
+  });
+}
+
+int lrp_op_conv_pool_sparse(const float* sc_dev, const unsigned char* pos_dev, const float* w_hwio_host, const float* gate_dev,
+                            float* out_dev, int32_t NB, int32_t Hp, int32_t Wp, int32_t Cin, int32_t Cout, int32_t reps, void* stream) {
+  return guarded([&]() -> int {
+    if (!sc_dev || !pos_dev || !w_hwio_host || !gate_dev || !out_dev) return fail(LRP_ERR_INVALID, "null argument");
+    if (NB < 1 || Hp < 1 || Wp < 1 || (reps & 255) < 1) return fail(LRP_ERR_INVALID, "NB, Hp, Wp, reps must be >= 1");
+    if (!conv_sparse_supports(Cin, Cout, Hp, Wp))
+      return fail(LRP_ERR_UNSUPPORTED, "the sparse consumer needs Cin %% 256 == 0 (output columns) and Cout %% 16 == 0");
+    hipStream_t st = S(stream);
+    const int Npb = conv_npad(Cin), Kb = 9 * conv_cinp(Cout);
+    std::vector<float> pk((size_t)Npb * Kb, 0.f);
+    pack_conv_bwd(w_hwio_host, 9, Cin, Cout, 0, pk.data());
+    DevBuf wb, wsp, pairs;
+    LRP_TRY(wb.alloc(pk.size() * sizeof(float), nullptr));
+    LRP_HIP_CHECK(hipMemcpy(wb.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    LRP_TRY(wsp.alloc(conv_sparse_weight_floats(Cin, Cout) * sizeof(float), nullptr));
+    LRP_HIP_CHECK(conv_sparse_pack(wb.as<float>(), wsp.as<float>(), Cin, Cout, st));
+    const size_t n8 = (size_t)NB * Hp * Wp * Cout / 8;
+    LRP_TRY(pairs.alloc(n8 * 32, nullptr));
+    hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, sc_dev, pairs.as<float>(), n8);
+    LRP_HIP_CHECK(hipGetLastError());
+    DevBuf idxp;
+    LRP_TRY(idxp.alloc(conv_sparse_index_words(NB, Hp, Wp, Cout) * sizeof(unsigned), nullptr));
+    LRP_HIP_CHECK(conv_sparse_index(pos_dev, idxp.as<unsigned>(), NB, Hp, Wp, Cout, st));
+    SparseArgs sa{};
+    sa.sc = pairs.as<float>(); sa.idxp = idxp.as<unsigned>(); sa.wsp = wsp.as<float>(); sa.gate = gate_dev; sa.out = out_dev;
+    sa.NB = NB; sa.Hp = Hp; sa.Wp = Wp; sa.C = Cout; sa.N = Cin; sa.out_plain = 1;
+    sa.diag = reps >> 8;                                   // (measurement variants, profiles/sparse_ab.py; results are then not meaningful)
+    reps &= 255;
+    for (int r = 0; r < reps; ++r) LRP_HIP_CHECK(conv_sparse_launch(sa, st));
+    LRP_HIP_CHECK(hipStreamSynchronize(st));               // the operand copies are freed on return
     return LRP_OK;
   });
 }

@@ -241,7 +241,7 @@ struct ResNetEncoder {
       LRP_TRY(mk(u.w_dual, nd));
       pack(u.w_dual.as<float>(), 0, Nd, 1, 0);
       if (!(u.cin & 7)) {
-        u.dual_il = fwd_il() && !(u.cout & 31) && Nd == 2 * u.cout;
+        u.dual_il = !(u.cout & 31) && Nd == 2 * u.cout;
         const float* src = u.w_dual.as<float>();
         if (u.dual_il) {                                  // rows in blocks of 32: [w | w+] of the same 32 channels
           pack(pack_tmp.as<float>(), 0, Nd, 2, 0);
@@ -305,7 +305,7 @@ struct ResNetEncoder {
       pack_conv_fwd(wp.data(), taps, u.cin, u.cout, u.cout, Nd, pk.data());
       LRP_TRY(up(u.w_dual, pk, total));
       if (!(u.cin & 7)) {
-        u.dual_il = fwd_il() && !(u.cout & 31) && Nd == 2 * u.cout;
+        u.dual_il = !(u.cout & 31) && Nd == 2 * u.cout;
         if (u.dual_il) {                                  // rows in blocks of 32: [w | w+] of the same 32 channels
           std::vector<float> il(pk.size(), 0.f);
           for (int c = 0; c < u.cout; ++c)
@@ -356,7 +356,7 @@ struct ResNetEncoder {
     else { ca.NB = B * u.Hout * u.Wout; ca.H = 1; ca.W = 1; ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin); ca.taps = 1; }
     ConvArgs cz = ca;
     const int ui = (int)(&u - units.data());
-    if (u.w_dual_h.p && slots_in && prec == PREC_BF16X3 && dual_fwd() && fwd_f16()) {
+    if (u.w_dual_h.p && slots_in && prec == PREC_BF16X3) {
       // the same single pass on the fp16 MFMA: x and (w | w+) as fp16 pairs, the product in three MFMAs with blocked
       // fp32 accumulation (conv_igemm.h PREC_F16X2) — fp32-grade, ~2.5x the fp32 matrix rate
       const size_t n8 = (size_t)B * u.Hout * u.Wout * u.cin / 8;
@@ -374,7 +374,7 @@ struct ResNetEncoder {
         return LRP_OK;
       }
       LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st, PREC_F16X2));
-    } else if (u.w_dual.p && dual_fwd()) {
+    } else if (u.w_dual.p) {
       // c = conv(x, w) + b and Z = conv(x, w+) + b in ONE pass over x: the A tile is staged once for both
       ca.wpk = u.w_dual.as<float>(); ca.N = 2 * u.cout; ca.split = u.cout; ca.dual_norelu = 1;
       ca.out = fc.as<float>(); ca.out2 = fz.as<float>();
@@ -497,7 +497,7 @@ struct ResNetEncoder {
     for (int bi = (int)blocks.size() - 1; bi >= 0; --bi) {
       const RnBlock& b = blocks[bi];
       const size_t per_o = (size_t)b.H * b.W * 4 * b.f;
-      if (b.u0 < 0 && fuse_tail()) {
+      if (b.u0 < 0) {
         // identity block, 3 conv launches: S3 -> S2 -> S1 -> R_t = t*C1 + R_o*GS, the join and (when the next block
         // agrees on the operand format) the next block's S3 = R_t * GA_next written by unit 1's epilogue
         const bool sp = block_split(b);
@@ -575,9 +575,8 @@ struct ResNetEncoder {
     const RnUnit& s = units[0];
     const size_t tot = (size_t)n * s.Hout * s.Wout * s.cout;
     // the stem's tap GEMM (K = stem channels -> 49 taps x 6 columns) as bf16x3 like the other convs of the walk: the pool
-    // routing writes its operand in split8 form (LRP_RN_STEM_SPLIT=0 / fp32 mode: plain fp32 on the fp32 MFMA)
-    static const bool stem_split_on = [] { const char* e = getenv("LRP_RN_STEM_SPLIT"); return !e || atoi(e) != 0; }();
-    const bool ssplit = stem_split_on && prec == PREC_BF16X3 && s.w_bs.p && !(s.cout & 7);
+    // routing writes its operand in split8 form (fp32 mode: plain fp32 on the fp32 MFMA)
+    const bool ssplit = prec == PREC_BF16X3 && s.w_bs.p && !(s.cout & 7);
     if (ssplit)
       hipLaunchKernelGGL(rn_pool3_route_kernel<true>, dim3(stream_grid(tot / 8)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
                          q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
@@ -599,22 +598,6 @@ struct ResNetEncoder {
   // (t * C1 of the first block), so multiplying by the relu-unit gate a0*Q would count a0 twice
   DevBuf q_stem;
   DevBuf pool_win;
-  static bool dual_fwd() {                 // LRP_RN_DUAL=0: separate c / Z+ convs
-    const char* e = getenv("LRP_RN_DUAL");
-    return !e || atoi(e) != 0;
-  }
-  static bool fwd_f16() {                  // LRP_RN_F16=0: the forward convs on the fp32 MFMA
-    const char* e = getenv("LRP_RN_F16");
-    return !e || atoi(e) != 0;
-  }
-  static bool fwd_il() {                   // LRP_RN_IL=0: stacked dual rows, separate BN + gate pass
-    const char* e = getenv("LRP_RN_IL");
-    return !e || atoi(e) != 0;
-  }
-  static bool fuse_tail() {                // LRP_RN_FUSE=0: separate element-wise join / head kernels
-    const char* e = getenv("LRP_RN_FUSE");
-    return !e || atoi(e) != 0;
-  }
 
   int profile_records(int cap, double* ms_out, double* flop_out, int* n_out) {
     int k = 0;

@@ -236,9 +236,8 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   }
   a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
   a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
-  static const int big = [] { const char* e = getenv("LRP_SGEMM_BIG"); return e ? atoi(e) : 1; }();
   int tm = a.M <= 64 ? 1 : 2, tn = a.N <= 64 ? 1 : 2;
-  if (big && a.K >= 4096) {                                       // 256 x 128 tiles: 1.5x the FLOPs per byte staged
+  if (a.K >= 4096) {                                       // 256 x 128 tiles: 1.5x the FLOPs per byte staged
     if (a.M >= 256 && a.N >= 128) tm = 4;
     else if (a.N >= 256 && a.M >= 128) tn = 4;
   }

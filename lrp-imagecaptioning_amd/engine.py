@@ -472,6 +472,23 @@ def op_conv(x, w_hwio, bias, aux, mode, taps=9, split_bf16=False):
     return out
 
 
+def op_conv_pool_sparse(sc, pos, w_hwio, gate, reps=1):
+    """The conv-LRP launch behind a 2x2 max-pool on the 2:4-sparse matrix cores (lrp_op_conv_pool_sparse): sc (NB, Hp, Wp, Cout)
+    float32 = each window's one non-zero, pos (same shape) uint8 = its position 2 dy + dx, w_hwio (3, 3, Cin, Cout) numpy,
+    gate (NB, 2 Hp, 2 Wp, Cin) -> (NB, 2 Hp, 2 Wp, Cin) float32."""
+    lib = _capi.load()
+    w = np.ascontiguousarray(w_hwio, dtype=np.float32)
+    Cin, Cout = w.shape[2], w.shape[3]
+    NB, Hp, Wp, _ = sc.shape
+    assert pos.dtype == torch.uint8 and tuple(pos.shape) == tuple(sc.shape) and tuple(gate.shape) == (NB, 2 * Hp, 2 * Wp, Cin)
+    sc, pos, gate = sc.contiguous(), pos.contiguous(), gate.contiguous()
+    out = torch.empty((NB, 2 * Hp, 2 * Wp, Cin), dtype=torch.float32, device=sc.device)
+    _capi.check(lib.lrp_op_conv_pool_sparse(C.c_void_p(sc.data_ptr()), C.c_void_p(pos.data_ptr()), w.ctypes.data_as(C.c_void_p),
+                                            C.c_void_p(gate.data_ptr()), C.c_void_p(out.data_ptr()), NB, Hp, Wp, Cin, Cout, int(reps),
+                                            _cur_stream(sc.device)))
+    return out
+
+
 def op_sgemm(A, B, transA=False, transB=False, C_init=None, split=True):
     """C (+)= op(A) op(B) through lrp_op_sgemm (fp32 MFMA); A, B 2-D device tensors (views with a row stride allowed)."""
     lib = _capi.load()
@@ -579,6 +596,36 @@ def heatmap_render(R_img, gamma=0.95, color_conversion=None):
     _capi.check(lib.lrp_heatmap_render(C.c_void_p(R.data_ptr()), C.c_void_p(_LUT_CACHE[key].data_ptr()),
                                        C.c_void_p(out.data_ptr()), n, Hh * Ww, Cc, C.c_float(gamma), _cur_stream(R.device)))
     return out
+
+
+class switches(object):
+    """`with switches(LRP_UP2_PW=0, ...):` — set the library's A/B switches for the body and restore the
+    environment afterwards (lrp_reload_switches re-reads them: they are not looked up on the launch path).  For tests and
+    measurement scripts; a switch that changes the encode caches takes effect at the next encode_images."""
+
+    def __init__(self, **env):
+        self.env = {k: str(v) for k, v in env.items()}
+        self.old = {}
+
+    def __enter__(self):
+        import os
+        for k, v in self.env.items():
+            if not k.startswith("LRP_"):
+                raise ValueError("not a library switch: %s" % k)
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+        _capi.check(_capi.load().lrp_reload_switches())
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        _capi.check(_capi.load().lrp_reload_switches())
+        return False
 
 
 def preprocess_images(rgb_u8, size=(224, 224)):

@@ -79,3 +79,18 @@ def test_no_exception_crosses_the_abi():
         pass
     else:
         raise AssertionError("LRP_ERR_NOMEM must map to MemoryError")
+
+
+def test_every_switch_of_the_library_is_listed_here():
+    """csrc/common.h names the switches the library reads; a new one must come with a case above."""
+    import os
+    import re
+    from conftest import ROOT
+    from test_gpu_switches import CASES
+    src = open(os.path.join(ROOT, "lrp-imagecaptioning_amd", "csrc", "common.h")).read()
+    in_lib = set(re.findall(r'rd\("(LRP_[A-Z0-9_]+)"', src))
+    assert in_lib == {c[0] for c in CASES}, in_lib ^ {c[0] for c in CASES}
+    # nothing else in csrc reads the environment
+    for f in os.listdir(os.path.join(ROOT, "lrp-imagecaptioning_amd", "csrc")):
+        if f != "common.h":
+            assert "getenv" not in open(os.path.join(ROOT, "lrp-imagecaptioning_amd", "csrc", f)).read(), f
