@@ -38,21 +38,24 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// PREC_FP32 : operands fp32, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+// PREC_FP32 : operands fp32, v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).  The walk and the forward of LRP_PREC_FP32; the image
+//   layer's forward GEMM and the decoder's products in every mode.
 // PREC_BF16X3: operands stored as "split8" — per 8 consecutive channels 32 B = [8 x bf16 hi | 8 x bf16 lo] with
 //   x ~= hi + lo (16 mantissa bits), same bytes as fp32.  Each product is hi*hi' + hi*lo' + lo*hi' on
 //   v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs of 32 cycles per 16 k instead of 8 of 64
-//   (5.3x fewer matrix-pipe cycles).  Used for the per-token reverse walk only; the per-image forward
-//   stays exact fp32 (measured: forward fp32 + backward split = 2-3.5e-6 relative L1 vs the float64
-//   graph; splitting the forward too = 2.4e-5, because errors in Z / a are systematic, errors in S average out).
+//   (5.3x fewer matrix-pipe cycles).  The per-token reverse walk of the DEFAULT mode (lrp_create: LRP_PREC_BF16X3): worst case
+//   2^-16 per product whatever the weights [MI355X: 2-3.5e-6 relative L1 vs the float64 graph on He-normal kernels,
+//   6e-6 ... 1.6e-5 on trained-like ones, DESIGN 4.2].
 // PREC_F16X2 : both operands as fp16 pairs hi + lo (22 mantissa bits) in the same split8 layout, carried scaled by powers
 //   of two taken from MEASURED maxima (fp16 has 5 exponent bits): per token for the relevance S of the reverse walk
-//   (ConvArgs::tok_*; Encoder::explain), per tensor for the forward's activations, per matrix for the weights.
-//   TERMS 7: hi*hi' + hi*lo' + lo*hi', three v_mfma_f32_32x32x16_f16 per 16 k — fp32-grade (forward; top block of the walk).
-//   TERMS 5: the weights' lo half is not read: lo*w + hi*w, TWO MFMAs — the walk's layers below the top block; the
-//   weight rounding (2^-12, the same for every token) averages out there and cancels against the denominators Z+, which
-//   the forward computes with the same rounded weights (TERMS bit 4) [MI355X: 4.4e-6 at the bench configuration vs
-//   3.3e-6 for bf16x3; DESIGN 4.1b].  The default arithmetic of the VGG path.
+//   (ConvArgs::tok_*; Encoder::explain), per image for the forward's activations, per matrix for the weights.
+//   TERMS 7: hi*hi' + hi*lo' + lo*hi', three v_mfma_f32_32x32x16_f16 per 16 k — fp32-grade.  This is the encoder FORWARD of every
+//   mode but LRP_PREC_FP32 (the interleaved dual conv a_l | Z+_l, blocked accumulation: features 7e-7 from float64) and the top
+//   block of the opt-in fast walk.
+//   TERMS 5: the weights' lo half is not read: lo*w + hi*w, TWO MFMAs — the layers of the OPT-IN fast walk (LRP_PREC_F16X2) that
+//   lrp_set_fast_layers / calibration.py selected; TERMS bit 4 computes the matching two-term denominators Z+ in the forward.
+//   One fp16 per weight is 2^-12 per product: fine on dense Gaussian kernels (the rounding averages out), above the 1e-4 bar on
+//   sparse heavy-tailed ones — which is why this is not the default (tests/test_gpu_stress_parity.py).
 enum ConvPrec { PREC_FP32 = 0, PREC_BF16X3 = 1, PREC_F16X2 = 2 };
 
 __device__ __forceinline__ void split8h_store(const float* r, float* dst) {  // 8 fp32 -> 32 B [fp16 hi8 | fp16 lo8]
