@@ -33,9 +33,10 @@ typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct SparseArgs {
-  const float* sc;            // S_c at pooled resolution [NB][Hp][Wp][C] as split8 pairs (32 B per 8 channels: hi8 | lo8)
-  const unsigned* idxp;       // conv_sparse_index_kernel's output (from the arg-max positions 2 dy + dx of the pool): per image, window,
-                              // 8-channel set and parity class 16 B of index words [images][Hp][Wp][C / 8][4 classes][2 halves][own|h|d|v]
+  const float* sc;            // S_c at pooled resolution as split8 pairs, CHUNK-MAJOR: [NB][C / 16][Hp][Wp][set 0: hi8 | lo8, set 1: hi8 | lo8]
+                              // (64 B per window and 16-channel chunk: what a tile stages per chunk is contiguous; conv_sparse_pairs_kernel)
+  const unsigned* idxp;       // conv_sparse_index_kernel's output (from the arg-max positions 2 dy + dx of the pool): per image, parity
+                              // class, chunk and window 2 x 16 B of index words [images][4 classes][C / 16][Hp][Wp][2 sets][2 halves][own|h|d|v]
   const float* wsp;           // conv_sparse_pack_kernel's output: [4 classes][n_tiles][C / 16][6 steps][32 KB]
   const float* gate;          // G of the layer below [images][2 Hp][2 Wp][N] fp32
   float* out;                 // [NB][2 Hp][2 Wp][N] split8 pairs (fp32 when out_plain)
@@ -48,11 +49,16 @@ struct SparseArgs {
 
 constexpr int SP_TW = 14, SP_TH = 18, SP_PITCH = SP_TW + 2;      // tile = 18 stack window rows x 14 window columns = 252 rows
 constexpr int SP_NENT = (SP_TH + 2) * SP_PITCH;                  // resident windows (tile + ring); entry SP_NENT = all-zero
-constexpr int SP_ENT = 96;                                       // bytes per resident window and 16-channel chunk (three 32 B planes)
-constexpr int SP_ABUF = (SP_NENT + 1) * SP_ENT;
+constexpr int SP_PENT = SP_NENT + 1;                             // entries of a sub-plane (the last one is the all-zero entry)
+constexpr int SP_SUB = SP_PENT * 16;                             // bytes of a sub-plane: 16 B per resident window = [lane half 0: 8 B | half 1: 8 B]
+constexpr int SP_ABUF = 6 * SP_SUB;                              // [pairs hi | pairs lo | index words] x [set 0 | set 1]
+constexpr int SP_SUBPIECES = (SP_PENT + 63) / 64;                // 1 KiB DMA pieces per sub-plane (the last one overlaps the one before)
+constexpr int SP_APIECES = 6 * SP_SUBPIECES;
+constexpr int SP_ASLOTS = (SP_APIECES + 7) / 8;                  // pieces per wave and chunk
 constexpr int SP_BSTAGE = 32768, SP_NSTAGE = 3;
-constexpr int SP_LDS = SP_NSTAGE * SP_BSTAGE + 2 * SP_ABUF;
+constexpr int SP_LDS = SP_NSTAGE * SP_BSTAGE + 2 * SP_ABUF + 128;      // (+ the window row -> image table)
 static_assert(SP_LDS <= 160 * 1024, "LDS");
+static_assert(SP_ASLOTS <= 8 && SP_PENT >= 64, "two A pieces per wave in each of the first four steps of a chunk");
 
 // B operand of class q: slot -> tap of the backward conv (the matrix conv_igemm's launch multiplies with: row = output channel
 // ci, k = tap * CPo + co, tap = 3 (dy + 1) + (dx + 1) reads S[y + dy][x + dx]); -1 = dump slot (zero row).
@@ -78,11 +84,13 @@ __host__ __device__ inline int sparse_slot_tap(int q, int group, int slot) {
 //   h     low index  = py, or dump slot 3        valid iff the non-zero sits in the column next to a class-q pixel (px != qx)
 //   d     high index = slot 2, or dump slot 3    valid iff it sits in the near corner
 //   v     (px or dump slot 2, 3)                 valid iff it sits in the near row (py != qy); second value zero
-// Lane half h of a fragment holds channels {2h, 2h+1, 4+2h, 5+2h} of the set (profiles/smfmac_semantics.hip).
-__global__ __launch_bounds__(256) void conv_sparse_index_kernel(const unsigned char* __restrict__ pos, unsigned* __restrict__ idxp, size_t n_sets) {
+// Lane half h of a fragment holds channels 4h .. 4h + 3 of the set (the B operand's k order is permuted to match: the compressed
+// operand's own k order would pair {2h, 2h+1, 4+2h, 5+2h}, profiles/smfmac_semantics.hip).
+__global__ __launch_bounds__(256) void conv_sparse_index_kernel(const unsigned char* __restrict__ pos, unsigned* __restrict__ idxp, size_t n_sets,
+                                                                int HW, int C) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_sets * 4; i += (size_t)gridDim.x * 256) {
     const int q = (int)(i & 3);
-    const size_t set = i >> 2;
+    const size_t set = i >> 2;                             // (image, window, set of 8 channels) in the positions' own order
     const u32x2 pp = *reinterpret_cast<const u32x2*>(pos + set * 8);
     const unsigned qxm = (q & 1) ? 0x01010101u : 0u, qym = (q >> 1) ? 0x01010101u : 0u;
     unsigned word[4][2];
@@ -97,15 +105,47 @@ __global__ __launch_bounds__(256) void conv_sparse_index_kernel(const unsigned c
       word[2][d] = (0x02020202u | ((mh & mv) ^ 0x01010101u)) << 2;
       word[3][d] = (px & mv) | (nmv << 1) | 0x0C0C0C0Cu;
     }
-    unsigned h0[4], h1[4];
+    unsigned h0[4], h1[4];                                   // per plane: the four nibbles of channels 0..3 / 4..7
 #pragma unroll
     for (int pl = 0; pl < 4; ++pl) {
       const unsigned t0 = word[pl][0] | (word[pl][0] >> 4), t1 = word[pl][1] | (word[pl][1] >> 4);
-      h0[pl] = (t0 & 0xFFu) | ((t1 & 0xFFu) << 8);
-      h1[pl] = ((t0 >> 16) & 0xFFu) | (((t1 >> 16) & 0xFFu) << 8);
+      h0[pl] = (t0 & 0xFFu) | (((t0 >> 16) & 0xFFu) << 8);
+      h1[pl] = (t1 & 0xFFu) | (((t1 >> 16) & 0xFFu) << 8);
     }
     const u32x4 iw = {h0[0] | (h0[1] << 16), h0[2] | (h0[3] << 16), h1[0] | (h1[1] << 16), h1[2] | (h1[3] << 16)};
-    reinterpret_cast<u32x4*>(idxp)[i] = iw;
+    const int spw = C >> 3;                                  // sets per window
+    const size_t win = set / spw;
+    const int sw = (int)(set - win * spw), chunk = sw >> 1, s2 = sw & 1;
+    const size_t img = win / HW, pix = win - img * HW;
+    reinterpret_cast<u32x4*>(idxp)[((((img * 4 + q) * (C >> 4) + chunk) * HW + pix) << 1) + s2] = iw;
+  }
+}
+
+// S_c fp32 [NB][Hp * Wp][C] -> split8 pairs in the chunk-major layout the tiles stage from: [NB][C / 16][Hp * Wp][2 sets x (hi8 | lo8)]
+__global__ __launch_bounds__(256) void conv_sparse_pairs_kernel(const float* __restrict__ sc, float* __restrict__ scp, size_t n_sets, int HW, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_sets; i += (size_t)gridDim.x * 256) {
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(sc + i * 8);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(sc + i * 8 + 4);
+    const int spw = C >> 3;
+    const size_t win = i / spw;
+    const int sw = (int)(i - win * spw), chunk = sw >> 1, s2 = sw & 1;
+    const size_t n = win / HW, pix = win - n * HW;
+    split8_store(v, scp + ((((n * (C >> 4) + chunk) * HW + pix) << 1) + s2) * 8);
+  }
+}
+
+// ... and the same re-layout of pairs the walk's producer has already written window-major ([NB][Hp * Wp][C] split8 groups)
+__global__ __launch_bounds__(256) void conv_sparse_relayout_kernel(const float* __restrict__ pairs, float* __restrict__ scp, size_t n_sets, int HW, int C) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_sets; i += (size_t)gridDim.x * 256) {
+    const u32x4 hi = *reinterpret_cast<const u32x4*>(pairs + i * 8), lo = *reinterpret_cast<const u32x4*>(pairs + i * 8 + 4);
+    const int spw = C >> 3;
+    const size_t win = i / spw;
+    const int sw_ = (int)(i - win * spw), chunk = sw_ >> 1, s2 = sw_ & 1;
+    const size_t n = win / HW, pix = win - n * HW;
+    float* dst = scp + ((((n * (C >> 4) + chunk) * HW + pix) << 1) + s2) * 8;
+    *reinterpret_cast<u32x4*>(dst) = hi;
+    *reinterpret_cast<u32x4*>(dst + 4) = lo;
   }
 }
 
@@ -127,7 +167,9 @@ __global__ __launch_bounds__(256) void conv_sparse_pack_kernel(const float* __re
     bf16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int k32 = 16 * half + 8 * part + e, ch8 = k32 >> 2, slot = k32 & 3;
+      // B's k = 4 cb + slot; the A lane (half h, group g) meets cb = 4 (g / 2) + 2 h + (g % 2) and holds real channel 4 h + g
+      const int k32 = 16 * half + 8 * part + e, cb = k32 >> 2, slot = k32 & 3;
+      const int ch8 = 4 * ((cb >> 1) & 1) + 2 * (cb >> 2) + (cb & 1);
       const int co = chunk * 16 + (step & 1) * 8 + ch8;
       const int tap = sparse_slot_tap(q, step >> 1, slot);
       const float v = (tap >= 0 && ci < N && co < C) ? wb[(size_t)ci * 9 * CPo + (size_t)tap * CPo + co] : 0.f;
@@ -165,13 +207,12 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
   unsigned char* Bs = lds;
   unsigned char* As = lds + SP_NSTAGE * SP_BSTAGE;
 
-  // ---- A in LDS: three planes per buffer (pairs hi, pairs lo, index words), 32 B per resident window each = four 8 B chunks
-  // c = 2 set + lane half; chunk c of window e lives at e * 32 + ((c ^ f(e)) << 3), f(e) = ((e >> 3) ^ (e >> 5)) & 3: the 32 lanes of a
-  // fragment read 32 (nearly) consecutive windows — the pitch-16 rows of a 14-wide tile make them span up to 36 entries — and
-  // windows 8, 16, 24, 32 apart (the same banks at a 32 B pitch) then read different chunks.
-  // Per A fragment: the plane offsets (set 0; set 1 = offset ^ 16) of the four windows its row reads — own, horizontal, vertical,
+  // ---- A in LDS: six sub-planes per buffer — pairs hi, pairs lo, index words, each for set 0 and set 1 — of 16 B per resident
+  // window: [lane half 0: 8 B | lane half 1: 8 B].  The 16 lanes LDS serves per cycle of a ds_read_b64 read 16 (nearly) consecutive
+  // windows at a 16 B pitch: all 64 banks once, no swizzle needed; and a sub-plane is a plain 16 B-per-lane LDS-DMA image of what
+  // lies in global memory.  Per A fragment: the sub-plane offsets of the four windows its row reads — own, horizontal, vertical,
   // diagonal neighbour; a neighbour outside the image, or in another token, is the all-zero entry.  Fixed for the whole K loop.
-  auto chunk0 = [&](int e) { return e * 32 + ((half ^ (((e >> 3) ^ (e >> 5)) & 3)) << 3); };
+  auto chunk0 = [&](int e) { return e * 16 + half * 8; };
   int e_own[4], e_h[4], e_v[4], e_d[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -188,7 +229,6 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
     e_v[i] = chunk0(okv ? e + sy * SP_PITCH : SP_NENT);
     e_d[i] = chunk0(okh && okv ? e + sy * SP_PITCH + sx : SP_NENT);
   }
-  constexpr int PLANE = (SP_NENT + 1) * 32;                 // bytes of one plane; buffer = [hi | lo | idx]
 
   // ---- B: LDS-DMA, 4 x 1 KiB per wave and step
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -204,69 +244,56 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
                                                step * SP_BSTAGE + (wave_s * 4 + p) * 1024, 0, 0);
   };
 
-  // ---- A staging: item = (resident window, 8-channel set) of the NEXT chunk; thread t owns items t and t + 512, one after the
-  // other through the same ten registers.  Where an item lives in global memory does not depend on the chunk: offsets once.
-  struct Item { u32x4 hi, lo, p; };
-  auto item_ok = [&](int it) -> bool {
-    const int e = it >> 1;
-    const int hy = e / SP_PITCH, hx = e - hy * SP_PITCH;
+  // ---- A staging: by LDS-DMA as well, 16 B per lane: a sub-plane entry IS 16 contiguous bytes of global memory — the hi (or lo)
+  // half of a window's split8 group of the set, or the index words conv_sparse_index_kernel left for (window, set, class) — so no
+  // register, no VALU on the data, and no register load shares vmcnt with the B stages.  (Earlier forms, all measured [MI355X,
+  // block4_conv3, 2.5 ms launch]: through registers, +0.4 ms — hipcc waits vmcnt(0) for a register load that has LDS-DMA behind it
+  // on the counter, and a load that misses L2 stalls the step it was issued in, also when only half of the waves stage; one DWORD
+  // per lane into a swizzled 32 B-per-window image, +0.9 ms — 123 DMA instructions per chunk.)  A piece = 64 windows of one
+  // sub-plane; wave w moves pieces w, w + 8, ...; windows outside the image and the all-zero entry are out-of-range offsets = zeros.
+  int* imgtab = reinterpret_cast<int*>(As + 2 * SP_ABUF);       // resident window row hy -> image of its token
+  if (tid < SP_TH + 2) {
+    const int Ys = Y0 - 1 + tid;
+    int n_, wy;
+    divmod(Ys >= 0 && Ys < nys ? Ys : 0, Hp, inv_Hp, n_, wy);
+    imgtab[tid] = a.row2img ? a.row2img[n_] : n_;
+  }
+  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.sc, 0, 0x7FFFFFFF, RSRC_FLAGS);
+  const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void*)a.idxp, 0, 0x7FFFFFFF, RSRC_FLAGS);
+  constexpr int OOB = (int)0x80000000;
+  auto fire_a = [&](int slot, int chunk, int abuf) {
+    // (opaque copies: the address math of a slot does not depend on the chunk, and hipcc otherwise keeps every slot's worth of it
+    //  alive across the K loop; recomputed per call it is ~25 VALU instructions)
+    int wv = wave_s, ln = lane;
+    asm volatile("" : "+s"(wv), "+v"(ln));
+    int pj = wv + 8 * slot;
+    if (pj >= SP_APIECES) pj = SP_APIECES - 1;               // (spare slots repeat the last piece: idempotent)
+    const int sp = pj / SP_SUBPIECES, jp = pj - sp * SP_SUBPIECES;         // sub-plane, piece of it (wave-uniform)
+    const int first = jp * 64 < SP_PENT - 64 ? jp * 64 : SP_PENT - 64;     // (the last piece overlaps its predecessor)
+    const int pl = sp >> 1, s = sp & 1;
+    const int e = first + ln;
+    const int hy = e >> 4, hx = e & 15;
     const int Ys = Y0 - 1 + hy, wx = x0 - 1 + hx;
-    return it < 2 * SP_NENT && Ys >= 0 && Ys < nys && wx >= 0 && wx < Wp;
-  };
-  const float* isp[2];
-  const unsigned* ipp[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int it = tid + u * 512;
-    const int e = it >> 1, s = it & 1;
-    const int hy = e / SP_PITCH, hx = e - hy * SP_PITCH;
-    const int Ys = Y0 - 1 + hy, wx = x0 - 1 + hx;
-    const bool ok = item_ok(it);
+    const bool ok = e < SP_NENT && Ys >= 0 && Ys < nys && wx >= 0 && wx < Wp;
     int n_, wy;
     divmod(ok ? Ys : 0, Hp, inv_Hp, n_, wy);
-    const int wxc = ok ? wx : 0;
-    const int img = a.row2img ? a.row2img[n_] : n_;
-    isp[u] = a.sc + (((size_t)n_ * Hp + wy) * Wp + wxc) * C + s * 8;          // (a clamped, always valid place for the items nobody reads)
-    ipp[u] = a.idxp + (((((size_t)img * Hp + wy) * Wp + wxc) * (C >> 3) + s) * 4 + q) * 4;
-  }
-  // (Plain loads: hipcc's wait-count pass sees LDS-DMA and register loads pending on one counter and waits vmcnt(0) in front
-  //  of an item's first use — the B stages requested in that step included.  Issuing the loads from inline assembly, invisible
-  //  to that pass and covered by the counted waits at the barriers alone, measured the same [MI355X 2.58 vs 2.59 ms] and leaves
-  //  the compiler free to copy a destination register before its load has landed: not kept.)
-  auto item_load = [&](Item& w, int u, int chunk) {
-    const float* sp = isp[u] + chunk * 16;
-    const unsigned* pp = ipp[u] + chunk * 32;
-    w.hi = *reinterpret_cast<const u32x4*>(sp);
-    w.lo = *reinterpret_cast<const u32x4*>(sp + 4);
-    w.p = *reinterpret_cast<const u32x4*>(pp);
-  };
-  auto item_store = [&](const Item& w, int it, int abuf) {
-    if (!item_ok(it)) return;                              // (windows outside the image are never read: their rows point at the zero entry)
-    const int e = it >> 1, s = it & 1, f = ((e >> 3) ^ (e >> 5)) & 3;
-    unsigned char* base = As + abuf * SP_ABUF + e * 32 + ((s ^ (f >> 1)) << 4);   // the set's 16 B slot; its halves swap when f is odd
-    // pairs in lane order: lane half h of a fragment reads channels {2h, 2h+1, 4+2h, 5+2h} of the set as 8 contiguous bytes
-    const bool swp = (f & 1) != 0;
-    const u32x4 hi = swp ? u32x4{w.hi[1], w.hi[3], w.hi[0], w.hi[2]} : u32x4{w.hi[0], w.hi[2], w.hi[1], w.hi[3]};
-    const u32x4 lo = swp ? u32x4{w.lo[1], w.lo[3], w.lo[0], w.lo[2]} : u32x4{w.lo[0], w.lo[2], w.lo[1], w.lo[3]};
-    *reinterpret_cast<u32x4*>(base) = hi;
-    *reinterpret_cast<u32x4*>(base + PLANE) = lo;
-    // the index words of (set, half) = 8 B chunks [own | h | d | v], precomputed per image (conv_sparse_index_kernel)
-    const u32x4 iw = swp ? u32x4{w.p[2], w.p[3], w.p[0], w.p[1]} : w.p;
-    *reinterpret_cast<u32x4*>(base + 2 * PLANE) = iw;
+    int vo;
+    if (pl < 2) {
+      vo = ((((n_ * (C >> 4) + chunk) * Hp + wy) * Wp + wx) << 6) + s * 32 + pl * 16;       // the set's hi8 (pl 0) or lo8 (pl 1)
+    } else {
+      const int img = imgtab[ok ? hy : 0];
+      vo = (((((img * 4 + q) * (C >> 4) + chunk) * Hp + wy) * Wp + wx) << 5) + s * 16;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(pl < 2 ? rsS : rsI, (lptr_t)(As + abuf * SP_ABUF + sp * SP_SUB + first * 16), 16, ok ? vo : OOB,
+                                             0, 0, 0);
   };
 
-  // ---- prologue: zero entries, chunk 0 of A, the first two B steps
-  if (tid < 12) {                                          // 2 buffers x 3 planes x 32 B
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(As + (tid / 6) * SP_ABUF + ((tid % 6) >> 1) * PLANE + SP_NENT * 32 + (tid & 1) * 16) = z;
-  }
-  Item itm;
+  // ---- prologue: chunk 0 of A, the first two B steps
+  __syncthreads();                                         // (imgtab)
+#pragma unroll
+  for (int sl = 0; sl < SP_ASLOTS; ++sl) fire_a(sl, 0, 0);
   fire_b(0, 0);
   fire_b(1, 1);
-  item_load(itm, 0, 0);
-  item_store(itm, tid, 0);
-  item_load(itm, 1, 0);
-  item_store(itm, tid + 512, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -300,14 +327,20 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
       const int st = chunk * 6 + k;
       const int grp = k >> 1, s = k & 1;
       const unsigned char* Bb = Bs + (k % SP_NSTAGE) * SP_BSTAGE + bcol;   // (6 steps per chunk: the stage of step st is k % 3)
-      // (1) the item loads for the next chunk, THEN (2) the DMA of step st + 2: the counted wait at the end of the step covers the loads
-      // item 0: requested at step 0, written to LDS at step 1; item 1: steps 2 -> 3
-      if (next_chunk && !(a.diag & 2)) {
-        if (k == 0) item_load(itm, 0, chunk + 1);
-        else if (k == 2) item_load(itm, 1, chunk + 1);
-      }
+      // (1) the B stage of step st + 2, THEN (2) A pieces of the next chunk (up to two per wave in each of the steps 0..3).  vmcnt
+      // counts in order: B comes from L2, an A piece is a first touch of 64 windows that may come from HBM — behind the B stage on
+      // the counter it is only waited for together with the NEXT step's B stage, two steps later (in front of it, it held the B
+      // stage's completion back: +0.3 ms of a 2.5 ms launch [MI355X]).
       const bool more = st + 2 < nsteps && !(a.diag & 4);
+      constexpr int NA0 = SP_ASLOTS;                       // A pieces of step k: slots 2k, 2k + 1 below SP_ASLOTS
+      auto na_of = [](int kk) { return kk >= 0 && kk < 4 ? (2 * kk + 2 <= NA0 ? 2 : 2 * kk + 1 <= NA0 ? 1 : 0) : 0; };
+      const int na = na_of(k), na_prev = na_of(k - 1);
+      const bool stage = next_chunk && !(a.diag & 2);
       if (more) fire_b(st + 2, (k + 2) % SP_NSTAGE);
+      if (stage && na > 0) {
+        fire_a(2 * k, chunk + 1, nbuf);
+        if (na > 1) fire_a(2 * k + 1, chunk + 1, nbuf);
+      }
       // (3) this step: B fragments, then per A fragment its operand and six smfmacs
       bf16x16 bh[2], bl[2];
 #pragma unroll
@@ -318,21 +351,23 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
         bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
         bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
       }
-      const int sx16 = s * 16;
+      const unsigned char* Ah = Ab + (0 + s) * SP_SUB;     // pairs hi / lo / index words of this step's set
+      const unsigned char* Al = Ab + (2 + s) * SP_SUB;
+      const unsigned char* Ai = Ab + (4 + s) * SP_SUB;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bf16x8 vh, vl;
         int ix;
         if (grp == 1) {
-          const int oh = e_h[i] ^ sx16, od = e_d[i] ^ sx16;
-          vh = pairup(ld8(Ab + oh), ld8(Ab + od));
-          vl = pairup(ld8(Ab + PLANE + oh), ld8(Ab + PLANE + od));
-          ix = (int)(ld2(Ab + 2 * PLANE + oh + 2) | ld2(Ab + 2 * PLANE + od + 4));
+          const int oh = e_h[i], od = e_d[i];
+          vh = pairup(ld8(Ah + oh), ld8(Ah + od));
+          vl = pairup(ld8(Al + oh), ld8(Al + od));
+          ix = (int)(ld2(Ai + oh + 2) | ld2(Ai + od + 4));
         } else {
-          const int oo = (grp == 0 ? e_own[i] : e_v[i]) ^ sx16;
-          vh = expand(ld8(Ab + oo));
-          vl = expand(ld8(Ab + PLANE + oo));
-          ix = (int)ld2(Ab + 2 * PLANE + oo + (grp == 0 ? 0 : 6));
+          const int oo = grp == 0 ? e_own[i] : e_v[i];
+          vh = expand(ld8(Ah + oo));
+          vl = expand(ld8(Al + oo));
+          ix = (int)ld2(Ai + oo + (grp == 0 ? 0 : 6));
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -341,16 +376,16 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
           acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vh, bh[j], acc[i][j], ix, 0, 0);
         }
       }
-      // (4) the next chunk's resident windows: requested a step ago
-      if (next_chunk && !(a.diag & 2)) {
-        if (k == 1) item_store(itm, tid, nbuf);
-        else if (k == 3) item_store(itm, tid + 512, nbuf);
-      }
-      // (5) step st + 1 has landed (everything older than this step's four DMA instructions); everyone is done with step st.
-      // (a bare s_barrier, not __syncthreads(): with plain global loads in the loop hipcc's workgroup fence waits vmcnt(0) in
-      //  front of every barrier and the DMA of step st + 2 would have to land within the step it was issued in)
+      // (5) step st + 1 has landed — everything older than this step's B stage: younger than that are the previous step's A
+      // pieces, this step's B stage and this step's A pieces — and everyone is done with step st.  The last A pieces (step 2) are
+      // older than the B stage of step 3: complete by the end of step 4.  (A bare s_barrier: __syncthreads() adds hipcc's fence.)
+      const int keep = more ? 4 + (stage ? na_prev + na : 0) : 0;
       if ((a.diag & 8) && !(k & 1)) {                      // (measurement: a barrier every second step only)
-      } else if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else if (keep == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (keep == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (keep == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (keep == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else if (keep == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
@@ -426,7 +461,13 @@ inline hipError_t conv_sparse_pack(const float* wb_dev, float* wsp_dev, int N, i
 inline size_t conv_sparse_index_words(int images, int Hp, int Wp, int C) { return (size_t)images * Hp * Wp * (C / 8) * 4 * 4; }
 inline hipError_t conv_sparse_index(const unsigned char* pos_dev, unsigned* idxp_dev, int images, int Hp, int Wp, int C, hipStream_t st) {
   const size_t n_sets = (size_t)images * Hp * Wp * (C / 8);
-  hipLaunchKernelGGL(conv_sparse_index_kernel, dim3(stream_grid(n_sets * 4)), dim3(256), 0, st, pos_dev, idxp_dev, n_sets);
+  hipLaunchKernelGGL(conv_sparse_index_kernel, dim3(stream_grid(n_sets * 4)), dim3(256), 0, st, pos_dev, idxp_dev, n_sets, Hp * Wp, C);
+  return hipGetLastError();
+}
+// S_c fp32 (NB, Hp, Wp, C) -> the chunk-major pairs a launch reads (NB * Hp * Wp * C floats)
+inline hipError_t conv_sparse_pairs(const float* sc_dev, float* scp_dev, int NB, int Hp, int Wp, int C, hipStream_t st) {
+  const size_t n_sets = (size_t)NB * Hp * Wp * (C / 8);
+  hipLaunchKernelGGL(conv_sparse_pairs_kernel, dim3(stream_grid(n_sets)), dim3(256), 0, st, sc_dev, scp_dev, n_sets, Hp * Wp, C);
   return hipGetLastError();
 }
 

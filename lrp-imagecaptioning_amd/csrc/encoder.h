@@ -14,6 +14,7 @@
 #include "cnn_kernels.h"
 #include "common.h"
 #include "conv_igemm.h"
+#include "conv_sparse.h"
 #include "f16_operand.h"
 
 namespace lrp {
@@ -46,6 +47,11 @@ struct ConvLayer {
   // pool interface; written by pool_gate_split_kernel, valid for the encode whose number gc_epoch holds
   DevBuf Gc, Gpos;
   long gc_epoch = -1;
+  // 2:4-sparse consumer of the pooled boundary behind this layer (conv_sparse.h; layers with cin % 256 == 0 whose output is pooled:
+  // VGG16 block3_conv3, block4_conv3): the four class arrangements of w+ and, per encode, the index planes of the pool's positions
+  DevBuf w_sp, idxp;
+  long idx_epoch = -1;
+  bool sparse_ok() const { return pool_after && conv_sparse_supports(cin, cout, H / 2, W / 2) && !(H & 1) && !(W & 1); }
   std::vector<float> raw_w, raw_b;   // host copies as set (HWIO / (cout,)): the fine-tune step's master weights start here
   DevBuf raw_w_dev, raw_b_dev;       // the same when the weights arrived through lrp_set_weight_dev (no host copy exists then)
   DevBuf fnorm;    // {largest absolute row sum of w, max|b|}: bound behind the scale of the pairs this layer emits (fwd_scale_kernel)
@@ -93,6 +99,7 @@ struct Encoder {
   }
                            // Its parity depends on the weight statistics (one fp16 per weight: worst case 2^-12 per product, above the
                            // 1e-4 bar; tests/test_gpu_stress_parity.py), so the default is the three-MFMA split-bf16 walk.
+  DevBuf sp_scp;                      // sparse consumers: S_c of the call as chunk-major pairs (conv_sparse.h)
   DevBuf act_max, act_unscale;        // fp16-pair forward: per layer ACT_MAX_SLOTS maxima of its output / 2^-k of its input
   DevBuf out_scale;                   // ... and 2^k of the pairs a layer emits for its consumer (no split pass in between)
   static bool fwd_emit() { return sw().fwd_emit != 0; }   // LRP_FWD_EMIT=0: split passes between the convs as in round 2
@@ -178,6 +185,16 @@ struct Encoder {
     }
     for (size_t i = 0; i + 1 < layers.size(); ++i)
       if (layers[i].pool_after) LRP_TRY(layers[i].P.alloc(B * layers[i].act_elems() / 4 * sizeof(float), total));
+    {  // sparse consumers: index planes per image, one chunk-major copy of S_c per call (the largest of them)
+      size_t mx = 0;
+      for (size_t i = 1; i + 1 < layers.size(); ++i) {
+        ConvLayer& Lc = layers[i];
+        if (!Lc.sparse_ok() || !Lc.Gpos.p || layers[i - 1].pool_after) continue;
+        LRP_TRY(Lc.idxp.alloc(conv_sparse_index_words((int)B, Lc.H / 2, Lc.W / 2, Lc.cout) * sizeof(unsigned), total));
+        mx = std::max(mx, NT * Lc.act_elems() / 4);
+      }
+      if (mx) LRP_TRY(sp_scp.alloc(mx * sizeof(float), total));
+    }
     {
       // lowest priority: the side work is throughput work that should only fill what the caller's stream leaves idle
       int lo = 0, hi = 0;
@@ -323,6 +340,10 @@ struct Encoder {
         pack_split8(pk.data(), pk.size(), sp.data());
         LRP_TRY(L.w_bwd_s.alloc(sp.size() * sizeof(float), total));
         LRP_HIP_CHECK(hipMemcpy(L.w_bwd_s.p, sp.data(), sp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (L.sparse_ok() && L.idxp.p) {
+          LRP_TRY(L.w_sp.alloc(conv_sparse_weight_floats(L.cin, L.cout) * sizeof(float), total));
+          LRP_HIP_CHECK(conv_sparse_pack(L.w_bwd.as<float>(), L.w_sp.as<float>(), L.cin, L.cout, nullptr));
+        }
         if (Npb == 64) {
           std::vector<float> fr((size_t)64 * Kb);
           pack_frag64(sp.data(), 9, conv_cinp(L.cout), fr.data());
@@ -392,6 +413,7 @@ struct Encoder {
     LRP_TRY(mk(L.w_fwd_a, nf)); LRP_TRY(mk(L.w_fwd_zs, nf)); LRP_TRY(mk(L.w_fwd_as, nf));
     LRP_TRY(mk(L.w_bwd, nb)); LRP_TRY(mk(L.w_bwd_s, nb)); LRP_TRY(mk(L.w_bwd_full, nb)); LRP_TRY(mk(L.w_bwd_full_s, nb));
     LRP_TRY(mk(L.w_bwd_h, nb));
+    if (L.sparse_ok() && L.idxp.p) LRP_TRY(mk(L.w_sp, conv_sparse_weight_floats(L.cin, L.cout)));
     if (conv_npad(L.cin) == 64) { LRP_TRY(mk(L.w_bwd_frag, (size_t)64 * Kb)); LRP_TRY(mk(L.w_bwd_frag_h, (size_t)64 * Kb)); }
     if (pack_tmp.bytes < nf * sizeof(float)) LRP_TRY(pack_tmp.alloc(nf * sizeof(float), total));
     return LRP_OK;
@@ -435,6 +457,7 @@ struct Encoder {
     split(L.w_fwd_a.as<float>(), L.w_fwd_as.as<float>(), nf);
     pack(L.w_bwd.as<float>(), 1, Npb, 0, 1);
     split(L.w_bwd.as<float>(), L.w_bwd_s.as<float>(), nb);
+    if (L.w_sp.p) LRP_HIP_CHECK(conv_sparse_pack(L.w_bwd.as<float>(), L.w_sp.as<float>(), L.cin, L.cout, st));
     if (L.w_bwd_frag.p)
       hipLaunchKernelGGL(pack_frag64_dev_kernel, dim3(stream_grid((size_t)CPo / 32 * 9 * 512)), dim3(256), 0, st, L.w_bwd_s.as<float>(),
                          L.w_bwd_frag.as<float>(), CPo);
@@ -634,6 +657,10 @@ struct Encoder {
                                  L.G.as<float>(), pin, keep_acts ? L.P.as<float>() : (float*)nullptr, oscale_of(li), B, L.H, L.W, L.cout,
                                  L.Gc.as<float>(), L.Gpos.as<unsigned char>());
               if (L.Gc.p) layers[li].gc_epoch = encode_epoch;
+              if (L.idxp.p && L.w_sp.p && sw().sparse_pool) {          // the sparse consumer's index words, once per image
+                LRP_HIP_CHECK(conv_sparse_index(L.Gpos.as<unsigned char>(), L.idxp.as<unsigned>(), B, L.H / 2, L.W / 2, L.cout, st));
+                layers[li].idx_epoch = encode_epoch;
+              }
             } else {
               hipLaunchKernelGGL(maxpool2_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, a_out, L.P.as<float>(), B, L.H, L.W, L.cout);
               hipLaunchKernelGGL(pool_gate_kernel, dim3(stream_grid(n / 16)), dim3(256), 0, st, L.G.as<float>(), bufZ.as<float>(),
@@ -922,6 +949,28 @@ struct Encoder {
           int hr_ = 0;
           (void)conv_halo_geom(128, L.H, L.W, fold_tw, fold_th, hr_);
           ca.img_w = P.w_bwd_s.as<float>(); ca.img_part = Snext; ca.out = nullptr;
+        }
+        if (compact_in == 2 && sw().sparse_pool && L.w_sp.p && L.idx_epoch == encode_epoch && !P.pool_after && split && !f16 && walk == 0 &&
+            !layer_hook && sp_scp.p) {
+          // the pooled boundary on the 2:4-sparse matrix cores (conv_sparse.h): S_c re-laid chunk-major, then one launch per class
+          const int Hp = L.H / 2, Wp = L.W / 2;
+          const size_t n_sets = (size_t)n * Hp * Wp * (L.cout / 8);
+          ProfileRec pr{};
+          if (profile) { (void)hipEventCreate(&pr.e0); (void)hipEventCreate(&pr.e1); (void)hipEventRecord(pr.e0, st); }
+          hipLaunchKernelGGL(conv_sparse_relayout_kernel, dim3(stream_grid(n_sets)), dim3(256), 0, st, S, sp_scp.as<float>(), n_sets, Hp * Wp, L.cout);
+          LRP_HIP_CHECK(hipGetLastError());
+          SparseArgs sa{};
+          sa.sc = sp_scp.as<float>(); sa.idxp = L.idxp.as<unsigned>(); sa.wsp = L.w_sp.as<float>(); sa.gate = P.G.as<float>(); sa.out = Snext;
+          sa.row2img = row2img_dev; sa.NB = n; sa.Hp = Hp; sa.Wp = Wp; sa.C = L.cout; sa.N = L.cin;
+          LRP_HIP_CHECK(conv_sparse_launch(sa, st));
+          if (profile) {
+            (void)hipEventRecord(pr.e1, st);
+            pr.flop = 2.0 * (double)n * L.H * L.W * 9.0 * L.cout * L.cin;
+            prof.push_back(pr);
+          }
+          compact_in = 0;
+          float* t = S; S = Snext; Snext = t;
+          continue;
         }
         if (compact_in == 2 || compact_in == 3) {         // pairs of S_c at pooled resolution (pipelined kernels' loader / the folded BREG launch)
           ca.up2_src = S; ca.up2_pairs = 1; ca.up2_gpos = L.Gpos.as<unsigned char>();

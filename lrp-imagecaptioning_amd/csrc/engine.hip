@@ -505,8 +505,7 @@ int lrp_op_conv_pool_sparse(const float* sc_dev, const unsigned char* pos_dev, c
     LRP_HIP_CHECK(conv_sparse_pack(wb.as<float>(), wsp.as<float>(), Cin, Cout, st));
     const size_t n8 = (size_t)NB * Hp * Wp * Cout / 8;
     LRP_TRY(pairs.alloc(n8 * 32, nullptr));
-    hipLaunchKernelGGL(split_copy_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, sc_dev, pairs.as<float>(), n8);
-    LRP_HIP_CHECK(hipGetLastError());
+    LRP_HIP_CHECK(conv_sparse_pairs(sc_dev, pairs.as<float>(), NB, Hp, Wp, Cout, st));
     DevBuf idxp;
     LRP_TRY(idxp.alloc(conv_sparse_index_words(NB, Hp, Wp, Cout) * sizeof(unsigned), nullptr));
     LRP_HIP_CHECK(conv_sparse_index(pos_dev, idxp.as<unsigned>(), NB, Hp, Wp, Cout, st));
