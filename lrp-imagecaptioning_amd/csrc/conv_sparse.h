@@ -19,8 +19,8 @@
 // ONE class (rows = windows), four weight arrangements exist (4/3 of the dense bytes each), and the grid walks class by class
 // so that the workgroups resident on an XCD share one arrangement in its L2.
 //
-// Tile 256 windows x 256 output channels, 8 waves of 128 x 64 (as the dense 8-wave tile); per 16-channel chunk six k-steps
-// (own, own, h+d, h+d, v, v: 8 channels each) of 24 smfmacs per wave.  B: LDS-DMA, three 32 KB stages, counted vmcnt.
+// Tile 256 windows x 256 output channels, 8 waves of 128 x 64 (as the dense 8-wave tile); per 8-channel set three k-steps
+// (own | h + d | v) of 24 smfmacs per wave, two k-steps per barrier.  B: LDS-DMA, four 32 KB stages (two super-steps).
 // A: the tile's windows + a one-window ring, 96 B per window and chunk (pairs in lane order + four planes of index words, the
 // latter precomputed once per image by conv_sparse_index_kernel), copied through registers a step ahead, double-buffered.
 #pragma once
@@ -44,21 +44,21 @@ struct SparseArgs {
   int NB, Hp, Wp, C, N;
   int cols_t, m_tiles, n_tiles;
   int out_plain;
-  int diag;                   // measurement only (profiles/sparse_ab.py): bit 0 no epilogue stores, bit 1 no A staging in the loop, bit 2 no B DMA in the loop
+  int diag;                   // measurement only (profiles/sparse_ab.py): bit 0 no epilogue stores
 };
 
 constexpr int SP_TW = 14, SP_TH = 18, SP_PITCH = SP_TW + 2;      // tile = 18 stack window rows x 14 window columns = 252 rows
 constexpr int SP_NENT = (SP_TH + 2) * SP_PITCH;                  // resident windows (tile + ring); entry SP_NENT = all-zero
 constexpr int SP_PENT = SP_NENT + 1;                             // entries of a sub-plane (the last one is the all-zero entry)
 constexpr int SP_SUB = SP_PENT * 16;                             // bytes of a sub-plane: 16 B per resident window = [lane half 0: 8 B | half 1: 8 B]
-constexpr int SP_ABUF = 6 * SP_SUB;                              // [pairs hi | pairs lo | index words] x [set 0 | set 1]
+constexpr int SP_ABUF = 3 * SP_SUB;                              // one 8-channel set: [pairs hi | pairs lo | index words]
 constexpr int SP_SUBPIECES = (SP_PENT + 63) / 64;                // 1 KiB DMA pieces per sub-plane (the last one overlaps the one before)
-constexpr int SP_APIECES = 6 * SP_SUBPIECES;
-constexpr int SP_ASLOTS = (SP_APIECES + 7) / 8;                  // pieces per wave and chunk
-constexpr int SP_BSTAGE = 32768, SP_NSTAGE = 3;
+constexpr int SP_APIECES = 3 * SP_SUBPIECES;
+constexpr int SP_ASLOTS = (SP_APIECES + 7) / 8;                  // pieces per wave and set
+constexpr int SP_BSTAGE = 32768, SP_NSTAGE = 4;
 constexpr int SP_LDS = SP_NSTAGE * SP_BSTAGE + 2 * SP_ABUF + 128;      // (+ the window row -> image table)
 static_assert(SP_LDS <= 160 * 1024, "LDS");
-static_assert(SP_ASLOTS <= 8 && SP_PENT >= 64, "two A pieces per wave in each of the first four steps of a chunk");
+static_assert(SP_PENT >= 64, "a DMA piece is 64 windows");
 
 // B operand of class q: slot -> tap of the backward conv (the matrix conv_igemm's launch multiplies with: row = output channel
 // ci, k = tap * CPo + co, tap = 3 (dy + 1) + (dx + 1) reads S[y + dy][x + dx]); -1 = dump slot (zero row).
@@ -261,22 +261,22 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
   const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)a.sc, 0, 0x7FFFFFFF, RSRC_FLAGS);
   const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc((void*)a.idxp, 0, 0x7FFFFFFF, RSRC_FLAGS);
   constexpr int OOB = (int)0x80000000;
-  auto fire_a = [&](int slot, int chunk, int abuf) {
-    // (opaque copies: the address math of a slot does not depend on the chunk, and hipcc otherwise keeps every slot's worth of it
+  auto fire_a = [&](int slot, int set8, int abuf) {           // set8 = 8-channel set of the layer (two per 16-channel chunk of the sources)
+    // (opaque copies: the address math of a slot does not depend on the set, and hipcc otherwise keeps every slot's worth of it
     //  alive across the K loop; recomputed per call it is ~25 VALU instructions)
     int wv = wave_s, ln = lane;
     asm volatile("" : "+s"(wv), "+v"(ln));
     int pj = wv + 8 * slot;
     if (pj >= SP_APIECES) pj = SP_APIECES - 1;               // (spare slots repeat the last piece: idempotent)
-    const int sp = pj / SP_SUBPIECES, jp = pj - sp * SP_SUBPIECES;         // sub-plane, piece of it (wave-uniform)
+    const int pl = pj / SP_SUBPIECES, jp = pj - pl * SP_SUBPIECES;         // sub-plane (hi, lo, index words), piece of it (wave-uniform)
     const int first = jp * 64 < SP_PENT - 64 ? jp * 64 : SP_PENT - 64;     // (the last piece overlaps its predecessor)
-    const int pl = sp >> 1, s = sp & 1;
     const int e = first + ln;
     const int hy = e >> 4, hx = e & 15;
     const int Ys = Y0 - 1 + hy, wx = x0 - 1 + hx;
     const bool ok = e < SP_NENT && Ys >= 0 && Ys < nys && wx >= 0 && wx < Wp;
     int n_, wy;
     divmod(ok ? Ys : 0, Hp, inv_Hp, n_, wy);
+    const int chunk = set8 >> 1, s = set8 & 1;
     int vo;
     if (pl < 2) {
       vo = ((((n_ * (C >> 4) + chunk) * Hp + wy) * Wp + wx) << 6) + s * 32 + pl * 16;       // the set's hi8 (pl 0) or lo8 (pl 1)
@@ -284,16 +284,29 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
       const int img = imgtab[ok ? hy : 0];
       vo = (((((img * 4 + q) * (C >> 4) + chunk) * Hp + wy) * Wp + wx) << 5) + s * 16;
     }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(pl < 2 ? rsS : rsI, (lptr_t)(As + abuf * SP_ABUF + sp * SP_SUB + first * 16), 16, ok ? vo : OOB,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(pl < 2 ? rsS : rsI, (lptr_t)(As + abuf * SP_ABUF + pl * SP_SUB + first * 16), 16, ok ? vo : OOB,
                                              0, 0, 0);
   };
-
-  // ---- prologue: chunk 0 of A, the first two B steps
-  __syncthreads();                                         // (imgtab)
+  auto fire_set = [&](int set8, int abuf) {
 #pragma unroll
-  for (int sl = 0; sl < SP_ASLOTS; ++sl) fire_a(sl, 0, 0);
-  fire_b(0, 0);
-  fire_b(1, 1);
+    for (int sl = 0; sl < SP_ASLOTS; ++sl) fire_a(sl, set8, abuf);
+  };
+
+  // ---- K loop.  A set = 8 channels = three k-steps (own | h + d | v); the sources are 16-channel chunks = two sets = six steps,
+  // walked as three SUPER-STEPS of two k-steps with ONE barrier each (48 smfmacs per wave between barriers, like the dense tile):
+  //     super-step 0: (set 0 own, set 0 h+d)    1: (set 0 v, set 1 own)    2: (set 1 h+d, set 1 v)
+  // B: four 32 KB stages = two super-steps; at the top of a super-step the two stages of the NEXT one are requested (into the
+  // stages the previous one just released).  A: one buffer per set parity; set 0 of the next chunk is requested at the top of
+  // super-step 2 (its buffer was last read in super-step 1), set 1 at the top of the next chunk's super-step 0.  Everything
+  // requested at the top of a super-step has landed by its end: one s_waitcnt vmcnt(0) per barrier, nothing to count.
+  const int nsteps2 = nchunks * 6;
+  // global step index t -> where its 32 KB of B lie: chunk16 * 6 + 2 * group + set  (the pack kernel's order)
+  auto bsrc = [&](int chunk, int t6) { return chunk * 6 + 2 * (t6 % 3) + t6 / 3; };
+  __syncthreads();                                         // (imgtab)
+  fire_set(0, 0);
+  if (nchunks * 2 > 1) fire_set(1, 1);
+  fire_b(bsrc(0, 0), 0);
+  fire_b(bsrc(0, 1), 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -317,76 +330,69 @@ __global__ __launch_bounds__(512, 2) void conv_sparse_kernel(SparseArgs a) {
   };
   auto ld8 = [](const unsigned char* p) { return *reinterpret_cast<const u32x2*>(p); };
   auto ld2 = [](const unsigned char* p) { return (unsigned)*reinterpret_cast<const unsigned short*>(p); };
-
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const unsigned char* Ab = As + (chunk & 1) * SP_ABUF;
-    const int nbuf = (chunk + 1) & 1;
-    const bool next_chunk = chunk + 1 < nchunks;
+  struct BF { bf16x16 h[2], l[2]; };
+  auto load_b = [&](BF& b, const unsigned char* Bb) {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const int st = chunk * 6 + k;
-      const int grp = k >> 1, s = k & 1;
-      const unsigned char* Bb = Bs + (k % SP_NSTAGE) * SP_BSTAGE + bcol;   // (6 steps per chunk: the stage of step st is k % 3)
-      // (1) the B stage of step st + 2, THEN (2) A pieces of the next chunk (up to two per wave in each of the steps 0..3).  vmcnt
-      // counts in order: B comes from L2, an A piece is a first touch of 64 windows that may come from HBM — behind the B stage on
-      // the counter it is only waited for together with the NEXT step's B stage, two steps later (in front of it, it held the B
-      // stage's completion back: +0.3 ms of a 2.5 ms launch [MI355X]).
-      const bool more = st + 2 < nsteps && !(a.diag & 4);
-      constexpr int NA0 = SP_ASLOTS;                       // A pieces of step k: slots 2k, 2k + 1 below SP_ASLOTS
-      auto na_of = [](int kk) { return kk >= 0 && kk < 4 ? (2 * kk + 2 <= NA0 ? 2 : 2 * kk + 1 <= NA0 ? 1 : 0) : 0; };
-      const int na = na_of(k), na_prev = na_of(k - 1);
-      const bool stage = next_chunk && !(a.diag & 2);
-      if (more) fire_b(st + 2, (k + 2) % SP_NSTAGE);
-      if (stage && na > 0) {
-        fire_a(2 * k, chunk + 1, nbuf);
-        if (na > 1) fire_a(2 * k + 1, chunk + 1, nbuf);
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char* bp = Bb + j * 512;                               // [hi|lo][half][part][col] x 16 B
+      const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(bp), h1 = *reinterpret_cast<const bf16x8*>(bp + 4096);
+      const bf16x8 l0 = *reinterpret_cast<const bf16x8*>(bp + 16384), l1 = *reinterpret_cast<const bf16x8*>(bp + 16384 + 4096);
+      b.h[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+      b.l[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    }
+  };
+  // one k-step: group grp (0 own, 1 h + d, 2 v) of the set in buffer Ab against the B fragments b
+  auto kstep = [&](const unsigned char* Ab, int grp, const BF& b) {
+    const unsigned char* Ah = Ab;
+    const unsigned char* Al = Ab + SP_SUB;
+    const unsigned char* Ai = Ab + 2 * SP_SUB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8 vh, vl;
+      int ix;
+      if (grp == 1) {
+        const int oh = e_h[i], od = e_d[i];
+        vh = pairup(ld8(Ah + oh), ld8(Ah + od));
+        vl = pairup(ld8(Al + oh), ld8(Al + od));
+        ix = (int)(ld2(Ai + oh + 2) | ld2(Ai + od + 4));
+      } else {
+        const int oo = grp == 0 ? e_own[i] : e_v[i];
+        vh = expand(ld8(Ah + oo));
+        vl = expand(ld8(Al + oo));
+        ix = (int)ld2(Ai + oo + (grp == 0 ? 0 : 6));
       }
-      // (3) this step: B fragments, then per A fragment its operand and six smfmacs
-      bf16x16 bh[2], bl[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const unsigned char* bp = Bb + j * 512;                             // [hi|lo][half][part][col] x 16 B
-        const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(bp), h1 = *reinterpret_cast<const bf16x8*>(bp + 4096);
-        const bf16x8 l0 = *reinterpret_cast<const bf16x8*>(bp + 16384), l1 = *reinterpret_cast<const bf16x8*>(bp + 16384 + 4096);
-        bh[j] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-        bl[j] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+        acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vl, b.h[j], acc[i][j], ix, 0, 0);     // small terms first
+        acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vh, b.l[j], acc[i][j], ix, 0, 0);
+        acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vh, b.h[j], acc[i][j], ix, 0, 0);
       }
-      const unsigned char* Ah = Ab + (0 + s) * SP_SUB;     // pairs hi / lo / index words of this step's set
-      const unsigned char* Al = Ab + (2 + s) * SP_SUB;
-      const unsigned char* Ai = Ab + (4 + s) * SP_SUB;
+    }
+  };
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const bool next_chunk = chunk + 1 < nchunks;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x8 vh, vl;
-        int ix;
-        if (grp == 1) {
-          const int oh = e_h[i], od = e_d[i];
-          vh = pairup(ld8(Ah + oh), ld8(Ah + od));
-          vl = pairup(ld8(Al + oh), ld8(Al + od));
-          ix = (int)(ld2(Ai + oh + 2) | ld2(Ai + od + 4));
-        } else {
-          const int oo = grp == 0 ? e_own[i] : e_v[i];
-          vh = expand(ld8(Ah + oo));
-          vl = expand(ld8(Al + oo));
-          ix = (int)ld2(Ai + oo + (grp == 0 ? 0 : 6));
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vl, bh[j], acc[i][j], ix, 0, 0);     // small terms first
-          acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vh, bl[j], acc[i][j], ix, 0, 0);
-          acc[i][j] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(vh, bh[j], acc[i][j], ix, 0, 0);
-        }
+    for (int ss = 0; ss < 3; ++ss) {
+      const int t0 = 2 * ss, t1 = 2 * ss + 1;              // the super-step's two k-steps of the chunk's six
+      const int st0 = chunk * 6 + t0;                        // global step index: its B stage is st % 4
+      // (1) requests: the next super-step's two B stages, and the A set whose buffer has just been released
+      if (st0 + 2 < nsteps2) {
+        const int nc = ss == 2 ? chunk + 1 : chunk, nt0 = (t0 + 2) % 6;
+        fire_b(bsrc(nc, nt0), (st0 + 2) & 3);
+        fire_b(bsrc(nc, nt0 + 1), (st0 + 3) & 3);
       }
-      // (5) step st + 1 has landed — everything older than this step's B stage: younger than that are the previous step's A
-      // pieces, this step's B stage and this step's A pieces — and everyone is done with step st.  The last A pieces (step 2) are
-      // older than the B stage of step 3: complete by the end of step 4.  (A bare s_barrier: __syncthreads() adds hipcc's fence.)
-      const int keep = more ? 4 + (stage ? na_prev + na : 0) : 0;
-      if ((a.diag & 8) && !(k & 1)) {                      // (measurement: a barrier every second step only)
-      } else if (keep == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (keep == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (keep == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (keep == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else if (keep == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (ss == 2 && next_chunk) fire_set(2 * chunk + 2, 0);
+      if (ss == 0 && chunk > 0) fire_set(2 * chunk + 1, 1);
+      // (2) the two k-steps; the second one's B fragments are read while the first one's smfmacs run
+      BF b0, b1;
+      load_b(b0, Bs + (st0 & 3) * SP_BSTAGE + bcol);
+      load_b(b1, Bs + ((st0 + 1) & 3) * SP_BSTAGE + bcol);
+      kstep(As + (t0 / 3) * SP_ABUF, t0 % 3, b0);
+      kstep(As + (t1 / 3) * SP_ABUF, t1 % 3, b1);
+      // (3) everything requested at the top has landed; everyone is done with this super-step's stages and (ss 1, 2) A buffer.
+      // (A bare s_barrier: __syncthreads() adds hipcc's workgroup fence.)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
 
