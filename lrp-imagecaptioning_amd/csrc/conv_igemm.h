@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
   // their latency sat on every tile's critical path [MI355X: the forward convs 7 % slower]
   int simg0 = 0;
   float us0 = 1.f, us1 = 1.f, ps0 = 1.f, ps1 = 1.f;
+  [[maybe_unused]] const float inv_img_rows = EPI == EPI_FWD_DUAL && a.scale_per_img ? 1.0f / (float)a.img_rows : 0.f;
   if constexpr (EPI == EPI_FWD_DUAL) {
     if (a.dual_il) {
       int simg1 = 0;
@@ -1335,7 +1336,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
           if (ch < a.split) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const int pc = (p & ~63) + (p & 31);          // the c column of the pair; Z+ sits 32 further
-            float omax0 = 0.f, omax1 = 0.f;               // running max|a_l| of this thread's rows of image simg0 / simg0 + 1
+            // running max|a_l| of this thread's rows of images simg0 .. simg0 + 3 (a tile spans more than two images where an
+            // image is a few dozen rows — the 7 x 7 maps of a ResNet's last stack: as unreduced atomics per row those launches
+            // took 250 us instead of 36 [MI355X])
+            float omax0 = 0.f, omax1 = 0.f, omax2 = 0.f, omax3 = 0.f;
             auto max_slot = [&](int img) { return a.act_max_out + (size_t)img * ACT_MAX_SLOTS + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)); };
             static_assert((RH / RPP) % 4 == 0, "constant, even trip count: the loop holds lane shuffles (no remainder loop)");
 #pragma unroll 2
@@ -1343,7 +1347,12 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
               const int ll = rin + (half + 2 * pi) * RPP;
               int row, n_, h_, w_;
               if (!locate(hf * RH + ll, row, n_, h_, w_)) continue;
-              const int rel = (!a.scale_per_img ? 0 : HALO ? n_ : row / a.img_rows) - simg0;
+              int rimg = 0;                                // image of the row (1-tap launches over a pixel list: rows / image is
+              if (a.scale_per_img) {                       //  not a power of two — float estimate + fix-up, not an integer division)
+                if constexpr (HALO) rimg = n_;
+                else { int rr; divmod(row, a.img_rows, inv_img_rows, rimg, rr); }
+              }
+              const int rel = rimg - simg0;
               float unscale = rel == 0 ? us0 : us1, pscale = rel == 0 ? ps0 : ps1;
               if (__builtin_expect(rel > 1, 0)) {         // (a tile over three or more images: images smaller than half a tile)
                 if constexpr (PREC == PREC_F16X2) unscale = a.in_unscale[simg0 + rel];
@@ -1379,6 +1388,8 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
                 const float m4 = fmaxf(fmaxf(fabsf(vc[0]), fabsf(vc[1])), fmaxf(fabsf(vc[2]), fabsf(vc[3])));
                 if (rel == 0) omax0 = fmaxf(omax0, m4);
                 else if (rel == 1) omax1 = fmaxf(omax1, m4);
+                else if (rel == 2) omax2 = fmaxf(omax2, m4);
+                else if (rel == 3) omax3 = fmaxf(omax3, m4);
                 else if (m4 > 0.f) atomicMax(max_slot(simg0 + rel), __float_as_uint(m4));
               }
               if (!a.skip_out) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.split + ch) = vc;
@@ -1417,9 +1428,13 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
               for (int o = 32; o > 0; o >>= 1) {
                 omax0 = fmaxf(omax0, __shfl_xor(omax0, o));
                 omax1 = fmaxf(omax1, __shfl_xor(omax1, o));
+                omax2 = fmaxf(omax2, __shfl_xor(omax2, o));
+                omax3 = fmaxf(omax3, __shfl_xor(omax3, o));
               }
               if (lane == 0 && omax0 > 0.f) atomicMax(max_slot(simg0), __float_as_uint(omax0));
               if (lane == 0 && omax1 > 0.f) atomicMax(max_slot(simg0 + 1), __float_as_uint(omax1));
+              if (lane == 0 && omax2 > 0.f) atomicMax(max_slot(simg0 + 2), __float_as_uint(omax2));
+              if (lane == 0 && omax3 > 0.f) atomicMax(max_slot(simg0 + 3), __float_as_uint(omax3));
             }
           }
         } else

@@ -52,6 +52,10 @@ struct ResNetEncoder {
   DevBuf fxs;                      // a unit's input as scaled fp16 pairs (fp16-pair forward)
   DevBuf f16_slots;                // scratch maxima of make_f16_operand
   DevBuf act_max, act_unscale;     // ACT_MAX_SLOTS maxima per unit output / block output; 2^-k per unit input
+  // round-4 forward (encode_emit): per IMAGE max-slots of every unit / block output, the pair scale of every tensor that is
+  // written as pairs, the unscale of every unit's input, and per unit the bound constants {A, B} (rn_unit_norm_kernel)
+  DevBuf eslots, eoscale, eunscale, fnorm;
+  bool norms_ready = false;
   DevBuf feat;                     // [B][top...]
   DevBuf r0, r1, r2, r3, r4, r5;   // reverse scratch (per token)
   int encoded = 0;
@@ -107,6 +111,10 @@ struct ResNetEncoder {
     for (DevBuf* d : {&fa, &fb, &fc, &fz, &fsc, &fxs}) LRP_TRY(d->alloc(B * max_act * 4, total));
     LRP_TRY(act_max.alloc((units.size() + blocks.size()) * ACT_MAX_SLOTS * sizeof(unsigned), total));
     LRP_TRY(act_unscale.alloc(units.size() * sizeof(float), total));
+    LRP_TRY(eslots.alloc((units.size() + blocks.size()) * B * ACT_MAX_SLOTS * sizeof(unsigned), total));
+    LRP_TRY(eoscale.alloc(units.size() * B * sizeof(float), total));
+    LRP_TRY(eunscale.alloc(units.size() * B * sizeof(float), total));
+    LRP_TRY(fnorm.alloc(units.size() * 2 * sizeof(float), total));
     LRP_TRY(feat.alloc(B * (size_t)top_h * top_w * top_c * 4, total));
     const size_t max_tok = std::max(max_act, stem_hw * (size_t)std::max(RN_STEM_TCOLS, stem_c));
     for (DevBuf* d : {&r0, &r1, &r2, &r3, &r4, &r5}) LRP_TRY(d->alloc(NT * max_tok * 4, total));
@@ -162,6 +170,7 @@ struct ResNetEncoder {
         LRP_TRY(up(*dst[s], std::vector<float>(data, data + u.cout), total));
       }
       u.have[s] = true;
+      norms_ready = false;
       return LRP_OK;
     }
     return 1;
@@ -199,6 +208,7 @@ struct ResNetEncoder {
         LRP_HIP_CHECK(hipMemcpyAsync(dst[s]->p, data_dev, (size_t)u.cout * 4, hipMemcpyDeviceToDevice, st));
       }
       u.have[s] = true;
+      norms_ready = false;
       encoded = 0;                                       // caches belong to the old weights
       return LRP_OK;
     }
@@ -393,9 +403,142 @@ struct ResNetEncoder {
     return LRP_OK;
   }
 
+  // ---- round 4: no pass between two convs (kernels and the bounds behind the scales: resnet_kernels.h) ----
+  unsigned* eslots_unit(int ui) { return eslots.as<unsigned>() + (size_t)ui * max_images * ACT_MAX_SLOTS; }
+  unsigned* eslots_block(size_t bi) { return eslots.as<unsigned>() + (units.size() + bi) * max_images * ACT_MAX_SLOTS; }
+  float* eoscale_unit(int ui) { return eoscale.as<float>() + (size_t)ui * max_images; }
+  float* eunscale_unit(int ui) { return eunscale.as<float>() + (size_t)ui * max_images; }
+  float* fnorm_unit(int ui) { return fnorm.as<float>() + (size_t)ui * 2; }
+  static dim3 img_grid(size_t per_img_items, int B) {
+    size_t gx = (per_img_items + 255) / 256, cap = (size_t)std::max(1, 256 * 8 / B);
+    return dim3((unsigned)std::max<size_t>(1, std::min(gx, cap)), (unsigned)B);
+  }
+  // the whole network on the pair-emitting path: fp16-pair forward, every unit behind the stem with interleaved dual rows
+  // (cout % 32 == 0) and whole split8 groups on its input (cin % 8 == 0).  ResNet-50/101/152 qualify; LRP_FWD_EMIT=0 = round 3's path
+  bool emit_ok() const {
+    if (prec != PREC_BF16X3 || !sw().fwd_emit || (stem_c & 7)) return false;
+    for (size_t i = 1; i < units.size(); ++i)
+      if (!units[i].w_dual_h.p || !units[i].dual_il || (units[i].cin & 7)) return false;
+    return true;
+  }
+  int unit_norms(hipStream_t st) {
+    LRP_HIP_CHECK(hipMemsetAsync(fnorm.p, 0, fnorm.bytes, st));
+    for (size_t i = 1; i < units.size(); ++i) {
+      const RnUnit& u = units[i];
+      hipLaunchKernelGGL(rn_unit_norm_kernel, dim3(u.cout), dim3(256), 0, st, u.w_a.as<float>(), u.k * u.k * conv_cinp(u.cin),
+                         u.bias.as<float>(), u.gamma.as<float>(), u.beta.as<float>(), u.mean.as<float>(), u.var.as<float>(),
+                         RN_BN_EPS, fnorm_unit((int)i));
+    }
+    LRP_HIP_CHECK(hipGetLastError());
+    norms_ready = true;
+    return LRP_OK;
+  }
+  // conv + BN unit on pairs: x (pairs, scaled per image) -> gate, max-slots and EITHER the activation as the next conv's pairs
+  // (pairs_out: relu units inside a block; fp32 activation not written) OR the fp32 pre-Add tensor `act`
+  int unit_forward_emit(RnUnit& u, const float* xpairs, int B, float* act, float* pairs_out, hipStream_t st) {
+    const int ui = (int)(&u - units.data());
+    ConvArgs ca{};
+    ca.in = xpairs; ca.bias = u.bias.as<float>();
+    if (u.k == 3) { ca.NB = B; ca.H = u.Hout; ca.W = u.Wout; ca.taps = 9; }
+    else { ca.NB = B * u.Hout * u.Wout; ca.H = 1; ca.W = 1; ca.taps = 1; }
+    ca.Cin = u.cin; ca.CinP = conv_cinp(u.cin);
+    ca.wpk = u.w_dual_h.as<float>(); ca.N = 2 * u.cout; ca.split = u.cout; ca.dual_norelu = 1;
+    ca.in_unscale = eunscale_unit(ui);
+    ca.dual_il = 1; ca.dual_gate = 2; ca.bn_gamma = u.gamma.as<float>(); ca.bn_beta = u.beta.as<float>();
+    ca.bn_mean = u.mean.as<float>(); ca.bn_var = u.var.as<float>(); ca.bn_eps = RN_BN_EPS; ca.bn_relu = u.relu ? 1 : 0;
+    ca.out = act; ca.out2 = u.gate.as<float>();
+    ca.act_max_out = pairs_out ? (unsigned*)nullptr : eslots_unit(ui);      // measured maxima: the block end's two summands only
+    ca.scale_per_img = 1; ca.img_rows = u.Hout * u.Wout; ca.n_imgs = B;
+    if (pairs_out) { ca.pairs_out = pairs_out; ca.pairs_scale = eoscale_unit(ui); ca.skip_out = 1; }
+    LRP_HIP_CHECK(conv_launch(EPI_FWD_DUAL, ca, st, PREC_F16X2));
+    return LRP_OK;
+  }
+  int encode_emit(int B, hipStream_t st) {
+    if (!norms_ready) LRP_TRY(unit_norms(st));
+    LRP_HIP_CHECK(hipMemsetAsync(eslots.p, 0, eslots.bytes, st));
+    RnUnit& s = units[0];
+    auto scales_of = [&](const RnBlock& rb) {             // what the producer of rb's input derives for rb (resnet_kernels.h)
+      RnBlockScales S{};
+      S.norm1 = fnorm_unit(rb.u1); S.norm2 = fnorm_unit(rb.u2);
+      S.wsc1 = units[rb.u1].wds.as<float>(); S.wsc2 = units[rb.u2].wds.as<float>(); S.wsc3 = units[rb.u3].wds.as<float>();
+      S.wsc0 = rb.u0 >= 0 ? units[rb.u0].wds.as<float>() : (const float*)nullptr;
+      S.osc_t = eoscale_unit(rb.u3);                     // (slot of a tensor that is never written as pairs itself)
+      S.osc1 = eoscale_unit(rb.u1); S.osc2 = eoscale_unit(rb.u2);
+      S.us1 = eunscale_unit(rb.u1); S.us2 = eunscale_unit(rb.u2); S.us3 = eunscale_unit(rb.u3);
+      S.us0 = rb.u0 >= 0 ? eunscale_unit(rb.u0) : (float*)nullptr;
+      return S;
+    };
+    float* tp = fc.as<float>();                          // the block input as pairs (fc / fsc alternate)
+    float* tp_other = fsc.as<float>();
+    {  // stem: im2col -> two 1-tap GEMMs (fp32 MFMA) -> BN + relu + gate -> pool (+ pairs of the first block's input)
+      const size_t tot = (size_t)B * s.Hout * s.Wout * 2 * RN_STEM_K;
+      hipLaunchKernelGGL(rn_stem_im2col_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, images.as<float>(),
+                         stemA.as<float>(), B, img_h, img_w);
+      LRP_HIP_CHECK(hipGetLastError());
+      ConvArgs ca{};
+      ca.in = stemA.as<float>(); ca.NB = B * s.Hout * s.Wout; ca.H = 1; ca.W = 1; ca.Cin = 2 * RN_STEM_K; ca.CinP = 2 * RN_STEM_K;
+      ca.taps = 1; ca.N = s.cout; ca.bias = s.bias.as<float>();
+      ConvArgs cz = ca;
+      ca.wpk = s.w_a.as<float>(); ca.out = fa.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_BIAS, ca, st));
+      cz.wpk = s.w_z.as<float>(); cz.out = fz.as<float>();
+      LRP_HIP_CHECK(conv_launch(EPI_BIAS, cz, st));
+      const size_t per = s.out_elems();
+      hipLaunchKernelGGL(rn_bn_unit_img_kernel, img_grid(per, B), dim3(256), 0, st, fa.as<float>(), fz.as<float>(),
+                         s.gamma.as<float>(), s.beta.as<float>(), s.mean.as<float>(), s.var.as<float>(), RN_BN_EPS,
+                         a0.as<float>(), s.gate.as<float>(), q_stem.as<float>(), per, s.cout, 1, eslots_unit(0));
+      hipLaunchKernelGGL(rn_pool3_pairs_kernel, img_grid(per / 4 / 8, B), dim3(256), 0, st, a0.as<float>(), blocks[0].t_in.as<float>(),
+                         pool_win.as<unsigned char>(), tp, eslots_unit(0), scales_of(blocks[0]), s.Hout, s.Wout, s.cout);
+      LRP_HIP_CHECK(hipGetLastError());
+    }
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+      RnBlock& b = blocks[bi];
+      const float* t = b.t_in.as<float>();
+      const unsigned* ts = bi == 0 ? eslots_unit(0) : eslots_block(bi - 1);      // per-image maxima of the block input
+      const float* tin = tp;
+      if (b.stride == 2) {
+        // the walk multiplies with the fp32 sub-sampled input; the strided 1x1 convs read the same gather of the pairs
+        // (a pixel's pairs are as many bytes as its fp32 row)
+        const size_t n = (size_t)B * b.H * b.W * b.cin;
+        hipLaunchKernelGGL(rn_subsample2_kernel, dim3(stream_grid(n)), dim3(256), 0, st, t, b.t_sub.as<float>(), B, b.Hin, b.Win, b.cin);
+        hipLaunchKernelGGL(rn_subsample2_kernel, dim3(stream_grid(n)), dim3(256), 0, st, tp, fxs.as<float>(), B, b.Hin, b.Win, b.cin);
+        LRP_HIP_CHECK(hipGetLastError());
+        tin = fxs.as<float>();
+      }
+      RnUnit &u1 = units[b.u1], &u2 = units[b.u2], &u3 = units[b.u3];
+      const float* sc = t;
+      const unsigned* sc_slots = ts;
+      if (b.u0 >= 0) {                                   // (first: it reads the gathered pairs, which unit 2 overwrites)
+        LRP_TRY(unit_forward_emit(units[b.u0], tin, B, fb.as<float>(), nullptr, st));                   // fb = y0
+        sc = fb.as<float>();
+        sc_slots = eslots_unit(b.u0);
+      }
+      LRP_TRY(unit_forward_emit(u1, tin, B, nullptr, fz.as<float>(), st));                              // fz = pairs(a1)
+      LRP_TRY(unit_forward_emit(u2, fz.as<float>(), B, nullptr, fxs.as<float>(), st));                  // fxs = pairs(a2)
+      LRP_TRY(unit_forward_emit(u3, fxs.as<float>(), B, fa.as<float>(), nullptr, st));                  // fa = y3
+      const bool last = bi + 1 == blocks.size();
+      float* o = last ? feat.as<float>() : blocks[bi + 1].t_in.as<float>();
+      const size_t per8 = (size_t)b.H * b.W * 4 * b.f / 8;
+      hipLaunchKernelGGL(rn_block_out_pairs_kernel, img_grid(per8, B), dim3(256), 0, st, sc, fa.as<float>(), u3.gate.as<float>(),
+                         b.u0 >= 0 ? units[b.u0].gate.as<float>() : (const float*)nullptr, o, b.GA.as<float>(), b.GS.as<float>(), per8,
+                         last ? (unsigned*)nullptr : eslots_block(bi), last ? (float*)nullptr : tp_other, eslots_unit(b.u3), sc_slots,
+                         last ? RnBlockScales{} : scales_of(blocks[bi + 1]));
+      LRP_HIP_CHECK(hipGetLastError());
+      std::swap(tp, tp_other);
+    }
+    return LRP_OK;
+  }
+
   int encode(const float* images_dev, int B, hipStream_t st) {
     if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
     LRP_TRY(check_ready());
+    if (emit_ok()) {
+      LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, (size_t)B * img_h * img_w * 3 * 4, hipMemcpyDeviceToDevice, st));
+      LRP_TRY(encode_emit(B, st));
+      encoded = B;
+      features_only = false;
+      return LRP_OK;
+    }
     LRP_HIP_CHECK(hipMemcpyAsync(images.p, images_dev, (size_t)B * img_h * img_w * 3 * 4, hipMemcpyDeviceToDevice, st));
     LRP_HIP_CHECK(hipMemsetAsync(act_max.p, 0, act_max.bytes, st));
     RnUnit& s = units[0];
@@ -525,49 +668,57 @@ struct ResNetEncoder {
         std::swap(cur, other);
         continue;
       }
-      if (have_s3) {                       // (projection block after a fused identity block: its S3 is already there)
-        // fall through to the generic path, which recomputes S3 into r1; keep it simple and just ignore the fused copy
-        have_s3 = false;
-      }
-      // bf16x3 mode: the three convs of the main branch (and the projection) chain in split8 form; the products that
-      // enter a chain are written split, what leaves it for the add / scatter kernels is plain fp32
-      bool sp = prec == PREC_BF16X3;                     // split8 groups need channel counts % 8 == 0: exact fp32 otherwise
-      for (int ui : {b.u0, b.u1, b.u2, b.u3})
-        if (ui >= 0 && ((units[ui].cin | units[ui].cout) & 7)) sp = false;
-      auto head = [&](const float* G) {
+      // projection block (first of a stack).  bf16x3 mode: the three convs of the main branch and the projection chain in
+      // split8 form; the products that enter a chain are written split, what leaves it for the join is plain fp32
+      const bool sp = block_split(b);                    // split8 groups need channel counts % 8 == 0: exact fp32 otherwise
+      auto head = [&](const float* G, float* dst) {
         if (sp)
           hipLaunchKernelGGL(rn_mul_gate_split_kernel, dim3(stream_grid((size_t)n * per_o / 8)), dim3(256), 0, st, Ro, G, row2img,
-                             r1.as<float>(), n, per_o / 8);
+                             dst, n, per_o / 8);
         else
           hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, G, row2img,
-                             (const float*)nullptr, r1.as<float>(), n, per_o);
+                             (const float*)nullptr, dst, n, per_o);
       };
-      head(b.GA.as<float>());                            // S3 = R_o * (fA Q3)
-      LRP_HIP_CHECK(hipGetLastError());
-      LRP_TRY(unit_backward(units[b.u3], n, row2img, r1.as<float>(), units[b.u2].gate.as<float>(), r2.as<float>(), st, sp, !sp));  // S2
-      LRP_TRY(unit_backward(units[b.u2], n, row2img, r2.as<float>(), units[b.u1].gate.as<float>(), r1.as<float>(), st, sp, !sp));  // S1
-      const float* taux = b.stride == 2 ? b.t_sub.as<float>() : b.t_in.as<float>();
-      LRP_TRY(unit_backward(units[b.u1], n, row2img, r1.as<float>(), taux, r2.as<float>(), st, sp, true));               // t*C1 (coarse)
-      const size_t per_c = (size_t)b.H * b.W * b.cin;          // coarse (= fine when stride 1)
-      if (b.u0 >= 0) {
-        head(b.GS.as<float>());                                                                                           // S0
-        LRP_HIP_CHECK(hipGetLastError());
-        LRP_TRY(unit_backward(units[b.u0], n, row2img, r1.as<float>(), taux, r3.as<float>(), st, sp, true));              // t*C0
-        if (b.stride == 2) {
-          const size_t tot = (size_t)n * b.Hin * b.Win * b.cin;
-          hipLaunchKernelGGL(rn_scatter2_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur, n,
-                             b.Hin, b.Win, b.cin);
-        } else {
-          hipLaunchKernelGGL(rn_add_kernel, dim3(stream_grid((size_t)n * per_c)), dim3(256), 0, st, r2.as<float>(),
-                             r3.as<float>(), cur, (size_t)n * per_c);
-        }
-        LRP_HIP_CHECK(hipGetLastError());
-      } else {
-        // identity shortcut (stride 1, cin == 4f): R_t = t*C1 + R_o * fS
-        hipLaunchKernelGGL(rn_mul_gate_kernel, dim3(stream_grid((size_t)n * per_o)), dim3(256), 0, st, Ro, b.GS.as<float>(),
-                           row2img, r2.as<float>(), cur, n, per_o);
+      // S3 = R_o * (fA Q3): already written by the epilogue of the identity block walked before this one (same operand
+      // format: have_s3 is only set then) — round 3 recomputed it here, one pass over R_o per stack for nothing
+      float* A = s3;                                     // r1 / r5: S3, later free
+      float* Bf = s3_other;                              // the other one: S1, then S0
+      if (!have_s3) {
+        head(b.GA.as<float>(), A);
         LRP_HIP_CHECK(hipGetLastError());
       }
+      LRP_TRY(unit_backward(units[b.u3], n, row2img, A, units[b.u2].gate.as<float>(), r2.as<float>(), st, sp, !sp));              // S2
+      LRP_TRY(unit_backward(units[b.u2], n, row2img, r2.as<float>(), units[b.u1].gate.as<float>(), Bf, st, sp, !sp));              // S1
+      const float* taux = b.stride == 2 ? b.t_sub.as<float>() : b.t_in.as<float>();
+      LRP_TRY(unit_backward(units[b.u1], n, row2img, Bf, taux, r2.as<float>(), st, sp, true));                                    // t*C1 (coarse)
+      head(b.GS.as<float>(), Bf);                                                                                                  // S0
+      LRP_HIP_CHECK(hipGetLastError());
+      LRP_TRY(unit_backward(units[b.u0], n, row2img, Bf, taux, r3.as<float>(), st, sp, true));                                    // t*C0
+      // join: R_t = t*C1 + t*C0 (scattered to the even positions behind a stride-2 block) and — one pass — the head of the
+      // block walked next, S3' = R_t * GA' (an identity block: the last of the stack below)
+      have_s3 = false;
+      const bool fuse_next = sp && bi > 0 && blocks[bi - 1].u0 < 0 && block_split(blocks[bi - 1]) && !(b.cin & 7);
+      if (sp && !(b.cin & 7)) {
+        const size_t tot8 = (size_t)n * b.Hin * b.Win * b.cin / 8;
+        const float* g2 = fuse_next ? blocks[bi - 1].GA.as<float>() : (const float*)nullptr;
+        float* o2 = fuse_next ? A : (float*)nullptr;
+        if (b.stride == 2)
+          hipLaunchKernelGGL(rn_join_split_kernel<true>, dim3(stream_grid(tot8)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur,
+                             g2, row2img, o2, n, b.Hin, b.Win, b.cin);
+        else
+          hipLaunchKernelGGL(rn_join_split_kernel<false>, dim3(stream_grid(tot8)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur,
+                             g2, row2img, o2, n, b.Hin, b.Win, b.cin);
+        if (fuse_next) { s3 = A; s3_other = Bf; have_s3 = true; }
+      } else if (b.stride == 2) {
+        const size_t tot = (size_t)n * b.Hin * b.Win * b.cin;
+        hipLaunchKernelGGL(rn_scatter2_kernel, dim3(stream_grid(tot)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur, n,
+                           b.Hin, b.Win, b.cin);
+      } else {
+        const size_t per_c = (size_t)b.H * b.W * b.cin;
+        hipLaunchKernelGGL(rn_add_kernel, dim3(stream_grid((size_t)n * per_c)), dim3(256), 0, st, r2.as<float>(), r3.as<float>(), cur,
+                           (size_t)n * per_c);
+      }
+      LRP_HIP_CHECK(hipGetLastError());
       Ro = cur;
       std::swap(cur, other);
     }

@@ -75,6 +75,147 @@ __global__ __launch_bounds__(256) void rn_block_out_kernel(const float* __restri
   if (max_slots) rn_flush_max(m, max_slots);
 }
 
+// ---- round 4: the fp16-pair forward without passes between the convs (the VGG encoder's round-3 design) ----
+// Every conv unit's epilogue writes its activation as the NEXT conv's operand (pairs scaled by a power of two); the block-end
+// kernel and the stem's pool do the same for the block inputs.  A producer's scale has to be known before it runs, so it
+// comes from a bound, and the bounds of a whole bottleneck block hang on ONE measured quantity — the maximum of the block's
+// input, per image (an image's result does not depend on its batch mates):
+//   block input t:   |sc + y3| <= max|sc| + max|y3|  (both measured: the producing convs raise max-slots; within 2x of the true
+//                    maximum)                         stem pool: max of the pooled map = max of the map (measured)
+//   conv + BN unit:  |y_c| <= |gamma_c| / sd_c * (max|x| * sum_k |w_c[k]| + |b_c - mean_c|) + |beta_c|   ->  norm = {A, B},
+//                    bound(a1) = bound(t) * A1 + B1,  bound(a2) = bound(a1) * A2 + B2     (rn_unit_norm_kernel; relu(y) <= |y|)
+// so the kernel that PRODUCES a block input derives every scale of the block that reads it (RnBlockScales below) and no scale
+// launch runs between the convs.  [MI355X: as one tiny launch in front of every producer, 99 per encode, they cost 0.49 of the
+// 1.30 ms the split passes had cost.]  The bounds overshoot — a row sum against a typical dot product: 20-100x per level, two
+// levels deep, then the next block starts from a measured maximum again — and what an overshoot costs is the fp16 subnormal floor
+// moving up: absolute error <= 2^-25 * overshoot / 30000 of the tensor's maximum (cnn_kernels.h, fwd_scale_kernel), 1e-8 at 10^4.
+struct RnBlockScales {
+  const float* norm1; const float* norm2;                // {A, B} of the reading block's units 1 and 2
+  const float* wsc1; const float* wsc0; const float* wsc2; const float* wsc3;   // weight scale records of its units (wsc0: projection or null)
+  float* osc_t; float* osc1; float* osc2;                // [images] pair scales: block input, a1, a2
+  float* us1; float* us0; float* us2; float* us3;        // [images] input unscales of units 1, 0 (or null), 2, 3
+};
+__device__ __forceinline__ int rn_pow2_scale(float bound) {   // k with bound * 2^k in (15000, 30000]
+  int k = 0;
+  if (bound > 0.f && bound < 3.0e38f) {
+    k = (int)floorf(log2f(30000.f / bound));
+    k = k < -120 ? -120 : k > 120 ? 120 : k;
+  }
+  return k;
+}
+// every thread of the block calls it: returns the pair scale of the block input of image n (bound_t from the image's slots:
+// max(slotsA) + max(slotsB)); `write`: this thread also stores the derived scales of the reading block
+__device__ __forceinline__ float rn_block_scales(const unsigned* __restrict__ slotsA, const unsigned* __restrict__ slotsB, int n,
+                                                 const RnBlockScales& S, bool write) {
+  const int l = threadIdx.x & (ACT_MAX_SLOTS - 1);
+  float m = __uint_as_float(slotsA[(size_t)n * ACT_MAX_SLOTS + l]);
+  float mb = slotsB ? __uint_as_float(slotsB[(size_t)n * ACT_MAX_SLOTS + l]) : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o));
+    mb = fmaxf(mb, __shfl_xor(mb, o));
+  }
+  const float bt = m + mb;
+  const int kt = rn_pow2_scale(bt);
+  if (write) {
+    const float b1 = bt * S.norm1[0] + S.norm1[1];
+    const float b2 = b1 * S.norm2[0] + S.norm2[1];
+    const int k1 = rn_pow2_scale(b1), k2 = rn_pow2_scale(b2);
+    S.osc_t[n] = ldexpf(1.f, kt); S.osc1[n] = ldexpf(1.f, k1); S.osc2[n] = ldexpf(1.f, k2);
+    S.us1[n] = ldexpf(1.f, -kt) * S.wsc1[1];
+    if (S.us0) S.us0[n] = ldexpf(1.f, -kt) * S.wsc0[1];
+    S.us2[n] = ldexpf(1.f, -k1) * S.wsc2[1];
+    S.us3[n] = ldexpf(1.f, -k2) * S.wsc3[1];
+  }
+  return ldexpf(1.f, kt);
+}
+// norm = {A, B} of a conv + BN unit (above); w = the unit's packed forward matrix [rows >= cout][K] (zero padded), one block
+// per output channel; norm zeroed before (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void rn_unit_norm_kernel(const float* __restrict__ w, int K, const float* __restrict__ b,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ mean, const float* __restrict__ var,
+                                                           float bn_eps, float* __restrict__ norm) {
+  __shared__ float red[256];
+  const int c = blockIdx.x;
+  const float* r = w + (size_t)c * K;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += fabsf(r[k]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float g = fabsf(gamma[c]) / sqrtf(var[c] + bn_eps);
+    atomicMax(reinterpret_cast<unsigned*>(norm), __float_as_uint(g * red[0] * 1.0001f));
+    atomicMax(reinterpret_cast<unsigned*>(norm) + 1, __float_as_uint((g * fabsf(b[c] - mean[c]) + fabsf(beta[c])) * 1.0001f));
+  }
+}
+// rn_bn_unit_kernel per image: grid (blocks per image, images), max|act| into slots[image][ACT_MAX_SLOTS]  (the stem)
+__global__ __launch_bounds__(256) void rn_bn_unit_img_kernel(const float* __restrict__ c, const float* __restrict__ Z,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             float bn_eps, float* __restrict__ act, float* __restrict__ gate,
+                                                             float* __restrict__ qonly, size_t per_img, int C, int relu,
+                                                             unsigned* __restrict__ slots) {
+  const size_t base = (size_t)blockIdx.y * per_img;
+  float m = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per_img; e += (size_t)gridDim.x * 256) {
+    const size_t i = base + e;
+    const int ch = (int)(e % C);
+    const float cv = c[i], mu = mean[ch], bt = beta[ch];
+    const float y = gamma[ch] * (cv - mu) / sqrtf(var[ch] + bn_eps) + bt;
+    const float q = (cv * (y - bt)) / safe_den(stab_sign((cv - mu) * y)) / safe_den(Z[i]);
+    const float av = relu ? fmaxf(y, 0.f) : y;
+    act[i] = av;
+    m = fmaxf(m, fabsf(av));
+    gate[i] = relu ? av * q : q;
+    if (qonly) qonly[i] = q;
+  }
+  rn_flush_max(m, slots + (size_t)blockIdx.y * ACT_MAX_SLOTS);
+}
+// rn_block_out_kernel per image, eight channels per thread, and the block output also as the next block's fp16 pairs, with the
+// scales of that block derived here (rn_block_scales: slots_y3 / slots_sc = the max-slots of the two summands); grid (blocks
+// per image, images); slots_out raised to max(o).  Last block of the network: pairs == nullptr, nothing but o / GA / GS.
+__global__ __launch_bounds__(256) void rn_block_out_pairs_kernel(const float* __restrict__ sc, const float* __restrict__ y3,
+                                                                 const float* __restrict__ Q3, const float* __restrict__ Q0,
+                                                                 float* __restrict__ o, float* __restrict__ GA, float* __restrict__ GS,
+                                                                 size_t per_img8, unsigned* __restrict__ slots_out,
+                                                                 float* __restrict__ pairs, const unsigned* __restrict__ slots_y3,
+                                                                 const unsigned* __restrict__ slots_sc, RnBlockScales S) {
+  const int n = blockIdx.y;
+  const size_t base = (size_t)n * per_img8;
+  const float ps = pairs ? rn_block_scales(slots_y3, slots_sc, n, S, blockIdx.x == 0 && threadIdx.x == 0) : 1.f;
+  float m = 0.f;
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per_img8; e += (size_t)gridDim.x * 256) {
+    const size_t i = (base + e) * 8;
+    float ov[8];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const f32x4 s = *reinterpret_cast<const f32x4*>(sc + i + 4 * g), y = *reinterpret_cast<const f32x4*>(y3 + i + 4 * g);
+      const f32x4 q3 = *reinterpret_cast<const f32x4*>(Q3 + i + 4 * g);
+      f32x4 q0 = {1.f, 1.f, 1.f, 1.f};
+      if (Q0) q0 = *reinterpret_cast<const f32x4*>(Q0 + i + 4 * g);
+      f32x4 o4, ga, gs;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float den = safe_den(s[q] + y[q]);
+        o4[q] = fmaxf(s[q] + y[q], 0.f);
+        m = fmaxf(m, s[q] + y[q]);
+        ga[q] = y[q] / den * q3[q];
+        gs[q] = Q0 ? s[q] / den * q0[q] : s[q] / den;
+        ov[4 * g + q] = o4[q] * ps;
+      }
+      *reinterpret_cast<f32x4*>(o + i + 4 * g) = o4;
+      *reinterpret_cast<f32x4*>(GA + i + 4 * g) = ga;
+      *reinterpret_cast<f32x4*>(GS + i + 4 * g) = gs;
+    }
+    if (pairs) split8h_store(ov, pairs + i);
+  }
+  if (slots_out) rn_flush_max(m, slots_out + (size_t)n * ACT_MAX_SLOTS);
+}
+
 // the same product written in the split-bf16 operand format of the conv kernel (8 channels per thread; head of a
 // conv chain in the bf16x3 mode)
 __global__ __launch_bounds__(256) void rn_mul_gate_split_kernel(const float* __restrict__ R, const float* __restrict__ G,
@@ -154,6 +295,48 @@ __global__ __launch_bounds__(256) void rn_scatter2_kernel(const float* __restric
   }
 }
 
+// End of a projection block's walk in ONE pass (bf16x3 chains, C % 8 == 0; eight channels per thread):
+//   fine = a + b   (SCATTER: at the even positions of the stride-2 grid, zeros elsewhere — the two kernels above in one)
+//   out2s = split8(fine * G2[img])   (optional: S3 = R_t * GA of the block walked NEXT, which would otherwise re-read R_t)
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void rn_join_split_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            float* __restrict__ fine, const float* __restrict__ G2,
+                                                            const int* __restrict__ row2img, float* __restrict__ out2s, int NB,
+                                                            int H, int W, int C) {
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2, C8 = C / 8;
+  const size_t total = (size_t)NB * H * W * C8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8;
+    size_t r = i / C8;
+    const int w = (int)(r % W);
+    r /= W;
+    const int h = (int)(r % H);
+    const int n = (int)(r / H);
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 0.f;
+    if (!SCATTER || (!(h & 1) && !(w & 1))) {
+      const size_t j = SCATTER ? (((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c : i * 8;
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const f32x4 s = *reinterpret_cast<const f32x4*>(a + j + 4 * g) + *reinterpret_cast<const f32x4*>(b + j + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[4 * g + q] = s[q];
+      }
+    }
+    *reinterpret_cast<f32x4*>(fine + i * 8) = *reinterpret_cast<const f32x4*>(v);
+    *reinterpret_cast<f32x4*>(fine + i * 8 + 4) = *reinterpret_cast<const f32x4*>(v + 4);
+    if (out2s) {
+      const int img = row2img ? row2img[n] : n;
+      const float* g2 = G2 + (((size_t)img * H + h) * W + w) * C + c;
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(g2), g1 = *reinterpret_cast<const f32x4*>(g2 + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] *= g0[q]; v[4 + q] *= g1[q]; }
+      split8_store(v, out2s + i * 8);
+    }
+  }
+}
+
 // 3x3/2 max-pool on the 1-padded map (ZeroPadding2D(1) + MaxPooling2D(3, 2, 'valid')):  a (H,W) -> (H/2, W/2)
 __device__ __forceinline__ float rn_padded_at(const float* __restrict__ a, int n, int i, int j, int c, int H, int W, int C) {
   return (i >= 0 && i < H && j >= 0 && j < W) ? a[(((size_t)n * H + i) * W + j) * C + c] : 0.f;   // zero padding is a candidate
@@ -180,6 +363,53 @@ __global__ __launch_bounds__(256) void rn_pool3_kernel(const float* __restrict__
       }
     out[i] = m;
     win[i] = (unsigned char)arg;
+  }
+}
+
+// the same pool, eight channels per thread, its output also as the first block's fp16 pairs, that block's scales derived here
+// from the stem activation's max-slots (rn_block_scales); grid (blocks per image, images).  (a >= 0 behind the stem's ReLU, so the zero padding never wins over a positive value and
+// ties with it resolve in scan order like above.)
+__global__ __launch_bounds__(256) void rn_pool3_pairs_kernel(const float* __restrict__ a, float* __restrict__ out,
+                                                             unsigned char* __restrict__ win, float* __restrict__ pairs,
+                                                             const unsigned* __restrict__ slots_a, RnBlockScales S, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C8 = C / 8, n = blockIdx.y;
+  const size_t per_img8 = (size_t)Ho * Wo * C8;
+  const float ps = rn_block_scales(slots_a, nullptr, n, S, blockIdx.x == 0 && threadIdx.x == 0);
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < per_img8; e += (size_t)gridDim.x * 256) {
+    const int c = (int)(e % C8) * 8;
+    size_t r = e / C8;
+    const int ow = (int)(r % Wo);
+    const int oh = (int)(r / Wo);
+    float m[8];
+    unsigned arg[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { m[q] = -INFINITY; arg[q] = 0; }
+    for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) {
+        const int i = 2 * oh + kh - 1, j = 2 * ow + kw - 1;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = 0.f;                                 // zero padding is a candidate
+        if (i >= 0 && i < H && j >= 0 && j < W) {
+          const float* p = a + (((size_t)n * H + i) * W + j) * C + c;
+          *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(p);
+          *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (v[q] > m[q]) { m[q] = v[q]; arg[q] = (unsigned)(kh * 3 + kw); }
+      }
+    const size_t o = ((size_t)n * per_img8 + e) * 8;
+    *reinterpret_cast<f32x4*>(out + o) = *reinterpret_cast<const f32x4*>(m);
+    *reinterpret_cast<f32x4*>(out + o + 4) = *reinterpret_cast<const f32x4*>(m + 4);
+    typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
+    u32x2p w8;
+    w8[0] = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+    w8[1] = arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24);
+    *reinterpret_cast<u32x2p*>(win + o) = w8;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] *= ps;
+    split8h_store(m, pairs + o);
   }
 }
 

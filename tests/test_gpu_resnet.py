@@ -71,6 +71,49 @@ def test_resnet101_full_size_matches_oracle(prec):
     assert max(errs) < TOL, errs
 
 
+def test_pair_emitting_forward_matches_oracle_is_batch_invariant_and_has_a_fallback():
+    """Round 4's ResNet forward (resnet_encoder.h encode_emit: every unit's epilogue writes the next conv's fp16 pairs, the block-end
+    kernel and the stem's pool the block inputs', scales per image from bounds on measured maxima) on a network whose every
+    unit qualifies (widths % 32 == 0: two stacks, a stride-1 and a stride-2 projection block, identity blocks, 3 images):
+    features and heat-maps vs the float64 oracle; an image alone == the same image inside the batch, bit for bit (what the
+    per-call scales of round 3 could not give); LRP_FWD_EMIT=0 (split passes between the convs) agrees to the forward's rounding;
+    the walk's projection-block path (S3 from the previous epilogue, join + next head in one pass) is the same arithmetic."""
+    import torch
+    from lrp_imagecaptioning_amd.engine import switches
+    stacks, stem, hw, B = ((32, 3), (64, 2)), 32, 64, 3
+    rs = np.random.RandomState(12)
+    w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
+    spec = RN.resnet_spec(stacks, stem=stem)
+    X = rs.uniform(-120, 130, size=(B, hw, hw, 3)).astype(np.float32)
+    X[2] *= 0.01                                           # an image 100x dimmer than its batch mates
+    eng, side, D = _engine(stacks, stem, hw, B, 2 * B, w)
+    one, _, _ = _engine(stacks, stem, hw, 1, 2, w)
+    feat_ref = RN.forward(w, spec, X)
+    idx = [0, 1, 2, 2, 1, 0]
+    R = (rs.standard_normal((2 * B,) + feat_ref.shape[1:]) * feat_ref[idx]).astype(np.float32)
+    ref = RN.analyze(w, spec, X[idx], R)
+
+    def run(e, Xs, ix, Rs):
+        e.encode_images(Xs)
+        return e.get_features().clone(), e.cnn_explain(ix, Rs).clone()
+    feat, out = run(eng, X, idx, R)
+    e_feat = rel_l1(feat.cpu().numpy().reshape(feat_ref.shape), feat_ref)
+    errs = [rel_l1(out[i].cpu().numpy(), ref[i]) for i in range(2 * B)]
+    for n in range(B):                                     # batch invariance
+        rows = [i for i in range(2 * B) if idx[i] == n]
+        f1, o1 = run(one, X[n:n + 1], [0, 0], R[rows])
+        assert torch.equal(f1[0], feat[n]), n
+        assert torch.equal(o1, out[rows]), n
+    with switches(LRP_FWD_EMIT=0):
+        feat0, out0 = run(eng, X, idx, R)
+    e_fb = float((feat0.double() - feat.double()).abs().sum() / feat.double().abs().sum())
+    e_fb_hm = max(rel_l1(out0[i].cpu().numpy(), out[i].cpu().numpy()) for i in range(2 * B))
+    report("resnet_emit", feat_rel_l1=e_feat, max_rel_l1=max(errs), fallback_feat=e_fb, fallback_heatmaps=e_fb_hm)
+    assert e_feat < 1e-5
+    assert max(errs) < TOL, errs
+    assert e_fb < 1e-5 and e_fb_hm < 2e-5
+
+
 def test_config4_gridtd_plus_resnet_end_to_end():
     """grid-TD decoder on a ResNet encoder (BASELINE config 4 at reduced size): decoder LRP -> CNN LRP fused call."""
     stacks, stem, hw, H, V = ((4, 2), (8, 2)), 8, 32, 32, 50
