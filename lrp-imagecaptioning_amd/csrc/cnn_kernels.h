@@ -364,6 +364,37 @@ __global__ __launch_bounds__(256) void pool_gate_split_kernel(const float* a, co
     }
   }
 }
+// the full-resolution pool gate from its compact form (one value per window and channel + its position byte): what the fused
+// pool epilogue of the forward conv (conv_igemm.h ConvArgs::pool_gc) leaves for the walks that read the expanded interface —
+// the gradient baselines, the fp32 / fast modes, LRP_UP2_COMPACT=0 — built on their first use after an encode.  8 channels per thread.
+__global__ __launch_bounds__(256) void pool_gate_expand_kernel(const float* __restrict__ gc, const unsigned char* __restrict__ gpos,
+                                                               float* __restrict__ g, int NB, int H, int W, int C) {
+  const int C8 = C >> 3, Ho = H >> 1, Wo = W >> 1;
+  const size_t total = (size_t)NB * Ho * Wo * C8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    size_t r = i / C8;
+    const int wo = (int)(r % Wo);
+    r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    const size_t po = (((size_t)n * Ho + ho) * Wo + wo) * C + 8 * c8;
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(gc + po);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(gc + po + 4);
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ pv = *reinterpret_cast<const u32x2_*>(gpos + po);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float o[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o[c] = ((pv[c >> 2] >> (8 * (c & 3))) & 0xFFu) == (unsigned)p ? v[c] : 0.f;
+      float* dst = g + ((((size_t)n * H + 2 * ho + (p >> 1)) * W + 2 * wo + (p & 1)) * C) + 8 * c8;
+      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(o);
+      *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(o + 4);
+    }
+  }
+}
 // max|x| of a tensor into ACT_MAX_SLOTS slots (the image layer's activations come from the fp32 kernel, which keeps no maximum)
 __global__ __launch_bounds__(256) void absmax_slots_kernel(const f32x4* __restrict__ x, size_t n4, unsigned* __restrict__ slots) {
   float m = 0.f;

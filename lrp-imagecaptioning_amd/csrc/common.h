@@ -46,6 +46,7 @@ struct Switches {
   int img_fold = 1;         // LRP_IMG_FOLD=0      image layer as its own launch
   int dec_batched = 1;      // LRP_DEC_BATCHED=0   decoder LRP: one workgroup per unit instead of the step-synchronous scan
   int dec_mfma_fwd = 1;     // LRP_DEC_MFMA_FWD=0  decoder forward: VALU skinny GEMMs
+  int pool_fused = 1;       // LRP_POOL_FUSED=0    forward: max-pool + gate + pooled pairs as a pass of their own behind the conv
   int sparse_pool = 0;      // LRP_SPARSE_POOL=1   pooled boundaries with >= 256 output columns on the 2:4-sparse matrix cores (conv_sparse.h); read by encode and explain
   void load() {
     *this = Switches();
@@ -54,7 +55,7 @@ struct Switches {
     rd("LRP_CONV_MID", conv_mid); rd("LRP_EPI_FAST", epi_fast); rd("LRP_UP2_PW", up2_pw); rd("LRP_TILE_ORDER", tile_order);
     rd("LRP_FWD_EMIT", fwd_emit); rd("LRP_FWD_IL", fwd_il); rd("LRP_IMG_FUSED", img_fused); rd("LRP_UP2_COMPACT", up2_compact);
     rd("LRP_UP2_GC", up2_gc); rd("LRP_UP2_BREG_PAIRS", up2_breg_pairs); rd("LRP_IMG_FOLD", img_fold); rd("LRP_DEC_BATCHED", dec_batched);
-    rd("LRP_DEC_MFMA_FWD", dec_mfma_fwd); rd("LRP_SPARSE_POOL", sparse_pool);
+    rd("LRP_DEC_MFMA_FWD", dec_mfma_fwd); rd("LRP_SPARSE_POOL", sparse_pool); rd("LRP_POOL_FUSED", pool_fused);
   }
 };
 inline Switches& sw() {

@@ -235,6 +235,18 @@ struct ConvArgs {
   // image rows for every token.  Tile row R of the launch covers token R / tpt, image rows (R % tpt) * th ...
   int tpt;
   int epi_generic;             // MUL / MUL_UP2 epilogues: 1 = always the general pass loop (A/B switch LRP_EPI_FAST=0; filled by the launcher)
+  // 2x2 max-pool fused into the interleaved dual forward's epilogue (PREC_F16X2, 128 x 128 resident-image tile: the whole C
+  // tile is in LDS; tiles of an EVEN number of rows and columns starting at even positions, so a window never straddles two
+  // tiles): per window and channel the epilogue takes the first maximum in scan order, and writes — instead of a_l and Z+_l
+  // at full resolution, which a streaming pass then read back (cnn_kernels.h pool_gate_split_kernel: the same arithmetic) —
+  //   pool_gc   [images][H/2][W/2][C]   the gate a_l / safe(Z+_l) at the winning position (IL:456-458 through the pool)
+  //   pool_pos  same shape, bytes        that position, 2 dy + dx
+  //   pairs_out [images][H/2][W/2][C]   the pooled activation as the next conv's fp16 pairs (x pairs_scale[image])
+  //   pool_x    (optional) the pooled activation in fp32
+  // and raises act_max_out from the pooled values.  The full-resolution gate is rebuilt from (pool_gc, pool_pos) on demand.
+  float* pool_gc;
+  unsigned char* pool_pos;
+  float* pool_x;
 };
 constexpr int ACT_MAX_SLOTS = 64;
 
@@ -1333,7 +1345,98 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
           // Z+ of the same channels.  The two threads that own a channel quad (one per block) share its rows by parity.
           const int p = c4 * 4, half = (p >> 5) & 1;
           const int ch = (n0 >> 1) + (p >> 6) * 32 + (p & 31);
-          if (ch < a.split) {
+          bool pooled = false;
+          if constexpr (HALO && NH == 1 && PREC == PREC_F16X2) {
+            if (a.pool_gc) {
+              // ---- fused 2x2 max-pool (ConvArgs::pool_gc): item = (window of the tile, channel quad)
+              pooled = true;
+              const int wpr = a.tw >> 1, nq = BN / 8;     // windows per tile row; channel quads of the tile's c columns
+              const int nitems = (a.th >> 1) * wpr * nq;
+              const float inv_wpr = 1.0f / (float)wpr;
+              float pmax0 = 0.f, pmax1 = 0.f;
+              for (int it = tid; it < nitems; it += NT) {
+                const int q = it % nq, win = it / nq;
+                int wy, wx;
+                divmod(win, wpr, inv_wpr, wy, wx);
+                const int cq = 4 * q, chp = (n0 >> 1) + cq, pcp = (cq >> 5) * 64 + (cq & 31);
+                const int r00 = (2 * wy) * a.tw + 2 * wx;
+                int row = 0, n_ = 0, h_ = 0, w_ = 0;
+                const bool ok = locate(r00, row, n_, h_, w_) && chp < a.split;
+                const int rel = a.scale_per_img ? n_ - simg0 : 0;
+                float unscale = rel == 0 ? us0 : us1, pscale = rel == 0 ? ps0 : ps1;
+                if (ok && rel > 1) { unscale = a.in_unscale[simg0 + rel]; pscale = a.pairs_scale[simg0 + rel]; }
+                f32x4 bvp = {0.f, 0.f, 0.f, 0.f};
+                if (ok) bvp = *reinterpret_cast<const f32x4*>(a.bias + chp);
+                f32x4 mx, zx;
+                unsigned posw = 0u;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                  const float* cr = Cs + (r00 + (pp >> 1) * a.tw + (pp & 1)) * BN + pcp;
+                  f32x4 vc = *reinterpret_cast<const f32x4*>(cr), vz = *reinterpret_cast<const f32x4*>(cr + 32);
+                  vc *= unscale; vz *= unscale;
+                  vc += bvp; vz += bvp;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float av = a.dual_norelu ? vc[e] : fmaxf(vc[e], 0.f);
+                    if (pp == 0 || av > mx[e]) {           // first maximum in scan order (what tf.gradients routes to)
+                      mx[e] = av; zx[e] = vz[e];
+                      posw = (posw & ~(0xFFu << (8 * e))) | ((unsigned)pp << (8 * e));
+                    }
+                  }
+                }
+                f32x4 gq;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gq[e] = mx[e] / (zx[e] + (zx[e] == 0.f ? 1e-7f : 0.f));
+                if (ok) {
+                  const size_t po = (((size_t)n_ * (a.H >> 1) + (h_ >> 1)) * (a.W >> 1) + (w_ >> 1)) * a.split + chp;
+                  *reinterpret_cast<f32x4*>(a.pool_gc + po) = gq;
+                  *reinterpret_cast<unsigned*>(a.pool_pos + po) = posw;
+                  if (a.pool_x) *reinterpret_cast<f32x4*>(a.pool_x + po) = mx;
+                  const float m4 = fmaxf(fmaxf(fabsf(mx[0]), fabsf(mx[1])), fmaxf(fabsf(mx[2]), fabsf(mx[3])));
+                  if (rel == 0) pmax0 = fmaxf(pmax0, m4);
+                  else if (rel == 1) pmax1 = fmaxf(pmax1, m4);
+                  else if (m4 > 0.f && a.act_max_out) atomicMax(a.act_max_out + (size_t)(simg0 + rel) * ACT_MAX_SLOTS + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1)), __float_as_uint(m4));
+                }
+                {
+                  // pairs of the pooled activation: the two lanes of a split8 group (quads q, q ^ 1: neighbouring items of the
+                  // same window) swap halves and store 16 B each, as in the unpooled epilogue below
+                  typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                  f16x4 hi, lo;
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float sv = mx[e] * pscale;
+                    hi[e] = (_Float16)sv;
+                    lo[e] = (_Float16)(sv - (float)hi[e]);
+                  }
+                  const bool odd = q & 1;
+                  const u32x2 mine = __builtin_bit_cast(u32x2, odd ? lo : hi);
+                  const u32x2 give = __builtin_bit_cast(u32x2, odd ? hi : lo);
+                  u32x2 got;
+                  got[0] = __shfl_xor(give[0], 1);
+                  got[1] = __shfl_xor(give[1], 1);
+                  u32x4 v16;
+                  v16[0] = odd ? got[0] : mine[0]; v16[1] = odd ? got[1] : mine[1];
+                  v16[2] = odd ? mine[0] : got[0]; v16[3] = odd ? mine[1] : got[1];
+                  if (ok) {
+                    const size_t po = (((size_t)n_ * (a.H >> 1) + (h_ >> 1)) * (a.W >> 1) + (w_ >> 1)) * a.split + (chp & ~7);
+                    *reinterpret_cast<u32x4*>(a.pairs_out + po + (odd ? 4 : 0)) = v16;
+                  }
+                }
+              }
+              if (a.act_max_out) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                  pmax0 = fmaxf(pmax0, __shfl_xor(pmax0, o));
+                  pmax1 = fmaxf(pmax1, __shfl_xor(pmax1, o));
+                }
+                unsigned* ms = a.act_max_out + (size_t)simg0 * ACT_MAX_SLOTS + ((blockIdx.x + wave) & (ACT_MAX_SLOTS - 1));
+                if (lane == 0 && pmax0 > 0.f) atomicMax(ms, __float_as_uint(pmax0));
+                if (lane == 0 && pmax1 > 0.f) atomicMax(ms + ACT_MAX_SLOTS, __float_as_uint(pmax1));
+              }
+            }
+          }
+          if (!pooled && ch < a.split) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const int pc = (p & ~63) + (p & 31);          // the c column of the pair; Z+ sits 32 further
             // running max|a_l| of this thread's rows of images simg0 .. simg0 + 3 (a tile spans more than two images where an
@@ -1747,6 +1850,21 @@ inline float conv_halo_geom(int BM, int H, int W, int& tw, int& th, int& hrows) 
   return best;
 }
 
+// ... with an even number of rows and columns (ConvArgs::pool_gc: 2x2 windows never straddle two tiles)
+inline float conv_halo_geom_even(int BM, int H, int W, int& tw, int& th, int& hrows) {
+  const int avail = conv_halo_rows(BM) / HALO_PITCH;
+  float best = 0.f;
+  for (int c = 2; c <= HALO_PITCH - 2 && c <= W; c += 2) {
+    int t = (BM / c) & ~1;
+    while (t > 0 && t + 2 + (t - 1 + H - 1) / H > avail) t -= 2;
+    if (t < 2) continue;
+    const int cols = (W + c - 1) / c;
+    const float u = (float)(t * c) / (float)BM * (float)W / (float)(cols * c);
+    if (u > best + 1e-6f) { best = u; tw = c; th = t; hrows = t + 2 + (t - 1 + H - 1) / H; }
+  }
+  return best;
+}
+
 // Would a 3x3 MUL launch with N = n_out, input H x W, take the weights-in-registers kernel?  (Encoder::explain asks before it
 // chooses the compact pool interface, which only that kernel reads.)
 inline bool conv_takes_breg(int n_out, int H, int W, bool have_frag) {
@@ -1765,6 +1883,16 @@ inline int conv_wide_tile(int n_out, long mrows) {
   // one 8-wave block per CU: only worth it when the grid still fills the chip ~1.5 times over
   if (wide && ((mrows + 255) / 256) * (n_out / wide) < 400) wide = 0;
   return wide;
+}
+
+// Can the interleaved dual forward of a layer with `cout` channels on NB images of H x W pool in its epilogue
+// (ConvArgs::pool_gc)?  The launch must reach the 128 x 128 resident-image kernel: mirrors conv_launch_epi; LRP_POOL_FUSED=0 disables.
+inline bool conv_takes_pool_fused(int cout, int NB, int H, int W) {
+  if (!sw().pool_fused || conv_halo_mode() <= 0 || (H & 1) || (W & 1) || (cout & 31) || conv_pick_tile(2 * cout).BN != 128) return false;
+  const long blocks = (((long)NB * H * W + 127) / 128) * ((2 * cout + 127) / 128);
+  if (conv_small_tile_on() && blocks <= 2 * conv_small_tile_blocks()) return false;      // (small / mid-size grids: other tiles)
+  int tw, th, hrows;
+  return conv_halo_geom_even(128, H, W, tw, th, hrows) >= 0.8f;
 }
 
 // Would a split-bf16 3x3 MUL launch (N = n_out columns, NB x H x W rows) take a pipelined halo kernel — 128 x 128 or the 8-wave
@@ -1911,6 +2039,18 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
 
   if constexpr (PREC != PREC_FP32 && (EPI == EPI_MUL || EPI == EPI_MUL_UP2 || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU || EPI == EPI_FWD_DUAL)) {
     const int mode = conv_halo_mode();
+    if (a.pool_gc) {
+      // pool fused into the dual forward's epilogue: 128 x 128 resident-image tiles of even height and width or nothing
+      if (!(EPI == EPI_FWD_DUAL && PREC == PREC_F16X2) || !a.dual_il || !a.pairs_out || !a.pool_pos || a.taps != 9 || small_tile ||
+          t.BM != 128 || t.BN != 128 || !conv_takes_pool_fused(a.split, a.NB, a.H, a.W))
+        return hipErrorInvalidValue;
+      (void)conv_halo_geom_even(128, a.H, a.W, a.tw, a.th, a.hrows);
+      a.nyh = a.NB * a.H;
+      a.cols_t = (a.W + a.tw - 1) / a.tw;
+      a.m_tiles = ((a.nyh + a.th - 1) / a.th) * a.cols_t;
+      hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2, EPI, PREC, true, false, TERMS>), dim3(a.m_tiles * a.n_tiles), dim3(256), 0, st, a);
+      return hipGetLastError();
+    }
     // N = 64 tiles (TM x TN = 2 x 1 per wave) lose with the resident image: 2 instead of 3 blocks per CU and the
     // per-tap address work is spread over half as many MFMAs  [MI355X: block1_conv2 bwd 4.5 ms vs 5.2 ms]
     if constexpr (EPI == EPI_MUL || EPI == EPI_MUL_UP2) {
@@ -1971,7 +2111,7 @@ inline hipError_t conv_launch_epi(ConvArgs a, hipStream_t st) {
   // Only the resident-image kernels above read the compact pool interface.  A launch that carries it and got here (tile
   // override, halo geometry below 0.9 for the tile actually chosen, fp32 operands) would run a kernel that ignores up2_src and
   // reads a.in as a dense tensor: refuse instead of producing wrong heat-maps silently.
-  if (a.up2_src) return hipErrorInvalidValue;
+  if (a.up2_src || a.pool_gc) return hipErrorInvalidValue;
   if (small_tile) {
     a.m_tiles = (a.M + 63) / 64;
     a.n_tiles = (a.N + 63) / 64;

@@ -47,6 +47,9 @@ struct ConvLayer {
   // pool interface; written by pool_gate_split_kernel, valid for the encode whose number gc_epoch holds
   DevBuf Gc, Gpos;
   long gc_epoch = -1;
+  // the full-resolution gate G of a pooled layer is current for the encode whose number this holds: the fused pool epilogue
+  // writes the compact form only, Encoder::full_gate() expands it for the walks that read G (cnn_kernels.h pool_gate_expand_kernel)
+  long gfull_epoch = -1;
   // 2:4-sparse consumer of the pooled boundary behind this layer (conv_sparse.h; layers with cin % 256 == 0 whose output is pooled:
   // VGG16 block3_conv3, block4_conv3): the four class arrangements of w+ and, per encode, the index planes of the pool's positions
   DevBuf w_sp, idxp;
@@ -535,6 +538,7 @@ struct Encoder {
     if (B < 1 || B > max_images) return fail(LRP_ERR_INVALID, "B=%d outside [1,%d]", B, max_images);
     LRP_TRY(check_ready());
     ++encode_epoch;
+    for (ConvLayer& L : layers) L.gfull_epoch = encode_epoch;     // (every path writes the full-resolution gates, except the fused pool below)
     const size_t img_elems = (size_t)img_h * img_w * 3;
     if (gates_pending) {                               // the previous encode's side work still owns G / bufZ / bufXs
       LRP_HIP_CHECK(hipStreamWaitEvent(st, ev_gates, 0));
@@ -637,6 +641,13 @@ struct Encoder {
             LRP_HIP_CHECK(hipGetLastError());
           }
           if (emit_conv) { cd.pairs_out = pout; cd.pairs_scale = oscale_of(li); cd.skip_out = keep_acts ? 0 : 1; }
+          // pooled layer: max-pool, arg-max gate (compact form) and the pooled pairs in THIS conv's epilogue — a_l and Z+_l at
+          // full resolution are neither written nor read back (round 4; the pass it replaces: pool_gate_split_kernel below)
+          const bool pool_fused = emit_pool && !keep_acts && cd.dual_il && L.Gc.p && L.Gpos.p && conv_takes_pool_fused(L.cout, B, L.H, L.W);
+          if (pool_fused) {
+            cd.pool_gc = L.Gc.as<float>(); cd.pool_pos = L.Gpos.as<unsigned char>(); cd.pairs_out = pout; cd.pairs_scale = oscale_of(li);
+            cd.out = nullptr; cd.out2 = nullptr;
+          }
           // The denominators Z+_l of the layers whose reverse launch is two-term (explain(): up to the last pool, >= 576
           // products) are computed two-term as well — with the SAME rounded weights hi(w+) the walk multiplies with.
           // [MI355X: parity at the bench configuration 5.5e-6 -> 4.4e-6, 6 seeds median 4.2e-6 -> 3.3e-6: gate and
@@ -649,6 +660,16 @@ struct Encoder {
           in_pairs = emit_conv || emit_pool;
           if (in_pairs) { float* t = pin; pin = pout; pout = t; }
           if (fused_gate) { xin[li + 1] = a_out; continue; }
+          if (L.pool_after && pool_fused) {
+            layers[li].gc_epoch = encode_epoch;
+            layers[li].gfull_epoch = -1;                 // G itself was not written: expanded on demand (full_gate)
+            if (L.idxp.p && L.w_sp.p && sw().sparse_pool) {
+              LRP_HIP_CHECK(conv_sparse_index(L.Gpos.as<unsigned char>(), L.idxp.as<unsigned>(), B, L.H / 2, L.W / 2, L.cout, st));
+              layers[li].idx_epoch = encode_epoch;
+            }
+            xin[li + 1] = L.P.as<float>();               // (not read: the next conv takes the pairs)
+            continue;
+          }
           if (L.pool_after) {
             const size_t n = (size_t)B * L.act_elems();
             if (emit_pool) {
@@ -826,6 +847,20 @@ struct Encoder {
   //   used as the ReLU/arg-max mask, exact fp32.
   // layer_hook (fine-tune step): called with (li, dZ_li) — the gradient at the pre-activation of conv li, n x H x W x cout —
   // before that layer's backward-data conv is launched; the image layer itself is then skipped (R_img_dev may be null).
+  // The walks that read a pooled layer's gate at full resolution (EPI_MUL_UP2 / up2_gate: the gradient baselines, the fp32 and
+  // fast modes, LRP_UP2_COMPACT=0) after an encode whose fused pool epilogue left the compact form only
+  int full_gate(int li, hipStream_t st) {
+    ConvLayer& L = layers[li];
+    if (!L.pool_after || L.gfull_epoch == encode_epoch) return LRP_OK;
+    if (!L.Gc.p || L.gc_epoch != encode_epoch) return fail(LRP_ERR_STATE, "no pool gate of layer %d for this encode", li);
+    const size_t n8 = (size_t)encoded * (L.H / 2) * (L.W / 2) * (L.cout / 8);
+    hipLaunchKernelGGL(pool_gate_expand_kernel, dim3(stream_grid(n8)), dim3(256), 0, st, L.Gc.as<float>(), L.Gpos.as<unsigned char>(),
+                       L.G.as<float>(), encoded, L.H, L.W, L.cout);
+    LRP_HIP_CHECK(hipGetLastError());
+    L.gfull_epoch = encode_epoch;
+    return LRP_OK;
+  }
+
   int explain(int n, const int* row2img_dev, const float* R_feat_dev, float* R_img_dev, hipStream_t st, int walk = 0,
               const std::function<int(int, const float*)>* layer_hook = nullptr) {
     const int* r2i_host = row2img_host;
@@ -1018,6 +1053,8 @@ struct Encoder {
       // Encoder::two_term is that rule; lrp_set_fast_layers replaces it by a per-model mask, LRP_F16_T2MASK (experiments)
       // overrides both.
       const int terms = f16 && two_term(li) ? 5 : 7;
+      if (epi == EPI_MUL_UP2) LRP_TRY(full_gate(li - 1, st));
+      if (ca.up2_gate) LRP_TRY(full_gate(li, st));
       LRP_HIP_CHECK(conv_launch(epi, ca, st, run_prec, terms));
       if (profile) {
         (void)hipEventRecord(pr.e1, st);

@@ -2,7 +2,7 @@
 
 VERDICT r3: "~40 LRP_* switches, six swept once, none under a committed test — each untested switch is a dead or wrong code
 path waiting for a user."  Round 4 deleted 21 of them (their code paths with them where nothing else reaches those) and
-keeps 17 as measurement knobs / fall-backs (+ the opt-in LRP_SPARSE_POOL of round 4); this file runs each of the kept ones — alone, at the setting that leaves the
+keeps 17 as measurement knobs / fall-backs (+ round 4's LRP_POOL_FUSED and the opt-in LRP_SPARSE_POOL); this file runs each of the kept ones — alone, at the setting that leaves the
 default path — through the engine at a size where the kernels of the benchmark configuration engage and compares every
 heat-map with the default run:
 
@@ -47,6 +47,7 @@ CASES = [
     ("LRP_FWD_IL", 0, 2e-5, 2e-5),
     ("LRP_DEC_BATCHED", 0, 2e-5, 2e-5),
     ("LRP_DEC_MFMA_FWD", 0, 2e-5, 2e-5),
+    ("LRP_POOL_FUSED", 0, 0.0, 0.0),        # max-pool / gate / pooled pairs as a pass behind the conv: the same arithmetic, bit for bit
     ("LRP_SPARSE_POOL", 1, 1e-6, 1e-6),    # opt-in: block4_conv3 / block3_conv3 on the 2:4-sparse matrix cores (other summation order)
 ]
 
