@@ -148,7 +148,9 @@ def test_config4_resnet101_gridtd_b32_matches_oracle_and_small_batch(prec):
         one = solo.explain_tokens([0] * T, list(range(1, T + 1)))[0]
         worst = max(worst, float(_gpu_rel_l1(out[b * T:(b + 1) * T], one).max()))
     report("config4_b32_batch_invariance_" + prec, max_rel_l1=worst, heatmaps=B * T)
-    assert worst < TOL_BATCH, worst
+    # round 4: the bf16x3 mode's forward takes every scale per IMAGE (resnet_encoder.h encode_emit), the fp32 mode's has none:
+    # an image's heat-maps do not depend on its batch mates, bit for bit — as for VGG16
+    assert worst == 0.0, worst
 
 
 # ------------------------------------------------------------------------------------------------ configs[4]

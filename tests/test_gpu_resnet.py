@@ -114,6 +114,86 @@ def test_pair_emitting_forward_matches_oracle_is_batch_invariant_and_has_a_fallb
     assert e_fb < 1e-5 and e_fb_hm < 2e-5
 
 
+def _stem_pool_windows(w, Xh, dtype):
+    """candidates of every window of the stem's overlapping 3x3/2 max-pool (zero padding included): (1, 64, 9, 56*56)"""
+    import torch
+    import torch.nn.functional as F
+    x = torch.as_tensor(Xh.copy(), dtype=dtype).permute(0, 3, 1, 2)
+    c = F.conv2d(F.pad(x, (3, 3, 3, 3)), torch.as_tensor(w["conv1_conv_W"], dtype=dtype).permute(3, 2, 0, 1).contiguous(),
+                 torch.as_tensor(w["conv1_conv_b"], dtype=dtype), stride=2)
+    g, b_, m, v = (torch.as_tensor(w["conv1_bn_" + k], dtype=dtype).view(1, -1, 1, 1) for k in ("gamma", "beta", "mean", "var"))
+    a0 = torch.relu(g * (c - m) / torch.sqrt(v + 1.001e-5) + b_)
+    return F.unfold(F.pad(a0, (1, 1, 1, 1)), 3, stride=2).view(1, 64, 9, -1)
+
+
+@pytest.mark.parametrize("pic", [0, 2], ids=["flickr30k_1009434119", "coco_000000005586"])
+def test_a_photograph_through_resnet101_and_gridtd(pic):
+    """BASELINE config 4's path on NATURAL images (tests/golden/real_images.npz: photographs the reference ships): device
+    preprocessing -> ResNet-101 -> grid-TD -> three per-word heat-maps vs the oracles; and the same picture inside a batch of
+    noise images, bit for bit.  What a photograph adds over noise images here:
+      * tens of thousands of windows of the stem's overlapping 3x3/2 max-pool are all zero (a tie of every candidate, the zero
+        padding included; counted in the float64 forward and asserted);
+      * NEAR-ties: the COCO picture has a flat region, and there two windows have their two best candidates within 1e-6 of
+        each other — and in ONE of them the reference's own float32 forward picks the other candidate than float64 does (counted
+        below from both forwards).  `MaxPoolGrad` then routes that window's relevance to another pixel: the float32 literal
+        graph (what the reference's TensorFlow computes) is 2.7e-5 / 1.0e-4 / 5.0e-5 from the float64 one on the three words,
+        44 % of it at that one unit, and every arithmetic of the engine (the exact fp32 mode included) lands 0.9 - 1.5e-4 from
+        float64 — a discrete decision of the reference's algorithm on a quantity float32 cannot order, not rounding that more
+        bits in the walk would remove (profiles/r04_resnet_photograph.txt).  Bound for a picture with such windows:
+        max(1e-4, 3 x the float32 literal graph's largest distance), as in test_gpu_stress_parity.py; without: 1e-4."""
+    import os
+    import torch
+    from conftest import GOLDEN
+    from lrp_imagecaptioning_amd.engine import LRPEngine, preprocess_images
+    from lrp_imagecaptioning_amd.synthetic import captions, images
+    rgb = np.load(os.path.join(GOLDEN, "real_images.npz"))["rgb_u8"][pic:pic + 1]
+    rs = np.random.RandomState(4)
+    V, T = 1000, 6
+    w = resnet_weights(rs)
+    w.update(gridtd_weights(rs, 49, 2048, 512, 512, V))
+    spec = RN.resnet_spec()
+    cap = captions(rs, 1, T, V)[0]
+    Xh = np.ascontiguousarray(rgb.astype(np.float32)[..., ::-1] - np.array([103.939, 116.779, 123.68], dtype=np.float32))   # preprocessors.py:38-53
+    w64, w32 = _stem_pool_windows(w, Xh, torch.float64), _stem_pool_windows(w, Xh, torch.float32)
+    top2 = w64.topk(2, dim=2)[0]
+    dead = int((top2[:, :, 0] == 0).sum())
+    near = int(((top2[:, :, 0] > 0) & ((top2[:, :, 0] - top2[:, :, 1]) < 1e-6 * top2[:, :, 0])).sum())
+    flips32 = int(((w64.argmax(2) != w32.argmax(2)) & (top2[:, :, 0] > 0)).sum())
+    kw = dict(decoder="gridtd", img_hw=(224, 224), L=49, D=2048, H=512, E=512, V=V, max_caption_len=T + 1,
+              resnet={"stem": 64, "stacks": RESNET101_STACKS})
+    one = LRPEngine(max_images=1, max_tokens=T, **kw)
+    one.set_weights(w)
+    Xd = preprocess_images(torch.as_tensor(rgb).cuda())
+    assert torch.equal(Xd.cpu(), torch.as_tensor(Xh))
+    one.encode_images(Xd)
+    one.decoder_forward([cap])
+    tt = [1, 3, T]
+    out = one.explain_tokens([0] * 3, tt)[0].clone()
+    o = GridTDOracle(w, 49, 2048, 512, 512)
+    o.forward(RN.forward(w, spec, Xh).astype(np.float32), cap)
+    Rs = [o.explain(t)[0].reshape(1, 7, 7, 2048) for t in tt]
+    refs = [RN.analyze(w, spec, Xh, R)[0] for R in Rs]
+    errs = [rel_l1(out[i].cpu().numpy(), refs[i]) for i in range(3)]
+    noise32 = 0.0
+    if near:                                               # the reference's own float32 arithmetic on this picture
+        noise32 = max(rel_l1(RN.analyze(w, spec, Xh, R, dtype=torch.float32)[0], ref) for R, ref in zip(Rs, refs))
+    B = 4
+    big = LRPEngine(max_images=B, max_tokens=3, **kw)
+    big.set_weights(w)
+    Xb = torch.as_tensor(images(rs, B)).cuda()
+    Xb[2] = Xd[0]
+    caps = captions(rs, B, T, V)
+    caps[2] = cap
+    big.encode_images(Xb)
+    big.decoder_forward(caps)
+    same = bool(torch.equal(big.explain_tokens([2] * 3, tt)[0], out))
+    report("resnet101_photograph_%d" % pic, stem_pool_all_zero_windows=dead, stem_pool_near_ties=near,
+           float32_forward_picks_another_candidate=flips32, float32_literal_graph_rel_l1=noise32, rel_l1=errs, in_batch_bit_identical=same)
+    assert dead >= 10000, dead
+    assert max(errs) < max(TOL, 3 * noise32), (errs, noise32)
+    assert same
+
+
 def test_config4_gridtd_plus_resnet_end_to_end():
     """grid-TD decoder on a ResNet encoder (BASELINE config 4 at reduced size): decoder LRP -> CNN LRP fused call."""
     stacks, stem, hw, H, V = ((4, 2), (8, 2)), 8, 32, 32, 50
