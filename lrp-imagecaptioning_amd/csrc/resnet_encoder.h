@@ -735,6 +735,24 @@ struct ResNetEncoder {
       hipLaunchKernelGGL(rn_pool3_route_kernel<false>, dim3(stream_grid(tot / 4)), dim3(256), 0, st, Ro, pool_win.as<unsigned char>(),
                          q_stem.as<float>(), row2img, r1.as<float>(), n, s.Hout, s.Wout, s.cout);
     LRP_HIP_CHECK(hipGetLastError());
+    if (sw().img_fused != 0 && s.cout == 64 && (ssplit ? s.w_bs.p : s.w_b.p) && conv_npad(RN_STEM_TCOLS) >= 5 * 60 + 4 && conv_cinp(s.cout) == 64) {
+      // T = S . W and the 7x7 / stride-2 shift-and-add in ONE launch, T never leaves LDS (resnet_kernels.h rn_stem_reverse_kernel);
+      // LRP_IMG_FUSED=0 (and stems that are not 64 channels wide): the two-kernel form below
+      const int txs = (s.Wout + RN_ST - 1) / RN_ST, tys = (s.Hout + RN_ST - 1) / RN_ST;
+      if (!stem_attr_set) {
+        LRP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rn_stem_reverse_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RN_STEM_LDS));
+        LRP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rn_stem_reverse_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RN_STEM_LDS));
+        stem_attr_set = true;
+      }
+      if (ssplit)
+        hipLaunchKernelGGL(rn_stem_reverse_kernel<true>, dim3((unsigned)(n * txs * tys)), dim3(512), RN_STEM_LDS, st, r1.as<float>(), s.w_bs.as<float>(),
+                           images.as<float>(), row2img, R_img_dev, s.Hout, s.Wout, txs, tys);
+      else
+        hipLaunchKernelGGL(rn_stem_reverse_kernel<false>, dim3((unsigned)(n * txs * tys)), dim3(512), RN_STEM_LDS, st, r1.as<float>(), s.w_b.as<float>(),
+                           images.as<float>(), row2img, R_img_dev, s.Hout, s.Wout, txs, tys);
+      LRP_HIP_CHECK(hipGetLastError());
+      return LRP_OK;
+    }
     ConvArgs ca{};
     ca.in = r1.as<float>(); ca.NB = n * s.Hout * s.Wout; ca.H = 1; ca.W = 1; ca.Cin = s.cout; ca.CinP = conv_cinp(s.cout);
     ca.taps = 1; ca.wpk = ssplit ? s.w_bs.as<float>() : s.w_b.as<float>(); ca.N = RN_STEM_TCOLS; ca.out = r2.as<float>();
@@ -749,6 +767,7 @@ struct ResNetEncoder {
   // (t * C1 of the first block), so multiplying by the relu-unit gate a0*Q would count a0 twice
   DevBuf q_stem;
   DevBuf pool_win;
+  bool stem_attr_set = false;
 
   int profile_records(int cap, double* ms_out, double* flop_out, int* n_out) {
     int k = 0;

@@ -526,6 +526,150 @@ __global__ __launch_bounds__(256) void rn_pack_stem_dev_kernel(const float* __re
     }
   }
 }
+// ---- the reverse of the 7x7 / stride-2 stem in ONE launch (round 4) -------------------------------------------------------------
+// Unfused (below: a 1-tap GEMM T = S . W with 49 taps x 6 columns per stem position, then rn_stem_stencil_kernel gathering from
+// T) the T tensor — 4.7 GB at 320 tokens — is written and read back: 3.0 of config 4's 30 ms walk.  Here a workgroup owns a
+// 16 x 16 PATCH of stem positions: their S rows (64 channels, split-bf16 pairs or fp32) stay in LDS, the 294 columns are
+// produced ten taps (60 columns) at a time on the matrix cores into an LDS tile, and every thread adds the taps that land on ITS
+// input pixels into registers — pixel (y, x) receives tap (kh, kw) from stem position ((y + 3 - kh) / 2, (x + 3 - kw) / 2) where
+// both are whole — before the next ten taps overwrite the tile.  Patches step 13 positions: the 26 x 26 input pixels whose whole
+// 4 x 4 neighbourhood of stem positions lies inside a patch are that patch's (1.5 x recompute of a GEMM that is 2 % of the walk).
+// S is read 1.5 x, R_img written once; nothing else moves.  8 waves; wave w owns patch rows 32 w .. 32 w + 31 of the GEMM and keeps
+// them in registers.  [MI355X, 320 tokens: 3.05 ms (GEMM 1.56 + gather 1.49) -> see DESIGN 4.8; with the S rows in LDS — one
+// workgroup per CU, every phase behind a barrier — the launch took 2.2 ms.]
+constexpr int RN_SP = 16, RN_ST = 13, RN_SO = 2 * RN_ST;      // patch edge, patch step (stem positions), output pixels per patch edge
+constexpr int RN_SROW = 68;                                   // LDS row pitch of the W tile in floats (64 + 4: conflict-free 16 B reads)
+constexpr int RN_STS = 61;                                    // ... of the T tile (60 columns used; odd: the stencil's column reads spread over the banks)
+constexpr int RN_STEM_LDS = (64 * RN_SROW + 256 * RN_STS) * 4;   // 79.9 KB: two workgroups per CU
+template <bool SPLIT>
+__global__ __launch_bounds__(512, 2) void rn_stem_reverse_kernel(const float* __restrict__ S, const float* __restrict__ Wb,
+                                                                 const float* __restrict__ ximg, const int* __restrict__ row2img,
+                                                                 float* __restrict__ out, int Ho, int Wo, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float rn_smem[];
+  float* Bs = rn_smem;                                        // [64 columns of this tap group][RN_SROW]
+  float* Ts = Bs + 64 * RN_SROW;                              // [256][RN_STS]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpi = tiles_x * tiles_y;
+  const int pn = blockIdx.x / tpi, rr = blockIdx.x - pn * tpi, ty = rr / tiles_x, tx = rr - ty * tiles_x;
+  const int oh0 = ty * RN_ST - 1, ow0 = tx * RN_ST - 1;       // first stem position of the patch
+  const int H2 = 2 * Ho, W2 = 2 * Wo;
+  const int h = lane >> 5, l31 = lane & 31;
+  // The wave's 32 patch rows as MFMA A fragments, straight from memory into registers (they are reused by all five tap groups;
+  // in LDS they cost 68 KB and a second workgroup per CU): lane (row, half h) holds, per k-step, the 32 B of channel group
+  // 2 ks + h (split8: hi8 | lo8) — or for fp32 the eight 16 B pieces 8 g + 4 h.  Positions outside the map are zero rows.
+  u32x4 af[8];
+  {
+    const int row = wave * 32 + l31, oh = oh0 + (row >> 4), ow = ow0 + (row & 15);
+    const bool ok = oh >= 0 && oh < Ho && ow >= 0 && ow < Wo;
+    const float* sp = S + (((size_t)pn * Ho + (ok ? oh : 0)) * Wo + (ok ? ow : 0)) * 64;
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* g = SPLIT ? sp + (2 * q + h) * 8 : sp + 16 * q + 4 * h;      // fp32: g = 2 q, 2 q + 1
+      const u32x4 v0 = *reinterpret_cast<const u32x4*>(g), v1 = *reinterpret_cast<const u32x4*>(g + (SPLIT ? 4 : 8));
+      af[2 * q] = ok ? v0 : z4;
+      af[2 * q + 1] = ok ? v1 : z4;
+    }
+  }
+  // this thread's input pixels and their running sums
+  float pos[2][3], neg[2][3];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { pos[q][c] = 0.f; neg[q][c] = 0.f; }
+  f32x4 bq[2];                                                // the next tap group's W rows (64 rows x 16 pieces = 2 per thread)
+  auto load_b = [&](int grp) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = tid + 512 * i, row = p >> 4, c16 = p & 15;
+      bq[i] = *reinterpret_cast<const f32x4*>(Wb + (size_t)(grp * 60 + row) * 64 + c16 * 4);
+    }
+  };
+  load_b(0);
+  for (int grp = 0; grp < 5; ++grp) {
+    __syncthreads();                                          // the previous group's Bs / Ts have been read
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = tid + 512 * i;
+      *reinterpret_cast<f32x4*>(Bs + (p >> 4) * RN_SROW + (p & 15) * 4) = bq[i];
+    }
+    __syncthreads();
+    if (grp + 1 < 5) load_b(grp + 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int go = (2 * ks + h) * 8;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, af[2 * ks]), al = __builtin_bit_cast(bf16x8, af[2 * ks + 1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float* brow = Bs + (j * 32 + l31) * RN_SROW + go;
+          const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(brow));
+          const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(brow + 4));
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);      // small terms first
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+        }
+      }
+    } else {
+      // exact fp32: lane half h takes k = 8 g + 4 h + s at sub-step s (one 16 B read of W and four MFMAs)
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const f32x4 a4 = __builtin_bit_cast(f32x4, af[g]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(Bs + (j * 32 + l31) * RN_SROW + 8 * g + 4 * h);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4], b4[s4], acc[j], 0, 0, 0);
+        }
+      }
+    }
+    // C map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (j * 32 + l31 < 60) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ts[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * RN_STS + j * 32 + l31] = acc[j][r];
+      }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int o = tid + 512 * q;
+      if (o < RN_SO * RN_SO) {
+        const int oy = o / RN_SO, ox = o - oy * RN_SO;
+        const int y = 2 * (oh0 + 1) + oy, x = 2 * (ow0 + 1) + ox;
+#pragma unroll
+        for (int tl = 0; tl < 10; ++tl) {
+          const int tap = grp * 10 + tl, kh = tap / 7, kw = tap - kh * 7;
+          if (tap < 49 && !((y + 3 - kh) & 1) && !((x + 3 - kw) & 1)) {
+            const float* r = Ts + ((((y + 3 - kh) >> 1) - oh0) * RN_SP + (((x + 3 - kw) >> 1) - ow0)) * RN_STS + tl * 6;
+            pos[q][0] += r[0]; pos[q][1] += r[1]; pos[q][2] += r[2];
+            neg[q][0] += r[3]; neg[q][1] += r[4]; neg[q][2] += r[5];
+          }
+        }
+      }
+    }
+  }
+  const int img = row2img ? row2img[pn] : pn;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int o = tid + 512 * q;
+    if (o >= RN_SO * RN_SO) continue;
+    const int oy = o / RN_SO, ox = o - oy * RN_SO;
+    const int y = 2 * (oh0 + 1) + oy, x = 2 * (ow0 + 1) + ox;
+    if (y >= H2 || x >= W2) continue;
+    const size_t pix = (size_t)y * W2 + x;
+    const float* xv = ximg + ((size_t)img * H2 * W2 + pix) * 3;
+    float* ov = out + ((size_t)pn * H2 * W2 + pix) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ov[c] = xv[c] >= 0.f ? xv[c] * pos[q][c] : xv[c] * neg[q][c];
+  }
+}
+
 __global__ __launch_bounds__(256) void rn_stem_stencil_kernel(const float* __restrict__ T, const float* __restrict__ ximg,
                                                               const int* __restrict__ row2img, float* __restrict__ out,
                                                               int ntok, int H, int W) {
