@@ -471,6 +471,17 @@ struct Decoder {
                        kchunk, slab);
     return hipGetLastError();
   }
+  // two products of one shape (R <= 32 rows, no bias) in one launch
+  template <typename TX, typename TA, typename TY>
+  static hipError_t skinny_pair(const TX* X0, const float* W0, TY* Y0, const TX* X1, const float* W1, TY* Y1, int ldx, int ldw, int ldy,
+                                int R, int K, int N, hipStream_t st, int ks, size_t slab) {
+    if (R > 32) return hipErrorInvalidValue;
+    int kchunk = ((K + ks - 1) / ks + 63) / 64 * 64;
+    SkinnyPair p{};
+    p.X[0] = X0; p.X[1] = X1; p.W[0] = W0; p.W[1] = W1; p.Y[0] = Y0; p.Y[1] = Y1;
+    hipLaunchKernelGGL((skinny_gemm_pair_kernel<TX, TA, TY>), dim3((N + 63) / 64, 2, ks), dim3(256), 0, st, p, ldx, ldw, ldy, R, K, N, kchunk, slab);
+    return hipGetLastError();
+  }
   static constexpr int KS_GATE = 8, KS_PROJ = 4;
 
   template <typename T>
@@ -695,10 +706,16 @@ struct Decoder {
                          S_<double>("g1t"), S_<double>("i1t_act"), S_<double>("f1t_act"), stt, (double*)nullptr,
                          S_<double>("o1t_act"), i, Tm, H);
       LRP_HIP_CHECK(hipGetLastError());
-      LRP_HIP_CHECK((skinny<double, double, double>(h1 + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
-                                                    hprojd.as<double>(), H, B, H, H, 0, st, KS_PROJ, ps)));
-      LRP_HIP_CHECK((skinny<double, double, double>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
-                                                    sprojd.as<double>(), H, B, H, H, 0, st, KS_PROJ, ps)));
+      if (B <= 32) {                                     // h1 . W_ha and s . W_s: one launch
+        LRP_HIP_CHECK((skinny_pair<double, double, double>(h1 + (size_t)(i + 1) * H, Wg.as<float>(), hprojd.as<double>(),
+                                                           stt + (size_t)(i + 1) * H, Ws.as<float>(), sprojd.as<double>(), S * H, H, H, B, H, H,
+                                                           st, KS_PROJ, ps)));
+      } else {
+        LRP_HIP_CHECK((skinny<double, double, double>(h1 + (size_t)(i + 1) * H, S * H, Wg.as<float>(), H, nullptr,
+                                                      hprojd.as<double>(), H, B, H, H, 0, st, KS_PROJ, ps)));
+        LRP_HIP_CHECK((skinny<double, double, double>(stt + (size_t)(i + 1) * H, S * H, Ws.as<float>(), H, nullptr,
+                                                      sprojd.as<double>(), H, B, H, H, 0, st, KS_PROJ, ps)));
+      }
       const size_t lds = (size_t)(2 * H + L + 8) * sizeof(double);
       hipLaunchKernelGGL(gtd_attention_kernel, dim3(B), dim3(256), lds, st, hprojd.as<double>(), sprojd.as<double>(), KS_PROJ, ps,
                          stat.as<float>(), vvec.as<float>(), if_pre.as<float>(), h1, h2, stt, S_<double>("attention"),

@@ -43,13 +43,13 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // (Y + z*slab); the consumer kernel adds the slabs in a fixed order (bit-reproducible, no atomics).
 // These GEMMs are latency-bound chains of dependent loads, so more, shorter blocks is the lever.
 template <typename TX, typename TA, typename TY>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__ X, int ldx, const float* __restrict__ W,
-                                                          int ldw, const float* __restrict__ bias, TY* __restrict__ Y,
-                                                          int ldy, int R, int K, int N, int relu, int kchunk, size_t slab) {
+__device__ __forceinline__ void skinny_gemm_body(const TX* __restrict__ X, int ldx, const float* __restrict__ W, int ldw,
+                                                 const float* __restrict__ bias, TY* __restrict__ Y, int ldy, int R, int K, int N,
+                                                 int relu, int kchunk, size_t slab, int row_block) {
   __shared__ TA xs[64][32];
   __shared__ TA red[3][32][64];
   const int tid = threadIdx.x, col = tid & 63, kg = tid >> 6;
-  const int n = blockIdx.x * 64 + col, r0 = blockIdx.y * 32;
+  const int n = blockIdx.x * 64 + col, r0 = row_block * 32;
   const int kbeg = blockIdx.z * kchunk;
   const int Kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
   Y += (size_t)blockIdx.z * slab;
@@ -108,6 +108,22 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__
       }
     }
   }
+}
+template <typename TX, typename TA, typename TY>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const TX* __restrict__ X, int ldx, const float* __restrict__ W,
+                                                          int ldw, const float* __restrict__ bias, TY* __restrict__ Y,
+                                                          int ldy, int R, int K, int N, int relu, int kchunk, size_t slab) {
+  skinny_gemm_body<TX, TA, TY>(X, ldx, W, ldw, bias, Y, ldy, R, K, N, relu, kchunk, slab, blockIdx.y);
+}
+// TWO products of one shape in one launch (R <= 32 rows: blockIdx.y picks the product) — the grid-TD step's h1 . W_ha and
+// s . W_s, which were two dependent-looking launches of ~25 us each on a latency-bound chain
+struct SkinnyPair { const void* X[2]; const float* W[2]; void* Y[2]; };
+template <typename TX, typename TA, typename TY>
+__global__ __launch_bounds__(256) void skinny_gemm_pair_kernel(SkinnyPair p, int ldx, int ldw, int ldy, int R, int K, int N,
+                                                               int kchunk, size_t slab) {
+  const int w = blockIdx.y;
+  skinny_gemm_body<TX, TA, TY>(static_cast<const TX*>(p.X[w]), ldx, p.W[w], ldw, nullptr, static_cast<TY*>(p.Y[w]), ldy, R, K, N, 0,
+                               kchunk, slab, 0);
 }
 
 // Caption generation (beam search) re-parents hypotheses between steps: row r continues the hypothesis that lived in
