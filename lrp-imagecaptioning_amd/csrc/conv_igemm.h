@@ -1653,78 +1653,10 @@ __global__ __launch_bounds__(64 * WM * WN, BREG ? 3 : NS > 2 ? 2 : conv_min_wave
               }
               continue;                                   // next slab
             }
-            // ---- the tail of a ResNet identity block with the next block's chain head (join + gate2; resnet_encoder.h
-            // unit_backward with BlockTail): out = acc x gate + join x join_gate, out2 = out x gate2.  These launches are
-            // HBM-bound — K = f channels of MFMA work against three full-width streams per output element — and through the
-            // general form below (gate rows "one pass ahead", every switch next to a load: one exposed memory round trip per
-            // pass) they ran at 2.2 TB/s [MI355X, ResNet-101 conv4_x: 370 us per launch for 0.8 GB].  Here the four operand
-            // rows of RING passes are in flight unconditionally, like the gate rows above.
-            if constexpr (EPI == EPI_MUL) {
-              if (tail_ && head2_ && !a.gate_none && !a.gate_binary && !a.relu_out && !a.epi_generic) {
-                constexpr int NPf = RH / RPP;
-                constexpr int RING = 2 < NPf ? 2 : NPf;
-                int imgf[NPf];
-#pragma unroll
-                for (int ps = 0; ps < NPf; ++ps) {
-                  int row, n_, h_, w_;
-                  if (!locate(hf * RH + rin + ps * RPP, row, n_, h_, w_)) n_ = 0;
-                  imgf[ps] = a.row2img ? a.row2img[n_] : n_;
-                }
-                f32x4 gq[RING][4][CW / 4];
-                auto issue = [&](int ps) {
-                  int row, n_, h_, w_;
-                  if (!locate(hf * RH + rin + ps * RPP, row, n_, h_, w_)) { row = 0; h_ = 0; w_ = 0; }
-                  const size_t go = ((size_t)imgf[ps] * HW + h_ * a.W + w_) * a.N + col;
-                  const float* jp = a.join + (size_t)row * a.N + col;
-#pragma unroll
-                  for (int q4 = 0; q4 < CW / 4; ++q4) {
-                    gq[ps % RING][0][q4] = *reinterpret_cast<const f32x4*>(a.aux + go + 4 * q4);
-                    gq[ps % RING][1][q4] = *reinterpret_cast<const f32x4*>(jp + 4 * q4);
-                    gq[ps % RING][2][q4] = *reinterpret_cast<const f32x4*>(a.join_gate + go + 4 * q4);
-                    gq[ps % RING][3][q4] = *reinterpret_cast<const f32x4*>(a.gate2 + go + 4 * q4);
-                  }
-                };
-#pragma unroll
-                for (int ps = 0; ps < RING - 1; ++ps) issue(ps);
-                const bool plain = SPLIT_OUT && a.out_plain;
-#pragma unroll
-                for (int ps = 0; ps < NPf; ++ps) {
-                  if (ps + RING - 1 < NPf) issue(ps + RING - 1);
-                  int row, n_, h_, w_;
-                  if (locate(hf * RH + rin + ps * RPP, row, n_, h_, w_)) {
-                    const int ll = rin + ps * RPP;
-                    float v[CW], r[CW], r2[CW];
-#pragma unroll
-                    for (int q4 = 0; q4 < CW / 4; ++q4)
-                      *reinterpret_cast<f32x4*>(v + 4 * q4) = *reinterpret_cast<const f32x4*>(Cs + ll * BN + c4 * CW + 4 * q4);
-#pragma unroll
-                    for (int q4 = 0; q4 < CW / 4; ++q4)
-#pragma unroll
-                      for (int e = 0; e < 4; ++e) {
-                        float pr = v[4 * q4 + e] * gq[ps % RING][0][q4][e];
-                        pr += gq[ps % RING][1][q4][e] * gq[ps % RING][2][q4][e];
-                        r[4 * q4 + e] = pr;
-                        r2[4 * q4 + e] = pr * gq[ps % RING][3][q4][e];
-                      }
-                    float* dst = a.out + (size_t)row * a.N + col;
-                    float* d2 = a.out2s + (size_t)row * a.N + col;
-                    if constexpr (SPLIT_OUT) {
-                      if (plain) {
-                        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
-                        *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(r + 4);
-                      } else {
-                        split8_store(r, dst);
-                      }
-                      split8_store(r2, d2);
-                    } else {
-                      *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(r);
-                      *reinterpret_cast<f32x4*>(d2) = *reinterpret_cast<const f32x4*>(r2);
-                    }
-                  }
-                }
-                continue;                                 // next slab
-              }
-            }
+            // (A counted-prefetch form of the join + second-head epilogue — the tail of a ResNet identity block — was built here in
+            //  round 4: config 4 -0.5 ms, but its mere presence in this instantiation cost the VGG walk's launches 2.4 %
+            //  [MI355X, same box: 24.55 -> 25.15 ms, WRITE_SIZE +11 %: the register allocator spilled], so it was taken out
+            //  again; those launches are bound by their three full-width streams either way)
           }
           constexpr int NP = RH / RPP;
           constexpr int UPN = EPI == EPI_MUL_UP2 ? 4 : 1;
