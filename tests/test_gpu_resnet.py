@@ -25,7 +25,10 @@ def _engine(stacks, stem, hw, B, ntok, w, decoder="gridtd", H=32, V=50):
 
 @pytest.mark.parametrize("prec", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("name,stacks,stem,hw,B", [("tiny", ((4, 2), (8, 2)), 8, 32, 2),      # widths % 8 != 0: fp32 either way
-                                                   ("mid", ((8, 2), (16, 3), (32, 2)), 16, 64, 2)])
+                                                   ("mid", ((8, 2), (16, 3), (32, 2)), 16, 64, 2),
+                                                   # 64-channel stem on a 96 x 96 image: the fused stem reverse (rn_stem_reverse_kernel:
+                                                   # 4 x 4 patches of the 48 x 48 stem map, the last ones ragged), pair-emitting forward
+                                                   ("stem64", ((32, 2), (64, 2)), 64, 96, 2)])
 def test_small_resnets_match_oracle(name, stacks, stem, hw, B, prec):
     rs = np.random.RandomState(3)
     w = resnet_weights(rs, stacks, stem=stem, bias_std=0.2)
