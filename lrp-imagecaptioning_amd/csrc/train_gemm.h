@@ -27,6 +27,9 @@ struct SgemmArgs {
   float* ws;
   int gather, gH, gW, dy, dx;   // transA only: row r = (n*gH + y)*gW + x reads row r + dy*gW + dx, zero outside the image
   int taps; long tapC;          // gather with taps = 9: blockIdx.z / ksplit = tap (dy, dx from it), C advances by tapC per tap
+  // without gather, taps > 1 = a strided BATCH of products of one shape in one launch: product p reads A + p * batchA and
+  // B + p * batchB and writes C + p * tapC (the four per-gate products of an LSTM step under keras' per-gate dropout masks)
+  long batchA, batchB;
   int vecA, vecB;          // 16 B loads allowed (alignment checked on the host)
   const float* bias;       // optional: + bias[n] on the final result (not with accumulate)
   // second product of the same shape in the same launch (consumer-side reduction only, sgemm(..., ks_out)): the upper half
@@ -112,7 +115,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmArgs a) {
     a.A = a.A2; a.B = a.B2; a.ws = a.ws2; a.C = a.ws2;
   }
   const int tap = a.taps > 1 ? bz / a.ksplit : 0, slice = a.taps > 1 ? bz % a.ksplit : bz;
-  if (a.taps > 1) { a.dy = tap / 3 - 1; a.dx = tap % 3 - 1; }
+  if (a.taps > 1) {
+    if (a.gather) { a.dy = tap / 3 - 1; a.dx = tap % 3 - 1; }
+    else { a.A += (long)tap * a.batchA; a.B += (long)tap * a.batchB; }
+  }
   const long kb = (long)slice * a.kchunk;
   const long ke = kb + a.kchunk < a.K ? kb + a.kchunk : a.K;
   sg_f32x16 acc[TM][TN];
@@ -227,15 +233,16 @@ inline void sgemm_launch_tile(int tm, int tn, dim3 grid, hipStream_t st, const S
 inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st, int* ks_out = nullptr) {
   if (a.M < 1 || a.N < 1 || a.K < 1) return hipErrorInvalidValue;
   if (ks_out) {
-    if (!ws || (size_t)a.M * a.N > ws_floats || (a.gather && a.taps > 1) || a.accumulate) return hipErrorInvalidValue;
+    if (!ws || (size_t)a.M * a.N > ws_floats || a.taps > 1 || a.accumulate) return hipErrorInvalidValue;
     a.C = ws; a.ldc = a.N; a.bias = nullptr;           // (a single slice writes straight to slab 0)
     if (a.A2 && (!a.B2 || !a.ws2 || !sg_aligned(a.A2, a.lda) != !sg_aligned(a.A, a.lda) || !sg_aligned(a.B2, a.ldb) != !sg_aligned(a.B, a.ldb)))
       return hipErrorInvalidValue;                     // (the pair shares one set of launch parameters)
   } else if (a.A2) {
     return hipErrorInvalidValue;
   }
-  a.vecA = sg_aligned(a.A, a.lda) ? 1 : 0;
-  a.vecB = sg_aligned(a.B, a.ldb) ? 1 : 0;
+  const bool batch = !a.gather && a.taps > 1;
+  a.vecA = sg_aligned(a.A, a.lda) && (!batch || !(a.batchA & 3)) ? 1 : 0;
+  a.vecB = sg_aligned(a.B, a.ldb) && (!batch || !(a.batchB & 3)) ? 1 : 0;
   int tm = a.M <= 64 ? 1 : 2, tn = a.N <= 64 ? 1 : 2;
   if (a.K >= 4096) {                                       // 256 x 128 tiles: 1.5x the FLOPs per byte staged
     if (a.M >= 256 && a.N >= 128) tm = 4;
@@ -243,7 +250,7 @@ inline hipError_t sgemm(SgemmArgs a, float* ws, size_t ws_floats, hipStream_t st
   }
   const int gx = (a.N + 64 * tn - 1) / (64 * tn), gy = (a.M + 64 * tm - 1) / (64 * tm);
   int ks = 1;
-  const int taps = a.gather && a.taps > 1 ? a.taps : 1;
+  const int taps = a.taps > 1 ? a.taps : 1;             // nine gathered taps, or a strided batch
   a.taps = taps;
   const long steps = (a.K + SG_BK - 1) / SG_BK;
   const long tiles = (long)gx * gy * taps;

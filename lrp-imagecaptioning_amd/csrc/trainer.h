@@ -177,6 +177,24 @@ struct Trainer {
     LRP_HIP_CHECK(sgemm(a, ws.as<float>(), ws_floats, st));
     return LRP_OK;
   }
+  // `nb` products of one shape in one launch: product p on A + p * sA, B + p * sB -> C + p * sC (train_gemm.h: strided batch).
+  // The per-gate products of an LSTM step under keras' per-gate dropout masks were four launches (+ four reduce passes) each.
+  int mm_batch(int nb, bool ta, bool tb, int M, int N, long K, const float* A, long lda, long sA, const float* Bp, long ldb, long sB,
+               float* C, long ldc, long sC, bool acc, hipStream_t st) {
+    SgemmArgs a{};
+    a.A = A; a.B = Bp; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.transA = ta; a.transB = tb; a.accumulate = acc;
+    a.taps = nb; a.batchA = sA; a.batchB = sB; a.tapC = sC;
+    LRP_HIP_CHECK(sgemm(a, ws.as<float>(), ws_floats, st));
+    return LRP_OK;
+  }
+  // two products of one shape whose operands sit anywhere in device memory: a batch of two whose strides are the operands'
+  // distances (the attention's h . W_h and s . W_s of a step, forward and backward)
+  int mm_pair(bool ta, bool tb, int M, int N, long K, const float* A0, const float* A1, long lda, const float* B0, const float* B1, long ldb,
+              float* C0, float* C1, long ldc, bool acc, hipStream_t st) {
+    const long sA = A1 - A0, sB = B1 - B0, sC = C1 - C0;
+    return mm_batch(2, ta, tb, M, N, K, A0, lda, sA, B0, ldb, sB, C0, ldc, sC, acc, st);
+  }
   static unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 4096); }
 
   // One step: gradients of 0.5 CE(y, logits) + 0.5 CE(y, logits * lrp_weight) for the B images last encoded.
@@ -362,8 +380,8 @@ struct Trainer {
     const int B = in.B, T = in.T;
     const size_t BH = (size_t)B * H;
     hipStream_t st = in.st;
-    LRP_TRY(mm(false, false, B, H, H, Hst.as<float>() + t * BH, H, W(nm_hatt()), H, HW.as<float>() + t * BH, H, false, st));
-    LRP_TRY(mm(false, false, B, H, H, Sst.as<float>() + t * BH, H, W(nm_satt()), H, SW.as<float>() + t * BH, H, false, st));
+    LRP_TRY(mm_pair(false, false, B, H, H, Hst.as<float>() + t * BH, Sst.as<float>() + t * BH, H, W(nm_hatt()), W(nm_satt()), H,
+                    HW.as<float>() + t * BH, SW.as<float>() + t * BH, H, false, st));
     hipLaunchKernelGGL(tr_att_scores_kernel, dim3(B, (L + 3) / 4), dim3(256), 0, st, proj.as<float>(), HW.as<float>() + t * BH, W(nm_vatt()),
                        Esc.as<float>(), L, H);
     hipLaunchKernelGGL(tr_att_mix_kernel, dim3(B, (H + 63) / 64), dim3(256), (size_t)(L + 8 + 256) * 4, st, Esc.as<float>(), Vf.as<float>(),
@@ -384,8 +402,8 @@ struct Trainer {
                        HW.as<float>() + t * BH, SW.as<float>() + t * BH, W(nm_vatt()), ALPHA.as<float>() + (size_t)t * B * L,
                        BETA.as<float>() + (size_t)t * B, Esc.as<float>(), dBeta.as<float>(), dCtx.as<float>(), DZS.as<float>() + t * BH,
                        DHW.as<float>() + t * BH, dProj.as<float>(), dVf.as<float>(), dVacc.as<float>(), L, H);
-    LRP_TRY(mm(false, true, B, H, H, DZS.as<float>() + t * BH, H, W(nm_satt()), H, dS.as<float>(), H, true, st));
-    LRP_TRY(mm(false, true, B, H, H, DHW.as<float>() + t * BH, H, W(nm_hatt()), H, dHtot.as<float>(), H, true, st));
+    LRP_TRY(mm_pair(false, true, B, H, H, DZS.as<float>() + t * BH, DHW.as<float>() + t * BH, H, W(nm_satt()), W(nm_hatt()), H,
+                    dS.as<float>(), dHtot.as<float>(), H, true, st));
     return LRP_OK;
   }
 
@@ -410,8 +428,7 @@ struct Trainer {
         if (in.m_lrec) {
           float* h4 = H4.as<float>() + (size_t)t * BH;
           hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(BH)), dim3(256), 0, st, hp, in.m_lrec, h4, B, B, H, t, hs);
-          for (int gt = 0; gt < 4; ++gt)
-            LRP_TRY(mm(false, false, B, H, H, h4 + gt * hs, H, W("lstm_Wh") + gt * H, 4 * H, zt + gt * H, 5 * H, true, st));
+          LRP_TRY(mm_batch(4, false, false, B, H, H, h4, H, (long)hs, W("lstm_Wh"), 4 * H, H, zt, 5 * H, H, true, st));
         } else {
           LRP_TRY(mm(false, false, B, 4 * H, H, hp, H, W("lstm_Wh"), 4 * H, zt, 5 * H, true, st));
         }
@@ -441,8 +458,7 @@ struct Trainer {
       if (t > 0) {
         if (in.m_lrec) {
           float* p4 = P4.as<float>();
-          for (int gt = 0; gt < 4; ++gt)
-            LRP_TRY(mm(false, true, B, H, H, dzt + gt * H, 5 * H, W("lstm_Wh") + gt * H, 4 * H, p4 + gt * BH, H, false, st));
+          LRP_TRY(mm_batch(4, false, true, B, H, H, dzt, 5 * H, H, W("lstm_Wh"), 4 * H, H, p4, H, (long)BH, false, st));
           hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, p4, in.m_lrec, dH.as<float>(), B, B, H, t, BH);
         } else {
           LRP_TRY(mm(false, true, B, H, 4 * H, dzt, 5 * H, W("lstm_Wh"), 4 * H, dH.as<float>(), H, false, st));
@@ -511,8 +527,7 @@ struct Trainer {
         // masked copies of both halves of x2: X4 rows [g][t][b][2H]; products per gate
         float* x4 = X4.as<float>() + (size_t)t * B * 2 * H;
         hipLaunchKernelGGL(tr_gate_masks2_kernel, dim3(grid_for((size_t)B * 2 * H)), dim3(256), 0, st, chat, h1, in.m_lin, x4, B, H, t, xs);
-        for (int gt = 0; gt < 4; ++gt)
-          LRP_TRY(mm(false, false, B, H, 2 * H, x4 + gt * xs, 2 * H, W("lang_Wi") + gt * H, 4 * H, z2t + gt * H, 4 * H, false, st));
+        LRP_TRY(mm_batch(4, false, false, B, H, 2 * H, x4, 2 * H, (long)xs, W("lang_Wi"), 4 * H, H, z2t, 4 * H, H, false, st));
       } else {
         LRP_TRY(mm(false, false, B, 4 * H, H, chat, H, W("lang_Wi"), 4 * H, z2t, 4 * H, false, st));
         LRP_TRY(mm(false, false, B, 4 * H, H, h1, H, W("lang_Wi") + (size_t)H * 4 * H, 4 * H, z2t, 4 * H, true, st));
@@ -521,8 +536,7 @@ struct Trainer {
         if (in.m_lrec) {
           float* h4 = H4.as<float>() + (size_t)t * BH;
           hipLaunchKernelGGL(tr_gate_masks_kernel, dim3(grid_for(BH)), dim3(256), 0, st, h2p, in.m_lrec, h4, B, B, H, t, hs);
-          for (int gt = 0; gt < 4; ++gt)
-            LRP_TRY(mm(false, false, B, H, H, h4 + gt * hs, H, W("lang_Wh") + gt * H, 4 * H, z2t + gt * H, 4 * H, true, st));
+          LRP_TRY(mm_batch(4, false, false, B, H, H, h4, H, (long)hs, W("lang_Wh"), 4 * H, H, z2t, 4 * H, H, true, st));
         } else {
           LRP_TRY(mm(false, false, B, 4 * H, H, h2p, H, W("lang_Wh"), 4 * H, z2t, 4 * H, true, st));
         }
@@ -556,8 +570,7 @@ struct Trainer {
       // back through x2 = [c_hat | h1] (and the cell's input masks): d c_hat += ..., d h1 (carry dH) += ...
       if (in.m_lin) {
         float* p4 = P4.as<float>();
-        for (int gt = 0; gt < 4; ++gt)
-          LRP_TRY(mm(false, true, B, 2 * H, H, dz2t + gt * H, 4 * H, W("lang_Wi") + gt * H, 4 * H, p4 + gt * (size_t)B * 2 * H, 2 * H, false, st));
+        LRP_TRY(mm_batch(4, false, true, B, 2 * H, H, dz2t, 4 * H, H, W("lang_Wi"), 4 * H, H, p4, 2 * H, (long)B * 2 * H, false, st));
         hipLaunchKernelGGL(tr_gate_masks2_bwd_kernel, dim3(grid_for((size_t)B * 2 * H)), dim3(256), 0, st, p4, in.m_lin, DCH.as<float>(),
                            dH.as<float>(), B, H, t);
       } else {
@@ -567,8 +580,7 @@ struct Trainer {
       if (t > 0) {                                    // carry into h2_{t-1} through the recurrent kernel
         if (in.m_lrec) {
           float* p4 = P4.as<float>();
-          for (int gt = 0; gt < 4; ++gt)
-            LRP_TRY(mm(false, true, B, H, H, dz2t + gt * H, 4 * H, W("lang_Wh") + gt * H, 4 * H, p4 + gt * BH, H, false, st));
+          LRP_TRY(mm_batch(4, false, true, B, H, H, dz2t, 4 * H, H, W("lang_Wh"), 4 * H, H, p4, H, (long)BH, false, st));
           hipLaunchKernelGGL(tr_gate_masks_bwd_kernel, dim3(grid_for(BH)), dim3(256), 0, st, p4, in.m_lrec, dH2.as<float>(), B, B, H, t, BH);
         } else {
           LRP_TRY(mm(false, true, B, H, 4 * H, dz2t, 4 * H, W("lang_Wh"), 4 * H, dH2.as<float>(), H, false, st));
