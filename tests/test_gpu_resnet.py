@@ -197,6 +197,34 @@ def test_a_photograph_through_resnet101_and_gridtd(pic):
     assert same
 
 
+def test_resnet101_walk_is_linear_zero_preserving_and_reproducible():
+    """Size-independent properties of the ResNet walk at full size (no oracle needed): analyze(3 R1 - 2 R2) = 3 analyze(R1) -
+    2 analyze(R2) (the walk is a linear map once the forward's gates are fixed: what is left is the rounding of the split-bf16
+    operands), zero relevance in -> exactly zero out, powers of two scale exactly, and a second call returns the same bits
+    (no atomics on the data path: the fused stem reverse and the fixed-order joins included)."""
+    import torch
+    rs = np.random.RandomState(6)
+    w = resnet_weights(rs)
+    X = rs.uniform(-120, 130, size=(2, 224, 224, 3)).astype(np.float32)
+    eng, side, D = _engine(RESNET101_STACKS, 64, 224, 2, 6, w)
+    eng.encode_images(X)
+    feat = eng.get_features().cpu().numpy().reshape(2, side, side, D)
+    Ra = (rs.standard_normal(feat[1].shape) * feat[1]).astype(np.float32)
+    Rb = (rs.standard_normal(feat[1].shape) * feat[1]).astype(np.float32)
+    R = np.stack([Ra, Rb, 3 * Ra - 2 * Rb, np.zeros_like(Ra), 4.0 * Ra, (rs.standard_normal(feat[0].shape) * feat[0]).astype(np.float32)])
+    idx = [1, 1, 1, 1, 1, 0]
+    out = eng.cnn_explain(idx, R).clone()
+    again = eng.cnn_explain(idx, R)
+    assert torch.equal(out, again)
+    o = out.cpu().numpy()
+    lin = rel_l1(o[2], 3 * o[0] - 2 * o[1])
+    report("resnet101_linearity", rel_l1=lin)
+    assert lin < 2e-5
+    assert (o[3] == 0).all()
+    assert np.array_equal(o[4], 4.0 * o[0])
+    assert np.isfinite(o).all()
+
+
 def test_config4_gridtd_plus_resnet_end_to_end():
     """grid-TD decoder on a ResNet encoder (BASELINE config 4 at reduced size): decoder LRP -> CNN LRP fused call."""
     stacks, stem, hw, H, V = ((4, 2), (8, 2)), 8, 32, 32, 50
