@@ -39,7 +39,7 @@ struct Switches {
   int tile_order = 1;       // LRP_TILE_ORDER=0    reverse-walk launches in stack order
   int fwd_emit = 1;         // LRP_FWD_EMIT=0      forward: split / absmax / pool passes between the convs
   int fwd_il = 1;           // LRP_FWD_IL=0        dual forward matrix with stacked rows: separate gate pass (decided when lrp_set_weight packs)
-  int img_fused = 1;        // LRP_IMG_FUSED=0     image layer as T GEMM + separate stencil kernel
+  int img_fused = 1;        // LRP_IMG_FUSED=0     image layer as T GEMM + separate stencil kernel (VGG16 and the ResNet stem)
   int up2_compact = 1;      // LRP_UP2_COMPACT=0   expanded pool interface between block2_conv1 and block1_conv2
   int up2_gc = 1;           // LRP_UP2_GC=0        that interface with the full-resolution pool gate
   int up2_breg_pairs = 1;   // LRP_UP2_BREG_PAIRS=0  block2_conv1 writes its plain fp32 product instead of pairs

@@ -218,7 +218,12 @@ def test_resnet101_walk_is_linear_zero_preserving_and_reproducible():
     assert torch.equal(out, again)
     o = out.cpu().numpy()
     lin = rel_l1(o[2], 3 * o[0] - 2 * o[1])
-    report("resnet101_linearity", rel_l1=lin)
+    from lrp_imagecaptioning_amd.engine import switches
+    with switches(LRP_IMG_FUSED=0):                       # the stem's reverse as 1-tap GEMM + gather kernel: the same sums, another order
+        unfused = eng.cnn_explain(idx, R).cpu().numpy()
+    stem_ab = max(rel_l1(o[i], unfused[i]) for i in (0, 1, 5))
+    report("resnet101_linearity", rel_l1=lin, fused_stem_vs_two_kernels=stem_ab)
+    assert stem_ab < 1e-6
     assert lin < 2e-5
     assert (o[3] == 0).all()
     assert np.array_equal(o[4], 4.0 * o[0])
