@@ -15,6 +15,7 @@ The line is self-certifying (N = 1): besides the timed default mode (split-bf16 
 every layer, 16 mantissa bits on both operands — parity independent of the weight statistics) the same invocation
   * times the exact-fp32 mode on the same batch              -> "fp32_mode"  {value, ms_per_step, roofline}
   * times the opt-in two-MFMA fp16 walk on the same batch    -> "fast_mode"  {value, ms_per_step, parity}
+  * times the opt-in 2:4-sparse pooled boundaries            -> "sparse_pool_mode" {value, ms_per_step, distance from the default path}
     (one fp16 per weight below the top block: faster, but its error depends on the weights; lrp_hip.h)
   * checks sampled heat-maps of the timed batch, in every mode, against the CPU oracle
     (outside the timed region)                               -> "parity"     {bf16x3, fp32, f16x2: worst relative L1}
@@ -562,6 +563,26 @@ def main():
         pipe.set_fast_layers(None)
         pipe.set_precision(args.precision)
 
+    # ---- and with the two >= 256-column pooled boundaries of the walk on the 2:4-sparse matrix cores (opt-in LRP_SPARSE_POOL=1,
+    # below the 25 % per-launch gain that would make it the default, and it would end B = 1 == B = 32 to the bit)
+    sparse_block = None
+    if extras and not args.no_fp32_mode and args.precision == "bf16x3":
+        from lrp_imagecaptioning_amd.engine import switches
+        pipe.reset()
+        with switches(LRP_SPARSE_POOL=1):
+            ksp = max(2, min(args.steps, 10))
+            dtsp = timed_run(2, ksp)
+            sp_maps = sampled("bf16x3")
+        sparse_block = {"value": round(B * T * ksp / dtsp, 2), "unit": "heatmaps/s", "steps": ksp, "warmup": 2,
+                        "ms_per_step": round(dtsp / ksp * 1e3, 3), "dtype": "bf16x3",
+                        "what": "LRP_SPARSE_POOL=1: block4_conv3 / block3_conv3 of the walk as v_smfmac_f32_32x32x32_bf16 launches "
+                                "(12 slots per channel instead of 9 dense taps x 4 window positions)"}
+        if got.get(args.precision):
+            ref_maps = got[args.precision]
+            sparse_block["rel_l1_vs_default_path"] = float(max(
+                np.abs(sp_maps[k].astype(np.float64) - ref_maps[k]).sum() / np.abs(ref_maps[k].astype(np.float64)).sum() for k in ref_maps))
+        pipe.reset()
+
     # ---- the reference's actual call: ONE image, explain every word of its caption (explain_image.py:152-161 ->
     # E:183-189): host clock around encode -> decoder replay -> T heat-maps -> device synchronise, on a B = 1 handle
     latency_block = None
@@ -612,6 +633,8 @@ def main():
             res["fp32_mode"] = fp32_block
         if fast_block:
             res["fast_mode"] = fast_block
+        if sparse_block:
+            res["sparse_pool_mode"] = sparse_block
         if sustained_block:
             res["sustained"] = sustained_block
         if world > 1:
