@@ -124,3 +124,37 @@ def test_switch_against_the_default_path(setup, name, value, tol_batch, tol_one)
     # and the default path is back afterwards
     back = run()
     assert torch.equal(back[0], ref[0]) and torch.equal(back[1], ref[1])
+
+
+def test_fused_pool_with_a_ragged_image_stack():
+    """The pool in the conv epilogue (ConvArgs::pool_gc) on FIVE images: the stack of block4's 28-row maps is 140 rows = 17.5
+    tiles of 8 rows — tiles that straddle two images and a last one that runs past the stack — and 5 x 10 heat-maps later every
+    bit equals the pass-behind-the-conv form, and the walk through the EXPANDED pool interfaces (LRP_UP2_COMPACT=0, LRP_UP2_PW=0:
+    every pooled layer's full-resolution gate, rebuilt on demand from the compact one by Encoder::full_gate) does too."""
+    import bench
+    from lrp_imagecaptioning_amd.engine import LRPEngine, switches
+    Bq, Tq = 5, 4
+    w = bench.synth_weights(0, V)
+    rs = np.random.RandomState(77)
+    X = torch.as_tensor(images(rs, Bq)).cuda()
+    caps = captions(rs, Bq, Tq, V)
+    eng = LRPEngine(decoder="adaptive", V=V, max_images=Bq, max_tokens=Bq * Tq, max_caption_len=Tq + 1)
+    eng.set_weights(w)
+    idx = [b for b in range(Bq) for _ in range(Tq)]
+    tpos = [t for _ in range(Bq) for t in range(1, Tq + 1)]
+
+    def run():
+        eng.encode_images(X)
+        eng.decoder_forward(caps)
+        hm = eng.explain_tokens(idx, tpos)[0].clone()
+        feat = eng.get_features()
+        R = (feat[[0, 4]] * 0.5).contiguous()
+        given = eng.cnn_explain([0, 4], R).clone()         # (the CNN half alone, on a given relevance)
+        return hm, given
+    a = run()
+    with switches(LRP_POOL_FUSED=0):
+        b = run()
+    with switches(LRP_UP2_COMPACT=0, LRP_UP2_PW=0):        # expanded interfaces: every pooled layer's full-resolution gate is read
+        c = run()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
